@@ -1,0 +1,159 @@
+/* vo_hip.h — C ABI of libvo_hip.so: the MI355X (gfx950) per-frame-pair visual-odometry front end.
+ *
+ * Drop-in boundary.  The reference (Samirez/Visual_odometry) is pure Python and reaches its
+ * arithmetic through five cv2 calls; this library replaces exactly those calls with
+ * hand-written HIP kernels.  Each entry point cites the reference call it stands in for
+ * (paths relative to the reference repository root).  Host code binds it with ctypes
+ * (visual_odometry_amd/_lib.py); no torch types, plain pointers and sizes only.
+ *
+ * Conventions: every function returns 0 on success, > 0 for a completed call with a warning
+ * (VO_WARN_*), < 0 on error (VO_ERR_*); vo_last_error(ctx) gives the message.  All pointer
+ * arguments are HOST memory owned by the caller unless a name ends in _dev.  One vo_ctx per
+ * (thread, device); a ctx owns its device buffers and one HIP stream; calls are synchronous.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_MAX_LEVELS 16
+
+#define VO_OK                 0
+#define VO_WARN_CAPACITY      1   /* a candidate / keypoint list hit its capacity and was truncated */
+#define VO_ERR_INVALID       -1
+#define VO_ERR_HIP           -2
+#define VO_ERR_TOO_FEW       -3   /* fewer than 5 correspondences (cv2.findEssentialMat returns None) */
+#define VO_ERR_NO_MODEL      -4   /* RANSAC found no model with > 4 inliers */
+#define VO_ERR_NOT_CONFIGURED -5
+
+typedef struct vo_ctx vo_ctx;
+
+/* cv2.ORB_create(...) parameters — src/image_and_keypoints.py:8 (all defaults), overridden by
+ * BASELINE configs (nfeatures 500/2000/4000, nlevels 8/4). */
+typedef struct {
+    int32_t nfeatures;       /* 500  */
+    float   scale_factor;    /* 1.2f */
+    int32_t nlevels;         /* 8    */
+    int32_t edge_threshold;  /* 31   */
+    int32_t first_level;     /* 0  (only 0 supported) */
+    int32_t wta_k;           /* 2  (only 2 supported) */
+    int32_t score_type;      /* 0 = HARRIS_SCORE, 1 = FAST_SCORE */
+    int32_t patch_size;      /* 31 (only 31 supported) */
+    int32_t fast_threshold;  /* 20 */
+} vo_orb_params;
+
+/* ------------------------------------------------------------------ lifetime */
+int         vo_create(int device_id, vo_ctx** out);
+void        vo_destroy(vo_ctx* ctx);
+const char* vo_last_error(const vo_ctx* ctx);
+int         vo_version(void);
+
+/* ------------------------------------------------------------------ single-call operators */
+
+/* detector.detectAndCompute(image, None) — src/frame_generator.py:25-26, src/image_and_keypoints.py:46.
+ * img: h x w x channels u8 (1 = gray, 3 = BGR, 4 = BGRA).  Outputs hold up to cap keypoints in
+ * canonical order (octave, y, x); desc is cap x 32 bytes. */
+int vo_orb_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                              const vo_orb_params* params,
+                              float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                              int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);
+
+/* self.matcher.match(d1, d2) for cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=...) —
+ * src/image_pair.py:234-236, matcher built at src/visual_slam.py:18 / src/image_and_keypoints.py:9.
+ * cross_check: 0 = nearest neighbour, 1 = cv2 crossCheck=True semantics, 2 = strict mutual NN.
+ * Outputs (capacity nq) are ordered by ascending queryIdx. */
+int vo_match_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int cross_check,
+                     int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
+
+/* matcher.knnMatch(d1, d2, k=2) + `m.distance < ratio * n.distance` — src/feature_detection.py:20-26. */
+int vo_knn2_ratio_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
+                          int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
+
+/* cv2.findEssentialMat(p1, p2, K, cv2.FM_RANSAC, prob, thresh) — src/image_pair.py:280-286.
+ * p1, p2: M x 2 float64 pixel coordinates; K: 3x3 row-major; seed: OpenCV's RNG seed 2^64-1.
+ * E: 9 doubles (M == 5: up to 10 stacked models, n_models tells how many); mask: M bytes (0/1). */
+int vo_find_essential_ransac(vo_ctx* ctx, const double* p1, const double* p2, int M, const double* K,
+                             double prob, double thresh_px, int max_iters, uint64_t seed,
+                             double* E, uint8_t* mask, int32_t* n_inl, int32_t* n_models);
+
+/* cv2.recoverPose(E, p1, p2, K) — src/image_pair.py:304-308 (distanceThresh 50).
+ * R: 9, t: 3 (unit norm), mask: M bytes (0/255, may be NULL). */
+int vo_recover_pose(vo_ctx* ctx, const double* E, const double* p1, const double* p2, int M, const double* K,
+                    double dist_thresh, double* R, double* t, uint8_t* mask, int32_t* n_good);
+
+/* cv2.triangulatePoints(P1, P2, x1, x2) — src/image_pair.py:332-336. x1, x2: 2 x M; X: 4 x M
+ * (NOT normalised by w; the caller divides, as src/image_pair.py:339 does). */
+int vo_triangulate(vo_ctx* ctx, const double* P1, const double* P2, const double* x1, const double* x2,
+                   int M, double* X);
+
+/* ------------------------------------------------------------------ stage outputs (parity tests) */
+/* gray + INTER_LINEAR_EXACT pyramid, levels packed tightly one after the other */
+int vo_stage_pyramid(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                     const vo_orb_params* params, uint8_t* out_packed);
+/* per level: FAST-9/16 score after 3x3 NMS (dense, packed like the pyramid) and the 7x7 blur */
+int vo_stage_fast_scores(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                         const vo_orb_params* params, uint8_t* out_packed);
+int vo_stage_blur(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                  const vo_orb_params* params, uint8_t* out_packed);
+/* EMEstimatorCallback::runKernel on one 5-point sample of normalised coordinates */
+int vo_stage_five_point(vo_ctx* ctx, const double* x1, const double* x2, double* E /*10x9*/, int32_t* n_models);
+
+/* ------------------------------------------------------------------ batched, device-resident path
+ * The throughput path: frames live in HBM, every stage runs batch-major on the ctx stream,
+ * nothing returns to the host between stages.  Mirrors the per-pair order of
+ * src/visual_slam.py:294-298 (match_features -> determine_essential_matrix ->
+ * estimate_camera_movement -> reconstruct_3d_points). */
+typedef struct {
+    int32_t match_mode;     /* 0 = BFMatcher(crossCheck=True).match, 1 = knnMatch(k=2) + ratio */
+    double  ratio;          /* ratio for match_mode 1 */
+    double  ransac_prob;    /* 0.99  src/image_pair.py:278 */
+    double  ransac_thresh;  /* 1.0   src/image_pair.py:279 */
+    int32_t ransac_max_iters; /* 1000 (cv2 default) */
+    uint64_t ransac_seed;   /* 0xFFFFFFFFFFFFFFFF */
+    double  pose_dist_thresh; /* 50 */
+    int32_t want_points;    /* also triangulate (reconstruct_3d_points) */
+} vo_pair_opts;
+
+typedef struct {
+    int32_t n_kp1, n_kp2, n_match, n_inl, n_good, status, ransac_iters, reserved;
+    double  R[9], t[3], E[9];
+} vo_pair_result;
+
+/* (re)allocate device buffers for frames of h x w, up to max_frames resident frames and
+ * max_pairs pairs per vo_pair_batch call */
+int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params* params, int max_frames, int max_pairs);
+/* copy F gray frames (u8, row_stride/frame_stride in bytes) into slots [first_slot, first_slot+F) */
+int vo_frames_upload(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot);
+/* detect + describe slots [first_slot, first_slot+F); results stay on the device */
+int vo_frames_detect(vo_ctx* ctx, int first_slot, int F);
+/* download one slot's keypoints / descriptors (capacity cap) */
+int vo_frame_features(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                      int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);
+/* run match + E-RANSAC + pose (+ triangulation) for B pairs of already detected slots.
+ * pair_slots: B x 2 int32.  results: B entries.  X (optional, may be NULL): B x 4 x x_cap
+ * doubles, w normalised to 1; the first n_inl columns of each are valid. */
+int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
+                 vo_pair_result* results, double* X, int32_t x_cap);
+/* per-pair match list of the last vo_pairs_run (capacity cap each) */
+int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* dist, uint8_t* inlier_mask,
+                    int cap, int32_t* n_out);
+
+/* ------------------------------------------------------------------ measurement
+ * With profiling on, every kernel family of the batched path is bracketed by hipEvents on the
+ * ctx stream; vo_profile_read returns accumulated milliseconds and launch counts per stage since
+ * the last vo_profile_reset. */
+#define VO_STAGE_COUNT 16
+int vo_profile_enable(vo_ctx* ctx, int on);
+int vo_profile_reset(vo_ctx* ctx);
+int vo_profile_read(vo_ctx* ctx, float* ms /*VO_STAGE_COUNT*/, int32_t* launches /*VO_STAGE_COUNT*/);
+const char* vo_stage_name(int stage);
+/* algorithmic HBM bytes one launch of `stage` moves for F frames of the configured geometry */
+double vo_stage_bytes(vo_ctx* ctx, int stage, int F);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

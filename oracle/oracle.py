@@ -1,0 +1,231 @@
+"""ctypes wrapper over oracle/libvoo.so — the CPU ORACLE (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under visual_odometry_amd/ does.  PARITY UNPINNED (see oracle/voo.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
+                ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32)]
+
+
+class PairResult(C.Structure):
+    _fields_ = [("n_kp1", C.c_int32), ("n_kp2", C.c_int32), ("n_match", C.c_int32),
+                ("n_inl_E", C.c_int32), ("n_good_pose", C.c_int32),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("E", C.c_double * 9)]
+
+
+def orb_params(nfeatures=500, scale_factor=1.2, nlevels=8, edge_threshold=31, first_level=0,
+               wta_k=2, score_type=0, patch_size=31, fast_threshold=20):
+    return OrbParams(nfeatures, scale_factor, nlevels, edge_threshold, first_level, wta_k,
+                     score_type, patch_size, fast_threshold)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libvoo.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "libvoo.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def level_geometry(h, w, params):
+    L = params.nlevels
+    lw = np.zeros(L, np.int32); lh = np.zeros(L, np.int32); q = np.zeros(L, np.int32)
+    ls = np.zeros(L, np.float32)
+    rc = lib().voo_level_geometry(h, w, C.byref(params), _p(lw, C.c_int32), _p(lh, C.c_int32),
+                                  _p(ls, C.c_float), _p(q, C.c_int32))
+    assert rc == 0
+    return lw, lh, ls, q
+
+
+def gray(img):
+    img = _u8(img)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((h, w), np.uint8)
+    rc = lib().voo_gray(_p(img, C.c_uint8), h, w, ch, img.strides[0], _p(out, C.c_uint8))
+    assert rc == 0
+    return out
+
+
+def resize_linear_exact(src, dw, dh):
+    src = _u8(src)
+    sh, sw = src.shape
+    dst = np.empty((dh, dw), np.uint8)
+    rc = lib().voo_resize_linear_exact(_p(src, C.c_uint8), sw, sh, sw, _p(dst, C.c_uint8), dw, dh, dw)
+    assert rc == 0
+    return dst
+
+
+def pyramid(gray_img, params):
+    g = _u8(gray_img)
+    h, w = g.shape
+    lw, lh, _, _ = level_geometry(h, w, params)
+    total = int((lw.astype(np.int64) * lh).sum())
+    out = np.empty(total, np.uint8)
+    rc = lib().voo_pyramid(_p(g, C.c_uint8), h, w, C.byref(params), _p(out, C.c_uint8))
+    assert rc == 0
+    levels, off = [], 0
+    for l in range(params.nlevels):
+        n = int(lw[l]) * int(lh[l])
+        levels.append(out[off:off + n].reshape(int(lh[l]), int(lw[l])))
+        off += n
+    return levels
+
+
+def fast_score_nms(img, threshold=20):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    rc = lib().voo_fast_score_nms(_p(img, C.c_uint8), w, h, w, threshold, _p(out, C.c_uint8))
+    assert rc == 0
+    return out
+
+
+def gaussian_blur7(img):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.uint8)
+    rc = lib().voo_gaussian_blur7(_p(img, C.c_uint8), w, h, w, _p(out, C.c_uint8), w)
+    assert rc == 0
+    return out
+
+
+def orb_detect_and_compute(img, params, cap=None):
+    img = _u8(img)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    cap = cap or (params.nfeatures * 2 + 4096)
+    xy = np.zeros((cap, 2), np.float32); size = np.zeros(cap, np.float32)
+    ang = np.zeros(cap, np.float32); resp = np.zeros(cap, np.float32)
+    octv = np.zeros(cap, np.int32); desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int32(0)
+    rc = lib().voo_orb_detect_and_compute(_p(img, C.c_uint8), h, w, ch, img.strides[0], C.byref(params),
+                                          _p(xy, C.c_float), _p(size, C.c_float), _p(ang, C.c_float),
+                                          _p(resp, C.c_float), _p(octv, C.c_int32), _p(desc, C.c_uint8),
+                                          cap, C.byref(n))
+    if rc < 0:
+        raise RuntimeError(f"voo_orb_detect_and_compute failed: {rc}")
+    n = n.value
+    return dict(xy=xy[:n].copy(), size=size[:n].copy(), angle=ang[:n].copy(), response=resp[:n].copy(),
+                octave=octv[:n].copy(), desc=desc[:n].copy(), overflow=(rc == 1))
+
+
+def match_hamming(q, t, cross_check=1):
+    q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
+    nq, nt = len(q), len(t)
+    qi = np.zeros(max(nq, 1), np.int32); ti = np.zeros(max(nq, 1), np.int32); d = np.zeros(max(nq, 1), np.float32)
+    n = C.c_int32(0)
+    rc = lib().voo_match_hamming(_p(q, C.c_uint8), nq, _p(t, C.c_uint8), nt, int(cross_check),
+                                 _p(qi, C.c_int32), _p(ti, C.c_int32), _p(d, C.c_float), C.byref(n))
+    assert rc == 0
+    return qi[:n.value].copy(), ti[:n.value].copy(), d[:n.value].copy()
+
+
+def knn2_ratio_hamming(q, t, ratio):
+    q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
+    nq, nt = len(q), len(t)
+    qi = np.zeros(max(nq, 1), np.int32); ti = np.zeros(max(nq, 1), np.int32); d = np.zeros(max(nq, 1), np.float32)
+    n = C.c_int32(0)
+    lib().voo_knn2_ratio_hamming.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib().voo_knn2_ratio_hamming(q.ctypes.data, nq, t.ctypes.data, nt, float(ratio),
+                                      qi.ctypes.data, ti.ctypes.data, d.ctypes.data, C.addressof(n))
+    assert rc == 0
+    return qi[:n.value].copy(), ti[:n.value].copy(), d[:n.value].copy()
+
+
+def five_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(5, 2); x2 = np.ascontiguousarray(x2, np.float64).reshape(5, 2)
+    E = np.zeros((10, 9), np.float64); n = C.c_int32(0)
+    rc = lib().voo_five_point(_p(x1, C.c_double), _p(x2, C.c_double), _p(E, C.c_double), C.byref(n))
+    assert rc == 0
+    return E[:n.value].reshape(-1, 3, 3).copy()
+
+
+def find_essential_ransac(p1, p2, K, prob=0.99, thresh=1.0, max_iters=1000, seed=0xFFFFFFFFFFFFFFFF):
+    p1 = np.ascontiguousarray(p1, np.float64).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64)
+    M = len(p1)
+    E = np.zeros((10, 9), np.float64); mask = np.zeros(max(M, 1), np.uint8)
+    ninl = C.c_int32(0); nmod = C.c_int32(0)
+    f = lib().voo_find_essential_ransac
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_uint64,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = f(p1.ctypes.data, p2.ctypes.data, M, K.ctypes.data, prob, thresh, max_iters, seed,
+           E.ctypes.data, mask.ctypes.data, C.addressof(ninl), C.addressof(nmod))
+    return rc, E[:max(nmod.value, 0)].reshape(-1, 3, 3).copy(), mask[:M].copy(), ninl.value
+
+
+def recover_pose(E, p1, p2, K, dist_thresh=50.0):
+    E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
+    p1 = np.ascontiguousarray(p1, np.float64).reshape(-1, 2); p2 = np.ascontiguousarray(p2, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64)
+    M = len(p1)
+    R = np.zeros((3, 3)); t = np.zeros((3, 1)); mask = np.zeros(max(M, 1), np.uint8); ng = C.c_int32(0)
+    f = lib().voo_recover_pose
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_void_p]
+    rc = f(E.ctypes.data, p1.ctypes.data, p2.ctypes.data, M, K.ctypes.data, dist_thresh, R.ctypes.data,
+           t.ctypes.data, mask.ctypes.data, C.addressof(ng))
+    assert rc == 0
+    return ng.value, R, t, mask[:M].copy()
+
+
+def triangulate(P1, P2, x1, x2):
+    P1 = np.ascontiguousarray(P1, np.float64).reshape(3, 4); P2 = np.ascontiguousarray(P2, np.float64).reshape(3, 4)
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(2, -1); x2 = np.ascontiguousarray(x2, np.float64).reshape(2, -1)
+    M = x1.shape[1]
+    X = np.zeros((4, M), np.float64)
+    rc = lib().voo_triangulate(_p(P1, C.c_double), _p(P2, C.c_double), _p(x1, C.c_double), _p(x2, C.c_double),
+                               M, _p(X, C.c_double))
+    assert rc == 0
+    return X
+
+
+def pair(img1, img2, params, K, match_mode=0, ratio=0.75, want_points=True):
+    img1 = _u8(img1); img2 = _u8(img2)
+    h, w = img1.shape
+    K = np.ascontiguousarray(K, np.float64)
+    res = PairResult()
+    cap = params.nfeatures * 2 + 4096
+    X = np.zeros((4, cap), np.float64)
+    f = lib().voo_pair
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                  C.c_void_p, C.c_void_p, C.c_int32]
+    rc = f(img1.ctypes.data, img2.ctypes.data, h, w, C.addressof(params), K.ctypes.data, match_mode, ratio,
+           C.addressof(res), X.ctypes.data if want_points else None, cap)
+    out = dict(rc=rc, n_kp1=res.n_kp1, n_kp2=res.n_kp2, n_match=res.n_match, n_inl=res.n_inl_E,
+               n_good=res.n_good_pose, R=np.array(res.R).reshape(3, 3), t=np.array(res.t).reshape(3, 1),
+               E=np.array(res.E).reshape(3, 3))
+    if want_points:
+        out["X"] = X[:, :res.n_inl_E].copy()
+    return out

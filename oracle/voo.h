@@ -1,0 +1,87 @@
+/* voo.h — CPU ORACLE for the per-frame-pair visual-odometry front end.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a scalar, plain-C restatement of what the
+ * reference's hot path computes (the five cv2 calls made from
+ * /root/reference/src/frame_generator.py:25-26 and
+ * /root/reference/src/image_pair.py:234-236,280-286,304-308,332-336).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (visual_odometry_amd/) never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the arithmetic lives in opencv-python 4.7.0.72 (Pipfile.lock:162-173),
+ * which is neither vendored in the reference nor installed in this image, and the
+ * reference holds no tests, fixtures or golden vectors for this path.  The restatement
+ * follows OpenCV 4.7's published algorithms as described function by function below;
+ * places where a bit-level choice could not be checked are marked [unverified].
+ */
+#ifndef VOO_H
+#define VOO_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOO_MAX_LEVELS 16
+
+typedef struct {
+    int32_t nfeatures;       /* cv2.ORB_create default 500 (image_and_keypoints.py:8) */
+    float   scale_factor;    /* 1.2f */
+    int32_t nlevels;         /* 8 */
+    int32_t edge_threshold;  /* 31 */
+    int32_t first_level;     /* 0 (only 0 supported) */
+    int32_t wta_k;           /* 2 (only 2 supported) */
+    int32_t score_type;      /* 0 = HARRIS_SCORE, 1 = FAST_SCORE */
+    int32_t patch_size;      /* 31 (only 31 supported) */
+    int32_t fast_threshold;  /* 20 */
+} voo_orb_params;
+
+/* --- ORB stages (each usable on its own by the parity tests) ------------------- */
+int voo_level_geometry(int h, int w, const voo_orb_params* p,
+                       int32_t* lw, int32_t* lh, float* lscale, int32_t* quota);
+int voo_gray(const uint8_t* img, int h, int w, int channels, int row_stride, uint8_t* out);
+int voo_resize_linear_exact(const uint8_t* src, int sw, int sh, int sstride,
+                            uint8_t* dst, int dw, int dh, int dstride);
+/* packed pyramid: level l stored tightly (lw[l]*lh[l] bytes) one after the other */
+int voo_pyramid(const uint8_t* gray, int h, int w, const voo_orb_params* p, uint8_t* out);
+/* dense FAST-9/16 score after 3x3 non-max suppression (0 where no keypoint) */
+int voo_fast_score_nms(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score);
+int voo_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+int voo_orb_detect_and_compute(const uint8_t* img, int h, int w, int channels, int row_stride,
+                               const voo_orb_params* p,
+                               float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                               int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);
+
+/* --- matcher ----------------------------------------------------------------- */
+/* cross_check: 0 = plain nearest neighbour, 1 = cv2 BFMatcher(crossCheck=True) semantics
+ * (batchDistance reverse-NN update), 2 = strict mutual nearest neighbour */
+int voo_match_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int cross_check,
+                      int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
+int voo_knn2_ratio_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
+                           int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
+
+/* --- two-view geometry (float64) --------------------------------------------- */
+int voo_find_essential_ransac(const double* p1, const double* p2, int M, const double* K,
+                              double prob, double thresh_px, int max_iters, uint64_t seed,
+                              double* E /*9, or 9*n_models when M==5*/, uint8_t* mask,
+                              int32_t* n_inl, int32_t* n_models);
+int voo_five_point(const double* x1 /*5x2 normalised*/, const double* x2, double* E /*10x9*/,
+                   int32_t* n_models);
+int voo_recover_pose(const double* E, const double* p1, const double* p2, int M, const double* K,
+                     double dist_thresh, double* R, double* t, uint8_t* mask, int32_t* n_good);
+int voo_triangulate(const double* P1, const double* P2, const double* x1 /*2xM*/,
+                    const double* x2 /*2xM*/, int M, double* X /*4xM*/);
+
+/* --- whole pair, the order of visual_slam.py:294-298 --------------------------- */
+typedef struct {
+    int32_t n_kp1, n_kp2, n_match, n_inl_E, n_good_pose;
+    double  R[9], t[3], E[9];
+} voo_pair_result;
+/* match_mode: 0 = BFMatcher(crossCheck=True).match, 1 = knnMatch(k=2)+ratio */
+int voo_pair(const uint8_t* img1, const uint8_t* img2, int h, int w, const voo_orb_params* p,
+             const double* K, int match_mode, double ratio, voo_pair_result* out,
+             double* X /*4 x cap, w=1*/, int32_t x_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

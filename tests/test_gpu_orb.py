@@ -1,0 +1,112 @@
+"""GPU parity: every ORB stage of the HIP path against the CPU oracle, bit for bit (integer stages) and
+value for value (float32 stages computed in the same operation order)."""
+import numpy as np
+import pytest
+
+from conftest import random_image
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(480, 640), (243, 331), (720, 1280)]
+
+
+def _det(nfeatures=500, nlevels=8, **kw):
+    from visual_odometry_amd.detector import OrbDetector
+    return OrbDetector(nfeatures=nfeatures, nlevels=nlevels, **kw)
+
+
+def _level_sizes(oracle, h, w, p):
+    lw, lh, _, _ = oracle.level_geometry(h, w, p)
+    return [(int(a), int(b)) for a, b in zip(lw, lh)]
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_pyramid_bit_exact(oracle, ctx, h, w):
+    img = random_image(1, h, w)
+    p = oracle.orb_params(nfeatures=500)
+    got = _det().stage_levels("vo_stage_pyramid", img, _level_sizes(oracle, h, w, p))
+    ref = oracle.pyramid(img, p)
+    for l, (g, r) in enumerate(zip(got, ref)):
+        assert np.array_equal(g, r), f"level {l}: {np.count_nonzero(g != r)} pixels differ"
+
+
+def test_gray_bgr_bit_exact(oracle, ctx):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
+    p = oracle.orb_params(nfeatures=100, nlevels=1)
+    got = _det(100, 1).stage_levels("vo_stage_pyramid", img, [(200, 120)])[0]
+    assert np.array_equal(got, oracle.gray(img))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_fast_score_map_bit_exact(oracle, ctx, h, w):
+    img = random_image(2, h, w)
+    p = oracle.orb_params(nfeatures=500)
+    sizes = _level_sizes(oracle, h, w, p)
+    got = _det().stage_levels("vo_stage_fast_scores", img, sizes)
+    for l, lvl in enumerate(oracle.pyramid(img, p)):
+        ref = oracle.fast_score_nms(lvl, 20)
+        assert np.array_equal(got[l], ref), f"level {l}: {np.count_nonzero(got[l] != ref)} scores differ"
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_blur_bit_exact(oracle, ctx, h, w):
+    img = random_image(4, h, w)
+    p = oracle.orb_params(nfeatures=500)
+    got = _det().stage_levels("vo_stage_blur", img, _level_sizes(oracle, h, w, p))
+    for l, lvl in enumerate(oracle.pyramid(img, p)):
+        ref = oracle.gaussian_blur7(lvl)
+        assert np.array_equal(got[l], ref), f"level {l}: {np.count_nonzero(got[l] != ref)} pixels differ"
+
+
+@pytest.mark.parametrize("nfeatures,nlevels,h,w,seed", [(500, 8, 480, 640, 5), (2000, 8, 720, 1280, 6),
+                                                         (300, 4, 300, 400, 7), (500, 8, 243, 331, 8)])
+def test_detect_and_compute_bit_exact(oracle, ctx, nfeatures, nlevels, h, w, seed):
+    img = random_image(seed, h, w)
+    p = oracle.orb_params(nfeatures=nfeatures, nlevels=nlevels)
+    ref = oracle.orb_detect_and_compute(img, p)
+    got = _det(nfeatures, nlevels).detect_arrays(img)
+    assert not got["truncated"]
+    assert len(got["xy"]) == len(ref["xy"])
+    assert np.array_equal(got["xy"], ref["xy"])            # bit-exact keypoint positions and order
+    assert np.array_equal(got["octave"], ref["octave"])
+    assert np.array_equal(got["response"], ref["response"])   # float32 Harris, same operation order
+    assert np.array_equal(got["angle"], ref["angle"])         # fastAtan2, same operation order
+    assert np.array_equal(got["size"], ref["size"])
+    assert np.array_equal(got["desc"], ref["desc"])
+
+
+def test_synthetic_frames_bit_exact(oracle, ctx, seq_small):
+    p = oracle.orb_params(nfeatures=500)
+    det = _det()
+    for f in seq_small["frames"][:2]:
+        ref = oracle.orb_detect_and_compute(f, p)
+        got = det.detect_arrays(f)
+        assert np.array_equal(got["xy"], ref["xy"]) and np.array_equal(got["desc"], ref["desc"])
+        assert np.array_equal(got["angle"], ref["angle"]) and np.array_equal(got["response"], ref["response"])
+
+
+def test_fast_score_type(oracle, ctx):
+    img = random_image(9, 300, 400)
+    p = oracle.orb_params(nfeatures=300, score_type=1)
+    ref = oracle.orb_detect_and_compute(img, p)
+    got = _det(300, 8, scoreType=1).detect_arrays(img)
+    assert np.array_equal(got["xy"], ref["xy"]) and np.array_equal(got["response"], ref["response"])
+    assert np.array_equal(got["desc"], ref["desc"])
+
+
+def test_featureless_and_tiny_images(oracle, ctx):
+    det = _det()
+    flat = np.full((200, 300), 90, np.uint8)
+    got = det.detect_arrays(flat)
+    assert len(got["xy"]) == 0 and got["desc"].shape == (0, 32)
+    tiny = random_image(10, 70, 70)          # only level 0 is larger than 2 * edgeThreshold
+    ref = oracle.orb_detect_and_compute(tiny, oracle.orb_params(nfeatures=500))
+    got = det.detect_arrays(tiny)
+    assert np.array_equal(got["xy"], ref["xy"]) and np.array_equal(got["desc"], ref["desc"])
+
+
+def test_detect_and_compute_object_surface(ctx, seq_small):
+    kps, desc = _det().detectAndCompute(seq_small["frames"][0], None)
+    assert len(kps) == len(desc) and desc.dtype == np.uint8 and desc.shape[1] == 32
+    assert isinstance(kps[0].pt, tuple) and len(kps[0].pt) == 2

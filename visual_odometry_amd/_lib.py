@@ -1,0 +1,137 @@
+"""ctypes binding of libvo_hip.so (the C ABI declared in include/vo_hip.h).
+
+The HIP library is the product: if it is missing or does not load, importing this module raises —
+there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+
+VO_OK, VO_WARN_CAPACITY = 0, 1
+VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL, VO_ERR_NOT_CONFIGURED = -1, -2, -3, -4, -5
+VO_STAGE_COUNT = 16
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
+                ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32)]
+
+
+class PairOpts(C.Structure):
+    _fields_ = [("match_mode", C.c_int32), ("ratio", C.c_double), ("ransac_prob", C.c_double),
+                ("ransac_thresh", C.c_double), ("ransac_max_iters", C.c_int32), ("ransac_seed", C.c_uint64),
+                ("pose_dist_thresh", C.c_double), ("want_points", C.c_int32)]
+
+
+PAIR_RESULT_DTYPE = np.dtype([("n_kp1", "<i4"), ("n_kp2", "<i4"), ("n_match", "<i4"), ("n_inl", "<i4"),
+                              ("n_good", "<i4"), ("status", "<i4"), ("ransac_iters", "<i4"), ("reserved", "<i4"),
+                              ("R", "<f8", (9,)), ("t", "<f8", (3,)), ("E", "<f8", (9,))], align=True)
+
+_P = C.c_void_p
+_SIGS = {
+    "vo_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "vo_destroy": (None, [_P]),
+    "vo_last_error": (C.c_char_p, [_P]),
+    "vo_version": (C.c_int, []),
+    "vo_orb_detect_and_compute": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "vo_match_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "vo_knn2_ratio_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_double, _P, _P, _P, _P]),
+    "vo_find_essential_ransac": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_double, C.c_double, C.c_int, C.c_uint64, _P, _P, _P, _P]),
+    "vo_recover_pose": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P]),
+    "vo_triangulate": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
+    "vo_stage_pyramid": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "vo_stage_fast_scores": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "vo_stage_blur": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "vo_stage_five_point": (C.c_int, [_P, _P, _P, _P, _P]),
+    "vo_batch_configure": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
+    "vo_frames_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int]),
+    "vo_frames_detect": (C.c_int, [_P, C.c_int, C.c_int]),
+    "vo_frame_features": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "vo_pairs_run": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
+    "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
+    "vo_profile_enable": (C.c_int, [_P, C.c_int]),
+    "vo_profile_reset": (C.c_int, [_P]),
+    "vo_profile_read": (C.c_int, [_P, _P, _P]),
+    "vo_stage_name": (C.c_char_p, [C.c_int]),
+    "vo_stage_bytes": (C.c_double, [_P, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvo_hip.so and declare every entry point. Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C visual_odometry_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+class VoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvo_hip error {code}: {msg}")
+        self.code = code
+
+
+class Context:
+    """One vo_ctx: owns device buffers and a HIP stream on `device`. Not thread safe."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = _P()
+        rc = self.lib.vo_create(int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise VoError(rc, f"vo_create(device={device}) failed — is a gfx950 GPU visible to this process?")
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vo_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc < 0:
+            msg = self.lib.vo_last_error(self.handle)
+            raise VoError(rc, msg.decode() if msg else "")
+        return rc
+
+
+_default = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data

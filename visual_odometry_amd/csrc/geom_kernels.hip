@@ -1,0 +1,857 @@
+// geom_kernels.hip — two-view geometry on gfx950, float64, no MFMA (no dense contraction here).
+//
+// Replaces (reference call sites, paths relative to the reference repo):
+//   cv2.findEssentialMat(p1, p2, K, cv2.FM_RANSAC, 0.99, 1)   src/image_pair.py:280-286
+//   cv2.recoverPose(E, p1, p2, K)                              src/image_pair.py:304-308
+//   cv2.triangulatePoints(P, P0, p1.T, p2.T) and `/= w`        src/image_pair.py:332-339
+//
+// Mapping: one wavefront (64 lanes) per frame pair.  A RANSAC round solves 64 five-point samples,
+// one per lane (Nister's solver: Householder null space, 10x20 elimination, degree-10 root finding
+// by Durand-Kerner); the models are then scored strictly in OpenCV's sequential order, each model
+// by all 64 lanes over the correspondences with a wavefront ballot + popcount, so the adaptive
+// iteration count (RANSACUpdateNumIters) and the strict `>` best-model rule are emulated exactly.
+// Compiled with -ffp-contract=off: every operation rounds on its own.
+#include "vo_internal.h"
+#include <float.h>
+
+#define WAVE 64
+
+// ------------------------------------------------------------------ one-sided Jacobi SVD
+// At: N rows of length M (row i = column i of the M x N matrix). Returns At rows = sigma_i u_i,
+// W descending, Vt rows = right singular vectors (Hestenes rotations, as OpenCV's JacobiSVDImpl_).
+template <int M, int N>
+__device__ __forceinline__ void jacobi_svd(double* At, double* W, double* Vt)
+{
+    const double eps = DBL_EPSILON * 10;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) sd += At[i * M + k] * At[i * M + k];
+        W[i] = sd;
+#pragma unroll
+        for (int k = 0; k < N; k++) Vt[i * N + k] = (k == i) ? 1.0 : 0.0;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) {
+#pragma unroll
+            for (int j = i + 1; j < N; j++) {
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
+                if (fabs(p) > eps * sqrt(a * b)) {
+                    p *= 2;
+                    double beta = a - b, gamma = hypot(p, beta), c, s;
+                    if (beta < 0) {
+                        double delta = (gamma - beta) * 0.5;
+                        s = sqrt(delta / gamma);
+                        c = p / (gamma * s * 2);
+                    } else {
+                        c = sqrt((gamma + beta) / (gamma * 2));
+                        s = p / (gamma * c * 2);
+                    }
+                    a = 0; b = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        double t0 = c * At[i * M + k] + s * At[j * M + k];
+                        double t1 = -s * At[i * M + k] + c * At[j * M + k];
+                        At[i * M + k] = t0; At[j * M + k] = t1;
+                        a += t0 * t0; b += t1 * t1;
+                    }
+                    W[i] = a; W[j] = b;
+                    changed = true;
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        double t0 = c * Vt[i * N + k] + s * Vt[j * N + k];
+                        double t1 = -s * Vt[i * N + k] + c * Vt[j * N + k];
+                        Vt[i * N + k] = t0; Vt[j * N + k] = t1;
+                    }
+                }
+            }
+        }
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) sd += At[i * M + k] * At[i * M + k];
+        W[i] = sqrt(sd);
+    }
+    // selection sort, descending (static indices only: compare-and-swap network of the same order)
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+        // find j = argmax W[i..N) with the first maximum winning, as `if (W[j] < W[k]) j = k`
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k2 = i + 1; k2 < N; k2++) {
+            if (j == k2) {
+                double t = W[i]; W[i] = W[k2]; W[k2] = t;
+#pragma unroll
+                for (int k = 0; k < M; k++) { t = At[i * M + k]; At[i * M + k] = At[k2 * M + k]; At[k2 * M + k] = t; }
+#pragma unroll
+                for (int k = 0; k < N; k++) { t = Vt[i * N + k]; Vt[i * N + k] = Vt[k2 * N + k]; Vt[k2 * N + k] = t; }
+            }
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void solve_z(const double* A, double* x)   // A row-major N x N
+{
+    double At[N * N], W[N], Vt[N * N];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int k = 0; k < N; k++) At[i * N + k] = A[k * N + i];
+    jacobi_svd<N, N>(At, W, Vt);
+#pragma unroll
+    for (int k = 0; k < N; k++) x[k] = Vt[(N - 1) * N + k];
+}
+
+// ------------------------------------------------------------------ polynomial index tables
+struct PolyTab { int t11[4][4]; int t21[10][4]; };
+
+constexpr int k_e1[4][3] = {{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+constexpr int k_e2[10][3] = {{2,0,0},{1,1,0},{1,0,1},{1,0,0},{0,2,0},{0,1,1},{0,1,0},{0,0,2},{0,0,1},{0,0,0}};
+// Nister's elimination order: x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1
+constexpr int k_e3[20][3] = {
+    {3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
+    {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0}};
+
+constexpr PolyTab make_poly_tab()
+{
+    PolyTab t{};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            int a = k_e1[i][0] + k_e1[j][0], b = k_e1[i][1] + k_e1[j][1], c = k_e1[i][2] + k_e1[j][2];
+            int idx = -1;
+            for (int m = 0; m < 10; m++) if (k_e2[m][0] == a && k_e2[m][1] == b && k_e2[m][2] == c) idx = m;
+            t.t11[i][j] = idx;
+        }
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 4; j++) {
+            int a = k_e2[i][0] + k_e1[j][0], b = k_e2[i][1] + k_e1[j][1], c = k_e2[i][2] + k_e1[j][2];
+            int idx = -1;
+            for (int m = 0; m < 20; m++) if (k_e3[m][0] == a && k_e3[m][1] == b && k_e3[m][2] == c) idx = m;
+            t.t21[i][j] = idx;
+        }
+    return t;
+}
+
+__device__ __forceinline__ void mul11_acc(const double* p, const double* q, double s, double* r)
+{
+    constexpr PolyTab T = make_poly_tab();
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[T.t11[i][j]] += s * p[i] * q[j];
+}
+
+__device__ __forceinline__ void mul21_acc(const double* p, const double* q, double s, double* r)
+{
+    constexpr PolyTab T = make_poly_tab();
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[T.t21[i][j]] += s * p[i] * q[j];
+}
+
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx cdiv(cplx a, cplx b)
+{
+    double t = 1. / (b.re * b.re + b.im * b.im);
+    return {(a.re * b.re + a.im * b.im) * t, (-a.re * b.im + a.im * b.re) * t};
+}
+
+template <int NA, int NB>
+__device__ __forceinline__ void conv(const double* a, const double* b, double* r)   // degrees NA, NB
+{
+#pragma unroll
+    for (int i = 0; i <= NA + NB; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i <= NA; i++)
+#pragma unroll
+        for (int j = 0; j <= NB; j++) r[i + j] += a[i] * b[j];
+}
+
+// cv::solvePoly's Durand-Kerner sweeps. FULL: degree 10 (the normal case, static indices).
+template <bool FULL>
+__device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, double* ri)
+{
+#pragma unroll 1
+    for (int iter = 0; iter < 300; iter++) {
+        bool conv_all = true;
+        double max_diff = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            if (FULL || i < n) {
+                cplx p = {rr[i], ri[i]};
+                double lead = c[10];
+                if (!FULL) {
+#pragma unroll
+                    for (int q = 1; q <= 10; q++) if (q == n) lead = c[q];
+                }
+                cplx num = {lead, 0}, denom = {lead, 0};
+#pragma unroll
+                for (int j = 0; j < 10; j++) {
+                    if (FULL || j < n) {
+                        double cj = c[9 - j];
+                        if (!FULL) {
+#pragma unroll
+                            for (int q = 0; q < 10; q++) if (q == n - j - 1) cj = c[q];
+                        }
+                        cplx np = cmul(num, p);
+                        num.re = np.re + cj; num.im = np.im;
+                        if (j != i) {
+                            cplx d = {p.re - rr[j], p.im - ri[j]};
+                            if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
+                        }
+                    }
+                }
+                num = cdiv(num, denom);
+                rr[i] = p.re - num.re; ri[i] = p.im - num.im;
+                double ab = sqrt(num.re * num.re + num.im * num.im);
+                max_diff = fmax(max_diff, ab);
+                double mag = fabs(rr[i]) + fabs(ri[i]);
+                conv_all &= ab <= 4 * DBL_EPSILON * mag;
+            }
+        }
+        if (max_diff <= 0 || conv_all) break;
+    }
+}
+
+// ------------------------------------------------------------------ five-point solver, one sample per lane
+// x1, x2: 5 normalised correspondences (interleaved x,y). Writes up to 10 row-major 3x3 models
+// (x2^T E x1 = 0, unit Frobenius norm) to Eout and returns their number.
+__device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout)
+{
+    double basis[36];
+    {
+        // Householder QR of Q^T (9 x 5); null space = last 4 columns of the orthogonal factor
+        double A[9][5], V[5][9];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+            A[0][i] = u2 * u1; A[1][i] = u2 * v1; A[2][i] = u2;
+            A[3][i] = v2 * u1; A[4][i] = v2 * v1; A[5][i] = v2;
+            A[6][i] = u1; A[7][i] = v1; A[8][i] = 1.0;
+        }
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            double nrm = 0;
+#pragma unroll
+            for (int r = k; r < 9; r++) nrm += A[r][k] * A[r][k];
+            nrm = sqrt(nrm);
+            bad |= nrm < 1e-300;
+            double alpha = A[k][k] > 0 ? -nrm : nrm;
+#pragma unroll
+            for (int r = 0; r < 9; r++) V[k][r] = r < k ? 0.0 : A[r][k];
+            V[k][k] -= alpha;
+            double vn = 0;
+#pragma unroll
+            for (int r = k; r < 9; r++) vn += V[k][r] * V[k][r];
+            vn = sqrt(vn);
+            bad |= vn < 1e-300;
+#pragma unroll
+            for (int r = k; r < 9; r++) V[k][r] /= vn;
+#pragma unroll
+            for (int c = k; c < 5; c++) {
+                double d = 0;
+#pragma unroll
+                for (int r = k; r < 9; r++) d += V[k][r] * A[r][c];
+#pragma unroll
+                for (int r = k; r < 9; r++) A[r][c] -= 2 * d * V[k][r];
+            }
+        }
+        if (bad) return 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double e[9];
+#pragma unroll
+            for (int r = 0; r < 9; r++) e[r] = (r == 5 + j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 4; k >= 0; k--) {
+                double d = 0;
+#pragma unroll
+                for (int r = k; r < 9; r++) d += V[k][r] * e[r];
+#pragma unroll
+                for (int r = k; r < 9; r++) e[r] -= 2 * d * V[k][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 9; r++) basis[j * 9 + r] = e[r];
+        }
+    }
+
+    // 10 cubic constraints in (x, y, z): det(E) = 0 and (E E^T - 0.5 tr(E E^T) I) E = 0
+    double C[10][20];
+    {
+        double E[3][3][4];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) E[r][c][k] = basis[k * 9 + r * 3 + c];
+        {
+            double row[20];
+#pragma unroll
+            for (int i = 0; i < 20; i++) row[i] = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                double m[10];
+#pragma unroll
+                for (int i = 0; i < 10; i++) m[i] = 0;
+                mul11_acc(E[1][c1], E[2][c2], 1.0, m);
+                mul11_acc(E[1][c2], E[2][c1], -1.0, m);
+                mul21_acc(m, E[0][c], 1.0, row);
+            }
+#pragma unroll
+            for (int i = 0; i < 20; i++) C[0][i] = row[i];
+        }
+        double L[3][3][10];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+#pragma unroll
+                for (int i = 0; i < 10; i++) L[r][c][i] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) mul11_acc(E[r][k], E[c][k], 1.0, L[r][c]);
+            }
+        double tr[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) tr[i] = L[0][0][i] + L[1][1][i] + L[2][2][i];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int i = 0; i < 10; i++) L[r][r][i] -= 0.5 * tr[i];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double row[20];
+#pragma unroll
+                for (int i = 0; i < 20; i++) row[i] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) mul21_acc(L[r][k], E[k][c], 1.0, row);
+#pragma unroll
+                for (int i = 0; i < 20; i++) C[1 + r * 3 + c][i] = row[i];
+            }
+    }
+
+    // Gauss-Jordan with partial pivoting on the left 10 columns
+#pragma unroll 1
+    for (int col = 0; col < 10; col++) {
+        int piv = col;
+        double best = fabs(C[col][col]);
+#pragma unroll 1
+        for (int r = col + 1; r < 10; r++) { double v = fabs(C[r][col]); if (v > best) { best = v; piv = r; } }
+        if (best < 1e-300) return 0;
+        if (piv != col)
+#pragma unroll 1
+            for (int k = 0; k < 20; k++) { double t = C[col][k]; C[col][k] = C[piv][k]; C[piv][k] = t; }
+        double inv = 1.0 / C[col][col];
+#pragma unroll 1
+        for (int k = 0; k < 20; k++) C[col][k] *= inv;
+#pragma unroll 1
+        for (int r = 0; r < 10; r++) {
+            if (r == col) continue;
+            double f = C[r][col];
+            if (f == 0) continue;
+#pragma unroll 1
+            for (int k = 0; k < 20; k++) C[r][k] -= f * C[col][k];
+        }
+    }
+
+    // B(z) [x y 1]^T = 0
+    double Bx[3][4], By[3][4], Bc[3][5];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double* r1 = &C[2 * i + 4][10];
+        const double* r2 = &C[2 * i + 5][10];
+        Bx[i][3] = -r2[0]; Bx[i][2] = r1[0] - r2[1]; Bx[i][1] = r1[1] - r2[2]; Bx[i][0] = r1[2];
+        By[i][3] = -r2[3]; By[i][2] = r1[3] - r2[4]; By[i][1] = r1[4] - r2[5]; By[i][0] = r1[5];
+        Bc[i][4] = -r2[6]; Bc[i][3] = r1[6] - r2[7]; Bc[i][2] = r1[7] - r2[8]; Bc[i][1] = r1[8] - r2[9]; Bc[i][0] = r1[9];
+    }
+    double c[11];
+    {
+        double t1[8], t2[8], t3[11];
+#pragma unroll
+        for (int i = 0; i < 11; i++) c[i] = 0;
+        conv<3, 4>(By[1], Bc[2], t1); conv<3, 4>(By[2], Bc[1], t2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) t1[i] -= t2[i];
+        conv<3, 7>(Bx[0], t1, t3);
+#pragma unroll
+        for (int i = 0; i < 11; i++) c[i] += t3[i];
+        conv<3, 4>(Bx[1], Bc[2], t1); conv<3, 4>(Bx[2], Bc[1], t2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) t1[i] -= t2[i];
+        conv<3, 7>(By[0], t1, t3);
+#pragma unroll
+        for (int i = 0; i < 11; i++) c[i] -= t3[i];
+        conv<3, 3>(Bx[1], By[2], t1); conv<3, 3>(Bx[2], By[1], t2);
+#pragma unroll
+        for (int i = 0; i < 7; i++) t1[i] -= t2[i];
+        conv<4, 6>(Bc[0], t1, t3);
+#pragma unroll
+        for (int i = 0; i < 11; i++) c[i] += t3[i];
+    }
+
+    // cv::solvePoly: Durand-Kerner from the starting points (1+i)^k, Gauss-Seidel updates.  OpenCV
+    // iterates a fixed 300 times (its exit test is maxDiff <= 0); here the loop also stops once every
+    // correction is below 4 ulp of its root, after which further sweeps only move rounding noise.
+    int n = 10;
+    while (n > 1 && !(fabs(c[n]) > DBL_EPSILON)) n--;
+    double rr[10], ri[10];
+    {
+        cplx p = {1, 0}, r = {1, 1};
+#pragma unroll
+        for (int i = 0; i < 10; i++) { rr[i] = p.re; ri[i] = p.im; p = cmul(p, r); }
+    }
+    if (n == 10) dk_iterate<true>(c, 10, rr, ri);
+    else dk_iterate<false>(c, n, rr, ri);
+
+    int count = 0;
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        double zr = 0, zi = 0;
+#pragma unroll
+        for (int q = 0; q < 10; q++) if (q == i) { zr = rr[q]; zi = ri[q]; }
+        if (fabs(zi) < 1e-100) zi = 0;
+        if (fabs(zi) > 1e-10) continue;
+        double z1 = zr, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        double bz[9], xy1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            bz[j * 3 + 0] = Bx[j][3] * z3 + Bx[j][2] * z2 + Bx[j][1] * z1 + Bx[j][0];
+            bz[j * 3 + 1] = By[j][3] * z3 + By[j][2] * z2 + By[j][1] * z1 + By[j][0];
+            bz[j * 3 + 2] = Bc[j][4] * z4 + Bc[j][3] * z3 + Bc[j][2] * z2 + Bc[j][1] * z1 + Bc[j][0];
+        }
+        solve_z<3>(bz, xy1);
+        if (fabs(xy1[2]) < 1e-10) continue;
+        double x = xy1[0] / xy1[2], y = xy1[1] / xy1[2], nrm = 0, e[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            e[k] = basis[k] * x + basis[9 + k] * y + basis[18 + k] * z1 + basis[27 + k];
+            nrm += e[k] * e[k];
+        }
+        nrm = sqrt(nrm);
+#pragma unroll
+        for (int k = 0; k < 9; k++) Eout[count * 9 + k] = e[k] / nrm;
+        count++;
+    }
+    return count;
+}
+
+// ------------------------------------------------------------------ RANSAC helpers
+__device__ __forceinline__ uint32_t rng_next(uint64_t& state)
+{
+    state = (uint64_t)(uint32_t)state * 4164903690ULL + (uint32_t)(state >> 32);
+    return (uint32_t)state;
+}
+
+__device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = fmax(p, 0.); p = fmin(p, 1.);
+    ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return (denom >= 0 || -num >= max_iters * (-denom)) ? max_iters : __double2int_rn(num / denom);
+}
+
+// Sampson error as EMEstimatorCallback::computeError stores it (float32)
+__device__ __forceinline__ float sampson_err(const double* E, double u1, double v1, double u2, double v2)
+{
+    double Ex0 = E[0] * u1 + E[1] * v1 + E[2], Ex1 = E[3] * u1 + E[4] * v1 + E[5], Ex2 = E[6] * u1 + E[7] * v1 + E[8];
+    double Et0 = E[0] * u2 + E[3] * v2 + E[6], Et1 = E[1] * u2 + E[4] * v2 + E[7];
+    double d = u2 * Ex0 + v2 * Ex1 + Ex2;
+    return (float)(d * d / (Ex0 * Ex0 + Ex1 * Ex1 + Et0 * Et0 + Et1 * Et1));
+}
+
+__device__ __forceinline__ int count_inliers(const double* E, const double* x1, const double* x2, int M, float t,
+                                             int lane, uint8_t* mask_out)
+{
+    int good = 0;
+    for (int base = 0; base < M; base += WAVE) {
+        int i = base + lane;
+        bool f = false;
+        if (i < M) {
+            f = sampson_err(E, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]) <= t;
+            if (mask_out) mask_out[i] = f ? 1 : 0;
+        }
+        good += __popcll(__ballot(f));
+    }
+    return good;
+}
+
+// ------------------------------------------------------------------ RANSACPointSetRegistrator::run, one wave per pair
+__global__ __launch_bounds__(WAVE) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int M = pb.m_count[p];
+    const double* x1 = pb.xn1 + (size_t)p * kp_cap * 2;
+    const double* x2 = pb.xn2 + (size_t)p * kp_cap * 2;
+    uint8_t* mask = pb.mask + (size_t)p * kp_cap;
+    double* models = pb.models + (size_t)p * 64 * 90;
+    vo_pair_result* res = pb.res + p;
+    __shared__ int s_sub[64][5];
+    __shared__ int s_nm[64];
+
+    if (M < 5) {
+        if (lane == 0) { res->status = VO_ERR_TOO_FEW; res->n_inl = 0; res->ransac_iters = 0; }
+        for (int i = lane; i < M; i += WAVE) mask[i] = 0;
+        return;
+    }
+    const double threshold = rp.thresh_px / ((rp.K[0] + rp.K[4]) / 2);
+    const float t = (float)(threshold * threshold);
+    uint64_t state = rp.seed ? rp.seed : 0xffffffffULL;
+
+    if (M == 5) {       // ptsetreg.cpp: count == modelPoints -> all solutions, every point an inlier
+        if (lane == 0) {
+            int nm = five_point_solve(x1, x2, models);
+            for (int k = 0; k < 9; k++) res->E[k] = nm > 0 ? models[k] : 0.0;
+            res->status = nm > 0 ? VO_OK : VO_ERR_NO_MODEL;
+            res->n_inl = nm > 0 ? 5 : 0;
+            res->reserved = nm;          // number of stacked models left in pb.models
+            res->ransac_iters = 0;
+        }
+        if (lane < 5) mask[lane] = 1;
+        return;
+    }
+
+    int niters = rp.max_iters > 1 ? rp.max_iters : 1;
+    int max_good = 0, iters_done = 0;
+    double bestE[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) bestE[k] = 0;
+
+    for (int r0 = 0; r0 < niters; r0 += WAVE) {
+        const int nh = min(WAVE, niters - r0);
+        if (lane == 0) {
+            for (int h = 0; h < nh; h++) {
+                int idx[5];
+                for (int i = 0; i < 5; i++) {
+                    int v; bool dup;
+                    do {
+                        v = (int)(rng_next(state) % (uint32_t)M);
+                        dup = false;
+                        for (int k = 0; k < i; k++) dup |= idx[k] == v;
+                    } while (dup);
+                    idx[i] = v;
+                    s_sub[h][i] = v;
+                }
+            }
+        }
+        __syncthreads();
+        int nm = 0;
+        if (lane < nh) {
+            double s1[10], s2[10];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                int v = s_sub[lane][i];
+                s1[2 * i] = x1[2 * v]; s1[2 * i + 1] = x1[2 * v + 1];
+                s2[2 * i] = x2[2 * v]; s2[2 * i + 1] = x2[2 * v + 1];
+            }
+            nm = five_point_solve(s1, s2, models + (size_t)lane * 90);
+        }
+        s_nm[lane] = nm;
+        __threadfence_block();
+        __syncthreads();
+        // score in OpenCV's sequential order; niters shrinks as better models appear
+        for (int h = 0; h < nh; h++) {
+            if (r0 + h >= niters) break;
+            iters_done = r0 + h + 1;
+            const int nmh = s_nm[h];
+            for (int m = 0; m < nmh; m++) {
+                double E[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) E[k] = models[(size_t)h * 90 + m * 9 + k];
+                int good = count_inliers(E, x1, x2, M, t, lane, nullptr);
+                if (good > max(max_good, 4)) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) bestE[k] = E[k];
+                    max_good = good;
+                    niters = ransac_update_num_iters(rp.prob, (double)(M - good) / M, 5, niters);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (max_good > 0) {
+        int good = count_inliers(bestE, x1, x2, M, t, lane, mask);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) res->E[k] = bestE[k];
+            res->n_inl = good; res->status = VO_OK; res->ransac_iters = iters_done; res->reserved = 1;
+        }
+    } else {
+        for (int i = lane; i < M; i += WAVE) mask[i] = 0;
+        if (lane == 0) { res->n_inl = 0; res->status = VO_ERR_NO_MODEL; res->ransac_iters = iters_done; res->reserved = 0; }
+    }
+}
+
+void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
+{
+    hipLaunchKernelGGL(k_ransac, dim3(P), dim3(WAVE), 0, s, pb, kp_cap, rp);
+}
+
+// ------------------------------------------------------------------ triangulation (DLT, 4x4 SVD per point)
+__device__ __forceinline__ void triangulate_one(const double* P1, const double* P2, double x1, double y1,
+                                                double x2, double y2, double* X)
+{
+    double A[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = x1 * P1[8 + k] - P1[k];
+        A[1 * 4 + k] = y1 * P1[8 + k] - P1[4 + k];
+        A[2 * 4 + k] = x2 * P2[8 + k] - P2[k];
+        A[3 * 4 + k] = y2 * P2[8 + k] - P2[4 + k];
+    }
+    solve_z<4>(A, X);
+}
+
+__global__ void k_triangulate_raw(const double* P1g, const double* P2g, const double* x1, const double* x2,
+                                  int M, double* X)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double P1[12], P2[12], q[4];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { P1[k] = P1g[k]; P2[k] = P2g[k]; }
+    triangulate_one(P1, P2, x1[i], x1[M + i], x2[i], x2[M + i], q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) X[(size_t)k * M + i] = q[k];
+}
+
+void launch_triangulate_raw(hipStream_t s, const double* P1, const double* P2, const double* x1, const double* x2,
+                            int M, double* X)
+{
+    if (M <= 0) return;
+    hipLaunchKernelGGL(k_triangulate_raw, dim3((M + 63) / 64), dim3(64), 0, s, P1, P2, x1, x2, M, X);
+}
+
+// image_pair.py:316-339: P = K [R^T | -R^T t] with frame-1 points, P0 = K [I | 0] with frame-2 points, X /= w
+__global__ void k_triangulate_pairs(PairBuf pb, int kp_cap, RansacParams rp)
+{
+    const int p = blockIdx.y;
+    const vo_pair_result* res = pb.res + p;
+    if (res->status != VO_OK) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= res->n_inl) return;
+    const double* R = res->R; const double* t = res->t; const double* K = rp.K;
+    double T[12], P[12], P0[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) T[r * 4 + c] = R[c * 3 + r];
+        T[r * 4 + 3] = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            P[r * 4 + c] = K[r * 3] * T[c] + K[r * 3 + 1] * T[4 + c] + K[r * 3 + 2] * T[8 + c];
+            P0[r * 4 + c] = c < 3 ? K[r * 3 + c] : 0.0;
+        }
+    const double* a = pb.ipx1 + ((size_t)p * kp_cap + i) * 2;
+    const double* b = pb.ipx2 + ((size_t)p * kp_cap + i) * 2;
+    double q[4];
+    triangulate_one(P, P0, a[0], a[1], b[0], b[1], q);
+    double* X = pb.X + (size_t)p * 4 * kp_cap;
+    double w = q[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) X[(size_t)k * kp_cap + i] = q[k] / w;
+}
+
+void launch_triangulate_pairs(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
+{
+    hipLaunchKernelGGL(k_triangulate_pairs, dim3((kp_cap + 63) / 64, P), dim3(64), 0, s, pb, kp_cap, rp);
+}
+
+// ------------------------------------------------------------------ decomposeEssentialMat + recoverPose, one wave per pair
+__device__ __forceinline__ double det3(const double* m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+__device__ __forceinline__ void mat3mul(const double* a, const double* b, double* r)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += a[i * 3 + k] * b[k * 3 + j];
+            r[i * 3 + j] = s;
+        }
+}
+
+__device__ void decompose_essential(const double* E, double* R1, double* R2, double* t)
+{
+    double At[9], W[3], Vt[9], U[9], u[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) At[i * 3 + k] = E[k * 3 + i];
+    jacobi_svd<3, 3>(At, W, Vt);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        double s = W[i] > DBL_MIN ? 1. / W[i] : 0.;
+#pragma unroll
+        for (int k = 0; k < 3; k++) u[i][k] = At[i * 3 + k] * s;
+    }
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) U[k * 3 + i] = u[i][k];
+    if (det3(U) < 0) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) U[k] = -U[k];
+    }
+    if (det3(Vt) < 0) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Vt[k] = -Vt[k];
+    }
+    const double Wm[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1}, Wt[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
+    double T[9];
+    mat3mul(U, Wm, T); mat3mul(T, Vt, R1);
+    mat3mul(U, Wt, T); mat3mul(T, Vt, R2);
+    t[0] = U[2]; t[1] = U[5]; t[2] = U[8];
+}
+
+// The E-RANSAC inliers are compacted in order (determine_essential_matrix returns them as a list,
+// image_pair.py:288-290), then the four (R, t) candidates are cheirality-tested on them.
+__global__ __launch_bounds__(WAVE) void k_pose(PairBuf pb, int kp_cap, RansacParams rp)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    vo_pair_result* res = pb.res + p;
+    if (res->status != VO_OK) {
+        if (lane == 0) res->n_good = 0;
+        return;
+    }
+    const int M = pb.m_count[p];
+    const size_t base2 = (size_t)p * kp_cap * 2;
+    const uint8_t* mask = pb.mask + (size_t)p * kp_cap;
+    double* in1 = pb.in1 + base2; double* in2 = pb.in2 + base2;
+    double* ip1 = pb.ipx1 + base2; double* ip2 = pb.ipx2 + base2;
+    int ninl = 0;
+    for (int b = 0; b < M; b += WAVE) {
+        int i = b + lane;
+        bool f = i < M && mask[i] != 0;
+        uint64_t bal = __ballot(f);
+        if (f) {
+            int pos = ninl + __popcll(bal & ((1ULL << lane) - 1));
+            in1[2 * pos] = pb.xn1[base2 + 2 * i]; in1[2 * pos + 1] = pb.xn1[base2 + 2 * i + 1];
+            in2[2 * pos] = pb.xn2[base2 + 2 * i]; in2[2 * pos + 1] = pb.xn2[base2 + 2 * i + 1];
+            ip1[2 * pos] = pb.px1[base2 + 2 * i]; ip1[2 * pos + 1] = pb.px1[base2 + 2 * i + 1];
+            ip2[2 * pos] = pb.px2[base2 + 2 * i]; ip2[2 * pos + 1] = pb.px2[base2 + 2 * i + 1];
+        }
+        ninl += __popcll(bal);
+    }
+    __threadfence_block();
+    __syncthreads();
+    double E[9], R1[9], R2[9], tt[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) E[k] = res->E[k];
+    decompose_essential(E, R1, R2, tt);
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    int good[4];
+#pragma unroll 1
+    for (int c = 0; c < 4; c++) {
+        const double* Rc = (c & 1) ? R2 : R1;
+        const double sgn = c >= 2 ? -1.0 : 1.0;
+        double P[12];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) P[r * 4 + k] = Rc[r * 3 + k];
+            P[r * 4 + 3] = sgn * tt[r];
+        }
+        int g = 0;
+        for (int b = 0; b < ninl; b += WAVE) {
+            int i = b + lane;
+            bool m = false;
+            if (i < ninl) {
+                double Q[4];
+                triangulate_one(P0, P, in1[2 * i], in1[2 * i + 1], in2[2 * i], in2[2 * i + 1], Q);
+                m = Q[2] * Q[3] > 0;
+                double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
+                m = m && (q2 < rp.dist_thresh);
+                double z = P[8] * q0 + P[9] * q1 + P[10] * q2 + P[11] * q3;
+                m = m && (z > 0) && (z < rp.dist_thresh);
+            }
+            g += __popcll(__ballot(m));
+        }
+        good[c] = g;
+    }
+    int best;
+    if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) best = 0;
+    else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) best = 1;
+    else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) best = 2;
+    else best = 3;
+    if (pb.pose_mask) {      // single-call cv2.recoverPose mask: rebuild the winning candidate's test
+        const double* Rc = (best & 1) ? R2 : R1;
+        const double sgn = best >= 2 ? -1.0 : 1.0;
+        double P[12];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) P[r * 4 + k] = Rc[r * 3 + k];
+            P[r * 4 + 3] = sgn * tt[r];
+        }
+        uint8_t* pm = pb.pose_mask + (size_t)p * kp_cap;
+        for (int i = lane; i < ninl; i += WAVE) {
+            double Q[4];
+            triangulate_one(P0, P, in1[2 * i], in1[2 * i + 1], in2[2 * i], in2[2 * i + 1], Q);
+            bool m = Q[2] * Q[3] > 0;
+            double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
+            m = m && (q2 < rp.dist_thresh);
+            double z = P[8] * q0 + P[9] * q1 + P[10] * q2 + P[11] * q3;
+            m = m && (z > 0) && (z < rp.dist_thresh);
+            pm[i] = m ? 255 : 0;
+        }
+    }
+    if (lane == 0) {
+        const double* Rb = (best & 1) ? R2 : R1;
+#pragma unroll
+        for (int k = 0; k < 9; k++) res->R[k] = Rb[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) res->t[k] = best >= 2 ? -tt[k] : tt[k];
+        res->n_good = good[best];
+        res->n_inl = ninl;
+    }
+}
+
+void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
+{
+    hipLaunchKernelGGL(k_pose, dim3(P), dim3(WAVE), 0, s, pb, kp_cap, rp);
+}
+
+// ------------------------------------------------------------------ single five-point sample (stage test)
+__global__ void k_five_point_raw(const double* x1, const double* x2, double* E, int* nm)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E);
+}
+
+void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm)
+{
+    hipLaunchKernelGGL(k_five_point_raw, dim3(1), dim3(64), 0, s, x1, x2, E, nm);
+}

@@ -1,0 +1,591 @@
+// orb_kernels.hip — ORB detect + describe on gfx950, batch-major (grid.y / grid.z = frame).
+//
+// Replaces `detector.detectAndCompute(image, None)` for a cv2.ORB detector
+// (reference: src/frame_generator.py:25-26, src/image_and_keypoints.py:8,46).
+// Stages: BGR->gray, INTER_LINEAR_EXACT pyramid, FAST-9/16 + score + 3x3 NMS into a dense score map
+// with a per-level score histogram, retainBest by FAST score (threshold from the histogram, ordered
+// compaction), Harris response, retainBest by Harris (radix select, ordered compaction), intensity
+// centroid angle, 7x7 Gaussian blur, steered BRIEF (one wavefront per keypoint, 4 ballots = 256 bits).
+// All integer stages are bit-exact against oracle/voo_orb.c; float stages use the same operation
+// order (the library is compiled with -ffp-contract=off).
+#include "vo_internal.h"
+#include <float.h>
+
+__constant__ int8_t c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// sepFilter2D integer taps of GaussianBlur(7x7, sigma 2): cvRound(256 * g)
+__constant__ int c_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
+
+// ------------------------------------------------------------------ block-wide exclusive scan (<= 1024 threads)
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// returns the exclusive prefix of v over the block; *total = block sum. s_w: >= 17 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int* s_w, int* total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = wave_incl_scan(v, lane);
+    __syncthreads();                      // protect s_w from the previous use
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        int w = lane < nw ? s_w[lane] : 0;
+        int winc = wave_incl_scan(w, lane);
+        if (lane < nw) s_w[lane] = winc - w;
+        if (lane == nw - 1) s_w[16] = winc;
+    }
+    __syncthreads();
+    *total = s_w[16];
+    return s_w[wid] + inc - v;
+}
+
+// ------------------------------------------------------------------ BGR -> gray (color_rgb RGB2Gray<uchar>, 15-bit)
+__global__ void k_gray(const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
+                       uint8_t* pyr, PyrGeom g)
+{
+    const int f = blockIdx.z;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    const LevelGeom lv = g.lv[0];
+    if (x4 >= lv.stride) return;
+    const uint8_t* s = src + (size_t)f * frame_stride + (size_t)y * row_stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int x = x4 + b, v = 0;
+        if (x < lv.w) {
+            const uint8_t* px = s + (size_t)x * channels;
+            v = channels == 1 ? px[0] : (px[0] * 3735 + px[1] * 19235 + px[2] * 9798 + (1 << 14)) >> 15;
+        }
+        out |= (uint32_t)v << (8 * b);
+    }
+    *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + lv.off + (size_t)y * lv.stride + x4) = out;
+}
+
+void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
+                 uint8_t* pyr, const PyrGeom& g, int F)
+{
+    const LevelGeom& lv = g.lv[0];
+    dim3 grid((lv.stride / 4 + 63) / 64, lv.h, F);
+    hipLaunchKernelGGL(k_gray, grid, dim3(64), 0, s, src, channels, row_stride, frame_stride, pyr, g);
+}
+
+// ------------------------------------------------------------------ INTER_LINEAR_EXACT (resize.cpp resize_bitExact, u8)
+// 8.8 fixed-point horizontal pass (exact), 16.16 vertical pass rounded half-up; edge columns / rows
+// replicate. One thread = 4 destination pixels (one dword store).
+__global__ void k_resize(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom dst, ResizeTab tab)
+{
+    const int f = blockIdx.z;
+    const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (dx0 >= dst.stride || dy >= dst.h) return;
+    const uint8_t* sp = pyr + (size_t)f * frame_bytes + src.off;
+    uint8_t* dp = pyr + (size_t)f * frame_bytes + dst.off;
+    int r0, r1; uint32_t w0 = 0, w1 = 0; bool edge;
+    if (dy < tab.min_y)       { r0 = r1 = 0; edge = true; }
+    else if (dy >= tab.max_y) { r0 = r1 = src.h - 1; edge = true; }
+    else { r0 = tab.yofs[dy]; r1 = r0 + 1; edge = false; w1 = tab.yc1[dy]; w0 = 256 - w1; }
+    const uint8_t* s0 = sp + (size_t)r0 * src.stride;
+    const uint8_t* s1 = sp + (size_t)r1 * src.stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int dx = dx0 + b;
+        uint32_t v = 0;
+        if (dx < dst.w) {
+            uint32_t h0, h1;
+            if (dx < tab.min_x)       { h0 = (uint32_t)s0[0] << 8; h1 = (uint32_t)s1[0] << 8; }
+            else if (dx >= tab.max_x) { h0 = (uint32_t)s0[src.w - 1] << 8; h1 = (uint32_t)s1[src.w - 1] << 8; }
+            else {
+                const int xo = tab.xofs[dx];
+                const uint32_t c1 = tab.xc1[dx], c0 = 256 - c1;
+                h0 = c0 * s0[xo] + c1 * s0[xo + 1];
+                h1 = c0 * s1[xo] + c1 * s1[xo + 1];
+            }
+            v = edge ? (h0 + 128u) >> 8 : (h0 * w0 + h1 * w1 + 32768u) >> 16;
+            v = v > 255u ? 255u : v;
+        }
+        out |= v << (8 * b);
+    }
+    *(uint32_t*)(dp + (size_t)dy * dst.stride + dx0) = out;
+}
+
+void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F)
+{
+    const LevelGeom& d = g.lv[level];
+    dim3 block(64, 4), grid((d.stride / 4 + 63) / 64, (d.h + 3) / 4, F);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
+}
+
+// ------------------------------------------------------------------ FAST-9/16 + cornerScore + 3x3 NMS
+// fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  Tile FAST_TW x FAST_TH per workgroup, halo 4 in
+// LDS.  is_corner <=> a 9-arc of the 16-ring is all darker than v-t or all brighter than v+t, tested on
+// two 16-bit masks; score = max(A, B) - 1 with A/B the best arc minimum of (v - ring) / (ring - v).
+__device__ __forceinline__ bool has_arc9(uint32_t m)
+{
+    m |= m << 16;
+    uint32_t x = m & (m >> 1);
+    x &= x >> 2;
+    x &= x >> 4;
+    x &= m >> 8;
+    return x != 0;
+}
+
+#define FT_LW (FAST_TW + 8)
+#define FT_LH (FAST_TH + 8)
+#define FT_SW (FAST_TW + 2)
+#define FT_SH (FAST_TH + 2)
+
+__device__ __forceinline__ int fast_score_at(const uint8_t* c, int t)   // c: centre in an LDS tile of row stride FT_LW
+{
+    int v = c[0];
+    int d[16];
+    d[0]  = v - c[3 * FT_LW];      d[1]  = v - c[3 * FT_LW + 1];  d[2]  = v - c[2 * FT_LW + 2];  d[3]  = v - c[FT_LW + 3];
+    d[4]  = v - c[3];              d[5]  = v - c[-FT_LW + 3];     d[6]  = v - c[-2 * FT_LW + 2]; d[7]  = v - c[-3 * FT_LW + 1];
+    d[8]  = v - c[-3 * FT_LW];     d[9]  = v - c[-3 * FT_LW - 1]; d[10] = v - c[-2 * FT_LW - 2]; d[11] = v - c[-FT_LW - 3];
+    d[12] = v - c[-3];             d[13] = v - c[FT_LW - 3];      d[14] = v - c[2 * FT_LW - 2];  d[15] = v - c[3 * FT_LW - 1];
+    uint32_t dark = 0, bright = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { dark |= (uint32_t)(d[k] > t) << k; bright |= (uint32_t)(d[k] < -t) << k; }
+    if (!has_arc9(dark) && !has_arc9(bright)) return 0;
+    // arc minima / maxima of 9 consecutive ring differences by doubling
+    int mn[16], mx[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
+    int mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
+    int A = -256, B = -256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int a = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int b = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, a);
+        B = max(B, -b);
+    }
+    return max(A, B) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g)
+{
+    __shared__ uint8_t s_px[FT_LH * FT_LW];
+    __shared__ uint8_t s_sc[FT_SH * FT_LW];
+    __shared__ uint32_t s_hist[256];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].ftile_base) l++;
+    const LevelGeom lv = g.lv[l];
+    const int tile = blockIdx.x - lv.ftile_base;
+    const int x0 = (tile % lv.ftiles_x) * FAST_TW, y0 = (tile / lv.ftiles_x) * FAST_TH;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
+    s_hist[tid] = 0;
+    // tile + halo 4, dword loads (x0 - 4 is 4-byte aligned, rows are 64-byte aligned)
+    for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
+        const int ry = i / (FT_LW / 4), rx4 = (i % (FT_LW / 4)) * 4;
+        const int gy = y0 - 4 + ry, gx = x0 - 4 + rx4;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < lv.h && gx >= 0 && gx < lv.stride) v = *(const uint32_t*)(img + (size_t)gy * lv.stride + gx);
+        *(uint32_t*)(s_px + ry * FT_LW + rx4) = v;
+    }
+    __syncthreads();
+    // raw scores on the tile + 1 ring
+    for (int i = tid; i < FT_SH * FT_SW; i += 256) {
+        const int sy = i / FT_SW, sx = i % FT_SW;
+        const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+        int sc = 0;
+        if (gx >= 3 && gx < lv.w - 3 && gy >= 3 && gy < lv.h - 3)
+            sc = fast_score_at(s_px + (sy + 3) * FT_LW + (sx + 3), g.fast_thr);
+        s_sc[sy * FT_LW + sx] = (uint8_t)sc;
+    }
+    __syncthreads();
+    // NMS, 4 pixels per thread, one dword store
+    const int tx = tid & 15, ty = tid >> 4;
+    const int gy = y0 + ty;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int lx = tx * 4 + b;
+        const uint8_t* c = s_sc + (ty + 1) * FT_LW + (lx + 1);
+        const int s = c[0];
+        if (s && s > c[-1] && s > c[1] && s > c[-FT_LW - 1] && s > c[-FT_LW] && s > c[-FT_LW + 1] &&
+            s > c[FT_LW - 1] && s > c[FT_LW] && s > c[FT_LW + 1]) {
+            out |= (uint32_t)s << (8 * b);
+            const int gx = x0 + lx;
+            if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[s], 1u);
+        }
+    }
+    if (gy < lv.h) *(uint32_t*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 4) = out;
+    __syncthreads();
+    const uint32_t hv = s_hist[tid];
+    if (hv) atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + tid], hv);
+}
+
+void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F)
+{
+    hipLaunchKernelGGL(k_fast, dim3(g.ftiles_total, F), dim3(256), 0, s, pyr, score, hist, g);
+}
+
+// ------------------------------------------------------------------ retainBest by FAST score
+// KeyPointsFilter::runByImageBorder + retainBest(2*quota): the kept SET is {score >= n-th largest};
+// the n-th largest comes from the 256-bin histogram, and the score map is swept in raster order with
+// an ordered compaction, so candidates come out in canonical (y, x) order.
+__global__ __launch_bounds__(1024) void k_select_fast(const uint8_t* score, PyrGeom g, FrameFeat ff)
+{
+    __shared__ int s_w[17];
+    __shared__ int s_suffix[257];
+    __shared__ int s_T;
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom lv = g.lv[l];
+    const int want = g.score_type == 0 ? 2 * lv.quota : lv.quota;
+    const int edge = g.edge;
+    int* count_out = ff.cand_count + f * VO_MAX_LEVELS + l;
+    if (lv.w <= 2 * edge || lv.h <= 2 * edge || want <= 0) {
+        if (tid == 0) *count_out = 0;
+        return;
+    }
+    if (tid < 256) s_suffix[tid] = (int)ff.hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + tid];
+    if (tid == 0) s_suffix[256] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, T = 1;
+        bool found = false;
+        for (int v = 255; v >= 1; v--) {
+            acc += s_suffix[v];
+            if (!found && acc >= want) { T = v; found = true; }
+        }
+        s_T = T;                       // fewer than `want` candidates: keep them all
+    }
+    __syncthreads();
+    const int T = s_T;
+    const uint8_t* sc = score + (size_t)f * g.frame_bytes + lv.off;
+    const int d_lo = edge >> 2, d_hi = (lv.w - edge - 1) >> 2, ndw = d_hi - d_lo + 1;
+    const int nrows = lv.h - 2 * edge, total_items = nrows * ndw;
+    uint32_t* out_pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
+    float* out_resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
+    int base_out = 0;
+    bool overflow = false;
+    for (int base = 0; base < total_items; base += 1024) {
+        const int idx = base + tid;
+        uint32_t v = 0; int x4 = 0, y = 0, keep = 0;
+        if (idx < total_items) {
+            const int row = idx / ndw, dc = idx - row * ndw + d_lo;
+            y = edge + row; x4 = dc * 4;
+            v = *(const uint32_t*)(sc + (size_t)y * lv.stride + x4);
+        }
+        if (v) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int s = (v >> (8 * b)) & 255, x = x4 + b;
+                if (s >= T && x >= edge && x < lv.w - edge) keep |= 1 << b;
+            }
+        }
+        int tot;
+        int pos = base_out + block_excl_scan(__popc(keep), s_w, &tot);
+        if (keep) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (keep & (1 << b)) {
+                    if (pos < lv.cand_cap) {
+                        out_pos[pos] = ((uint32_t)y << 16) | (uint32_t)(x4 + b);
+                        out_resp[pos] = (float)((v >> (8 * b)) & 255);
+                    } else overflow = true;
+                    pos++;
+                }
+            }
+        }
+        base_out += tot;
+    }
+    if (overflow) atomicOr(&ff.flags[f], 1);
+    if (tid == 0) *count_out = min(base_out, lv.cand_cap);
+}
+
+void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F)
+{
+    hipLaunchKernelGGL(k_select_fast, dim3(g.nlevels, F), dim3(1024), 0, s, score, g, ff);
+}
+
+// ------------------------------------------------------------------ Harris response (orb.cpp HarrisResponses)
+__global__ void k_harris(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
+{
+    const int l = blockIdx.y, f = blockIdx.z;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const LevelGeom lv = g.lv[l];
+    if (i >= ff.cand_count[f * VO_MAX_LEVELS + l]) return;
+    const size_t ci = (size_t)f * g.cand_total + lv.cand_off + i;
+    const uint32_t pos = ff.cand_pos[ci];
+    const int x0 = pos & 0xffff, y0 = pos >> 16, st = lv.stride;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
+    int a = 0, b = 0, c = 0;
+    for (int yy = -3; yy <= 3; yy++) {
+        const uint8_t* p = img + (size_t)(y0 + yy) * st + x0 - 3;
+#pragma unroll
+        for (int xx = 0; xx < 7; xx++, p++) {
+            int Ix = (p[1] - p[-1]) * 2 + (p[-st + 1] - p[-st - 1]) + (p[st + 1] - p[st - 1]);
+            int Iy = (p[st] - p[-st]) * 2 + (p[st - 1] - p[-st - 1]) + (p[st + 1] - p[-st + 1]);
+            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+        }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    ff.cand_resp[ci] = ((float)a * (float)b - (float)c * (float)c - 0.04f * ((float)a + (float)b) * ((float)a + (float)b)) * scale_sq_sq;
+}
+
+void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F)
+{
+    int maxcap = 0;
+    for (int l = 0; l < g.nlevels; l++) maxcap = g.lv[l].cand_cap > maxcap ? g.lv[l].cand_cap : maxcap;
+    hipLaunchKernelGGL(k_harris, dim3((maxcap + 255) / 256, g.nlevels, F), dim3(256), 0, s, pyr, g, ff);
+}
+
+// ------------------------------------------------------------------ retainBest by response (per level), canonical order
+__device__ __forceinline__ uint32_t f2key(float v)
+{
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void k_select_harris(PyrGeom g, FrameFeat ff)
+{
+    __shared__ int s_w[17];
+    __shared__ int s_hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_remaining;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    int out_base = 0;
+    bool overflow = false;
+    uint32_t* kp_pos = ff.kp_pos + (size_t)f * g.kp_cap;
+    int* kp_level = ff.kp_level + (size_t)f * g.kp_cap;
+    float* kp_resp = ff.kp_resp + (size_t)f * g.kp_cap;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom lv = g.lv[l];
+        const int n = ff.cand_count[f * VO_MAX_LEVELS + l];
+        const uint32_t* pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
+        const float* resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
+        float thr = -FLT_MAX;
+        if (n > lv.quota && lv.quota > 0 && g.score_type == 0) {
+            // 32-bit radix select of the quota-th largest response, 8 bits per pass
+            if (tid == 0) { s_prefix = 0; s_remaining = lv.quota; }
+            uint32_t maskbits = 0;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                s_hist[tid] = 0;
+                __syncthreads();
+                const uint32_t prefix = s_prefix;
+                for (int i = tid; i < n; i += 256) {
+                    const uint32_t k = f2key(resp[i]);
+                    if ((k & maskbits) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int rem = s_remaining, d = 255;
+                    for (; d > 0; d--) { if (s_hist[d] >= rem) break; rem -= s_hist[d]; }
+                    s_remaining = rem;
+                    s_prefix = prefix | ((uint32_t)d << shift);
+                }
+                maskbits |= 255u << shift;
+                __syncthreads();
+            }
+            thr = key2f(s_prefix);
+        }
+        const int keep_all = (lv.quota <= 0) ? 0 : 1;     // retainBest(n_points == 0) clears
+        for (int base = 0; base < n; base += 256) {
+            const int i = base + tid;
+            const bool keep = keep_all && i < n && resp[i] >= thr;
+            int tot;
+            const int p = out_base + block_excl_scan(keep ? 1 : 0, s_w, &tot);
+            if (keep) {
+                if (p < g.kp_cap) { kp_pos[p] = pos[i]; kp_level[p] = l; kp_resp[p] = resp[i]; }
+                else overflow = true;
+            }
+            out_base += tot;
+        }
+        __syncthreads();
+    }
+    if (overflow) atomicOr(&ff.flags[f], 1);
+    if (tid == 0) ff.kp_count[f] = min(out_base, g.kp_cap);
+}
+
+void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F)
+{
+    hipLaunchKernelGGL(k_select_harris, dim3(F), dim3(256), 0, s, g, ff);
+}
+
+// ------------------------------------------------------------------ orientation (orb.cpp ICAngles + fastAtan2)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// one wavefront per keypoint: lanes 0..30 sweep the columns of rows v = -15..-1? no: lane = column u,
+// the wave walks the 31 rows; integer moments are order independent, reduced with shuffles.
+__global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= ff.kp_count[f]) return;
+    const size_t ki = (size_t)f * g.kp_cap + k;
+    const uint32_t pos = ff.kp_pos[ki];
+    const LevelGeom lv = g.lv[ff.kp_level[ki]];
+    const int x0 = pos & 0xffff, y0 = pos >> 16;
+    const uint8_t* center = pyr + (size_t)f * g.frame_bytes + lv.off + (size_t)y0 * lv.stride + x0;
+    // lanes 0..30: u = lane - 15 on rows v = -15..15 (upper half of the wave takes odd rows)
+    const int u = (lane & 31) - 15, half = lane >> 5;
+    int m10 = 0, m01 = 0;
+    if ((lane & 31) < 31) {
+        for (int r = half; r < 31; r += 2) {
+            const int v = r - 15, av = v < 0 ? -v : v;
+            if (u >= -c_umax[av] && u <= c_umax[av]) {
+                const int I = center[v * lv.stride + u];
+                m10 += u * I; m01 += v * I;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
+    if (lane == 0) ff.kp_angle[ki] = fast_atan2_deg((float)m01, (float)m10);
+}
+
+void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F)
+{
+    hipLaunchKernelGGL(k_angle, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, s, pyr, g, ff);
+}
+
+// ------------------------------------------------------------------ GaussianBlur(7x7, sigma 2), BORDER_REFLECT_101
+// sepFilter2D 8u integer path: taps {18,34,49,55,49,34,18}, (sum + 2^15) >> 16, saturated.
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+#define BL_LW (BLUR_TW + 8)
+#define BL_LH (BLUR_TH + 6)
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur, PyrGeom g)
+{
+    __shared__ uint8_t s_in[BL_LH * BL_LW];
+    __shared__ uint16_t s_h[BL_LH * BLUR_TW];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].btile_base) l++;
+    const LevelGeom lv = g.lv[l];
+    const int tile = blockIdx.x - lv.btile_base;
+    const int x0 = (tile % lv.btiles_x) * BLUR_TW, y0 = (tile / lv.btiles_x) * BLUR_TH;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
+    const bool interior = x0 >= 4 && x0 + BLUR_TW + 4 <= lv.w && y0 >= 3 && y0 + BLUR_TH + 3 <= lv.h;
+    if (interior) {
+        for (int i = tid; i < BL_LH * (BL_LW / 4); i += 256) {
+            const int ry = i / (BL_LW / 4), rx4 = (i % (BL_LW / 4)) * 4;
+            *(uint32_t*)(s_in + ry * BL_LW + rx4) = *(const uint32_t*)(img + (size_t)(y0 - 3 + ry) * lv.stride + x0 - 4 + rx4);
+        }
+    } else {
+        for (int i = tid; i < BL_LH * BL_LW; i += 256) {
+            const int ry = i / BL_LW, rx = i % BL_LW;
+            const int gy = reflect101(y0 - 3 + ry, lv.h), gx = reflect101(x0 - 4 + rx, lv.w);
+            s_in[i] = img[(size_t)gy * lv.stride + gx];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < BL_LH * BLUR_TW; i += 256) {
+        const int ry = i / BLUR_TW, rx = i % BLUR_TW;
+        const uint8_t* p = s_in + ry * BL_LW + rx + 1;       // column x0 + rx - 3
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += c_gauss7[k] * p[k];
+        s_h[i] = (uint16_t)s;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4, gy = y0 + ty;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int lx = tx * 4 + b;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s += c_gauss7[k] * s_h[(ty + k) * BLUR_TW + lx];
+        s = (s + (1 << 15)) >> 16;
+        out |= (uint32_t)(s > 255 ? 255 : s) << (8 * b);
+    }
+    if (gy < lv.h) *(uint32_t*)(blur + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 4) = out;
+}
+
+void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F)
+{
+    hipLaunchKernelGGL(k_blur, dim3(g.btiles_total, F), dim3(256), 0, s, pyr, blur, g);
+}
+
+// ------------------------------------------------------------------ steered BRIEF (orb.cpp computeOrbDescriptors, WTA_K = 2)
+// One wavefront per keypoint; lane j evaluates tests j, 64 + j, 128 + j, 192 + j; each ballot is 64
+// descriptor bits (8 bytes, LSB first).  Also writes the exported keypoint record.
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= ff.kp_count[f]) return;
+    const size_t ki = (size_t)f * g.kp_cap + k;
+    const uint32_t pos = ff.kp_pos[ki];
+    const int level = ff.kp_level[ki];
+    const LevelGeom lv = g.lv[level];
+    const int x0 = pos & 0xffff, y0 = pos >> 16;
+    const float sf = lv.scale;
+    const float kx = (float)x0 * sf, ky = (float)y0 * sf;
+    // computeOrbDescriptors re-derives the level position from the scaled keypoint
+    const float inv = 1.f / sf;
+    const int cx = __float2int_rn(kx * inv), cy = __float2int_rn(ky * inv);
+    const float angle_deg = ff.kp_angle[ki];
+    const float angle = angle_deg * (float)(3.1415926535897932384626433832795 / 180.f);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const uint8_t* center = blur + (size_t)f * g.frame_bytes + lv.off + (size_t)cy * lv.stride + cx;
+    uint64_t words[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int8_t* pt = c_pattern + (w * 64 + lane) * 4;
+        const float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
+        const float xa = px0 * a - py0 * b, ya = px0 * b + py0 * a;
+        const float xb = px1 * a - py1 * b, yb = px1 * b + py1 * a;
+        const int t0 = center[__float2int_rn(ya) * lv.stride + __float2int_rn(xa)];
+        const int t1 = center[__float2int_rn(yb) * lv.stride + __float2int_rn(xb)];
+        words[w] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        uint64_t wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+        *(uint64_t*)(ff.desc + ki * 32 + lane * 8) = wv;
+    }
+    if (lane == 0) {
+        ff.kp_xy[ki * 2] = kx; ff.kp_xy[ki * 2 + 1] = ky;
+        ff.kp_size[ki] = 31 * sf;
+    }
+}
+
+void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F)
+{
+    hipLaunchKernelGGL(k_brief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, s, blur, g, ff);
+}

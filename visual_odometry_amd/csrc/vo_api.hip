@@ -1,0 +1,852 @@
+// vo_api.hip — context, device buffers and the C ABI of libvo_hip.so (see include/vo_hip.h).
+// Host-side plumbing only: every arithmetic stage is a HIP kernel in orb_/match_/geom_kernels.hip.
+#include "vo_internal.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define MAX_EVENTS 96
+
+struct vo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+
+    bool configured = false;
+    int h = 0, w = 0, max_frames = 0, max_pairs = 0;
+    vo_orb_params params{};
+    PyrGeom g{};
+    ResizeTab tabs[VO_MAX_LEVELS]{};
+    void* tab_mem = nullptr;
+    uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
+    size_t staging_bytes = 0;
+    FrameFeat ff{};
+    PairBuf pb{};
+    int pb_pairs = 0, pb_cap = 0;
+    double* dK = nullptr;
+    int last_pairs = 0;
+
+    // scratch for the single-call operators
+    int raw_cap = 0;
+    uint8_t* raw_desc = nullptr; float* raw_xy = nullptr; int* raw_count = nullptr;
+    PairBuf raw_pb{};
+    double* raw_d = nullptr; size_t raw_d_n = 0;     // generic double scratch
+    int* raw_i = nullptr;
+
+    bool prof = false;
+    float prof_ms[VO_STAGE_COUNT] = {0};
+    int prof_n[VO_STAGE_COUNT] = {0};
+    hipEvent_t ev[MAX_EVENTS][2];
+    int ev_stage[MAX_EVENTS];
+    int n_ev = 0;
+    bool ev_ready = false;
+};
+
+static const char* k_stage_names[VO_STAGE_COUNT] = {
+    "gray", "pyramid_resize", "fast_score_nms", "select_fast", "harris", "select_harris", "ic_angle",
+    "gaussian_blur", "rbrief", "match_nn", "match_select", "essential_ransac", "recover_pose",
+    "triangulate", "misc", "reserved"};
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            snprintf(ctx->err, sizeof(ctx->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,    \
+                     hipGetErrorString(e_));                                                      \
+            return VO_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define FAIL(code, ...)                                                                           \
+    do { snprintf(ctx->err, sizeof(ctx->err), __VA_ARGS__); return (code); } while (0)
+
+template <typename T>
+static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
+
+// ------------------------------------------------------------------ profiling brackets
+struct StageTimer {
+    vo_ctx* c; int idx;
+    StageTimer(vo_ctx* ctx, int stage) : c(ctx), idx(-1)
+    {
+        if (c->prof && c->n_ev < MAX_EVENTS) {
+            idx = c->n_ev++;
+            c->ev_stage[idx] = stage;
+            (void)hipEventRecord(c->ev[idx][0], c->stream);
+        }
+    }
+    ~StageTimer() { if (idx >= 0) (void)hipEventRecord(c->ev[idx][1], c->stream); }
+};
+
+static void prof_collect(vo_ctx* c)
+{
+    for (int i = 0; i < c->n_ev; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]) == hipSuccess) {
+            c->prof_ms[c->ev_stage[i]] += ms;
+            c->prof_n[c->ev_stage[i]] += 1;
+        }
+    }
+    c->n_ev = 0;
+}
+
+// ------------------------------------------------------------------ geometry (host)
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int cv_floor_d(double v) { int i = (int)v; return i - (i > v); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static int check_params(vo_ctx* ctx, const vo_orb_params* p)
+{
+    if (!p) FAIL(VO_ERR_INVALID, "params is NULL");
+    if (p->first_level != 0 || p->wta_k != 2 || p->patch_size != 31)
+        FAIL(VO_ERR_INVALID, "only firstLevel=0, WTA_K=2, patchSize=31 are supported");
+    if (p->nlevels < 1 || p->nlevels > VO_MAX_LEVELS) FAIL(VO_ERR_INVALID, "nlevels out of range");
+    if (p->edge_threshold < 19 || p->edge_threshold > 255) FAIL(VO_ERR_INVALID, "edgeThreshold must be in [19, 255]");
+    if (p->fast_threshold < 1 || p->fast_threshold > 254) FAIL(VO_ERR_INVALID, "fastThreshold must be in [1, 254]");
+    if (p->score_type != 0 && p->score_type != 1) FAIL(VO_ERR_INVALID, "scoreType must be 0 (HARRIS) or 1 (FAST)");
+    if (p->nfeatures < 0 || p->nfeatures > 100000) FAIL(VO_ERR_INVALID, "nfeatures out of range");
+    if (!(p->scale_factor > 1.0f)) FAIL(VO_ERR_INVALID, "scaleFactor must be > 1");
+    return VO_OK;
+}
+
+// orb.cpp: layerScale, level sizes and per-level quotas
+static int make_geometry(vo_ctx* ctx, int h, int w, const vo_orb_params* p, PyrGeom* g)
+{
+    memset(g, 0, sizeof(*g));
+    const int L = p->nlevels;
+    g->nlevels = L; g->edge = p->edge_threshold; g->fast_thr = p->fast_threshold;
+    g->score_type = p->score_type; g->nfeatures = p->nfeatures;
+    const double sf = (double)p->scale_factor;
+    const float factor = (float)(1.0 / sf);
+    float nd = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0, off = 0, ft = 0, bt = 0, co = 0;
+    for (int l = 0; l < L; l++) {
+        LevelGeom& lv = g->lv[l];
+        lv.scale = (float)pow(sf, (double)l);
+        lv.w = cv_round_f((float)w / lv.scale);
+        lv.h = cv_round_f((float)h / lv.scale);
+        if (lv.w < 1 || lv.h < 1) FAIL(VO_ERR_INVALID, "pyramid level %d is empty (%dx%d input)", l, w, h);
+        if (lv.w > 65535 || lv.h > 65535) FAIL(VO_ERR_INVALID, "image too large");
+        lv.stride = align_up(lv.w, 64);
+        lv.off = off;
+        off += lv.stride * lv.h;
+        if (l < L - 1) { lv.quota = cv_round_f(nd); sum += lv.quota; nd *= factor; }
+        else lv.quota = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
+        lv.ftile_base = ft; lv.ftiles_x = (lv.w + FAST_TW - 1) / FAST_TW;
+        ft += lv.ftiles_x * ((lv.h + FAST_TH - 1) / FAST_TH);
+        lv.btile_base = bt; lv.btiles_x = (lv.w + BLUR_TW - 1) / BLUR_TW;
+        bt += lv.btiles_x * ((lv.h + BLUR_TH - 1) / BLUR_TH);
+        const int want = p->score_type == 0 ? 2 * lv.quota : lv.quota;
+        lv.cand_off = co;
+        lv.cand_cap = align_up(want + (want > 1024 ? want : 1024), 8);
+        co += lv.cand_cap;
+    }
+    g->frame_bytes = align_up(off, 256);
+    g->ftiles_total = ft; g->btiles_total = bt;
+    g->cand_total = co;
+    g->kp_cap = align_up(p->nfeatures + (p->nfeatures / 8 > 256 ? p->nfeatures / 8 : 256), 8);
+    return VO_OK;
+}
+
+// resize.cpp interpolationLinear<ufixedpoint16>::getCoeffs
+static void build_lin_tab(int ssize, int dsize, int* ofs, uint16_t* c1, int* pmin, int* pmax)
+{
+    const double inv_scale = (double)dsize / (double)ssize;
+    const double scale = 1.0 / inv_scale;
+    int minofst = 0, maxofst = dsize;
+    for (int val = 0; val < dsize; val++) {
+        volatile double fval = scale * ((double)val + 0.5);
+        fval = fval - 0.5;
+        const double fv = fval;
+        const int ival = cv_floor_d(fv);
+        ofs[val] = 0; c1[val] = 0;
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) {
+                ofs[val] = ival;
+                volatile double fr = fv - (double)ival;
+                fr = fr * 256.0;
+                c1[val] = (uint16_t)lrint((double)fr);
+            } else {
+                ofs[val] = ssize - 1;
+                if (val < maxofst) maxofst = val;
+            }
+        } else if (val + 1 > minofst) minofst = val + 1;
+    }
+    *pmin = minofst; *pmax = maxofst;
+}
+
+// ------------------------------------------------------------------ buffers
+static void free_pairbuf(PairBuf& pb)
+{
+    void* ptrs[] = {pb.slots, pb.nn_idx, pb.nn_dist, pb.nn_idx2, pb.nn_dist2, pb.m_q, pb.m_t, pb.m_d, pb.m_count,
+                    pb.px1, pb.px2, pb.xn1, pb.xn2, pb.mask, pb.models, pb.nmodels, pb.in1, pb.in2, pb.ipx1, pb.ipx2,
+                    pb.res, pb.X, pb.pose_mask};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    memset(&pb, 0, sizeof(pb));
+}
+
+static hipError_t alloc_pairbuf(PairBuf& pb, int P, int cap, bool with_pose_mask)
+{
+    hipError_t e;
+    const size_t pc = (size_t)P * cap;
+#define A_(field, n) if ((e = dmalloc(&pb.field, (n))) != hipSuccess) return e
+    A_(slots, (size_t)P * 2); A_(nn_idx, pc * 2); A_(nn_dist, pc * 2); A_(nn_idx2, pc); A_(nn_dist2, pc);
+    A_(m_q, pc); A_(m_t, pc); A_(m_d, pc); A_(m_count, (size_t)P);
+    A_(px1, pc * 2); A_(px2, pc * 2); A_(xn1, pc * 2); A_(xn2, pc * 2);
+    A_(mask, pc); A_(models, (size_t)P * 64 * 90); A_(nmodels, (size_t)P * 64);
+    A_(in1, pc * 2); A_(in2, pc * 2); A_(ipx1, pc * 2); A_(ipx2, pc * 2);
+    A_(res, (size_t)P); A_(X, pc * 4);
+    if (with_pose_mask) { A_(pose_mask, pc); }
+#undef A_
+    return hipSuccess;
+}
+
+static void free_config(vo_ctx* c)
+{
+    void* ptrs[] = {c->tab_mem, c->pyr, c->blur, c->score, c->ff.cand_pos, c->ff.cand_resp, c->ff.cand_count,
+                    c->ff.kp_pos, c->ff.kp_level, c->ff.kp_resp, c->ff.kp_angle, c->ff.kp_xy, c->ff.kp_size,
+                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr;
+    memset(&c->ff, 0, sizeof(c->ff));
+    free_pairbuf(c->pb);
+    c->pb_pairs = c->pb_cap = 0;
+    c->configured = false;
+}
+
+extern "C" int vo_version(void) { return 100; }
+
+extern "C" int vo_create(int device_id, vo_ctx** out)
+{
+    if (!out) return VO_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return VO_ERR_HIP;
+    vo_ctx* ctx = new vo_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+        dmalloc(&ctx->dK, 16) != hipSuccess) {
+        delete ctx;
+        return VO_ERR_HIP;
+    }
+    for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventCreate(&ctx->ev[i][0]); (void)hipEventCreate(&ctx->ev[i][1]); }
+    ctx->ev_ready = true;
+    *out = ctx;
+    return VO_OK;
+}
+
+extern "C" void vo_destroy(vo_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_config(ctx);
+    free_pairbuf(ctx->raw_pb);
+    void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* vo_last_error(const vo_ctx* ctx) { return ctx ? ctx->err : "ctx is NULL"; }
+
+// ------------------------------------------------------------------ configuration
+extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params* params, int max_frames, int max_pairs)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    int rc = check_params(ctx, params);
+    if (rc) return rc;
+    if (h < 1 || w < 1 || max_frames < 1 || max_pairs < 1) FAIL(VO_ERR_INVALID, "bad sizes");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->configured && ctx->h == h && ctx->w == w && memcmp(&ctx->params, params, sizeof(*params)) == 0 &&
+        ctx->max_frames >= max_frames && ctx->max_pairs >= max_pairs)
+        return VO_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_config(ctx);
+    PyrGeom g;
+    rc = make_geometry(ctx, h, w, params, &g);
+    if (rc) return rc;
+    ctx->g = g; ctx->h = h; ctx->w = w; ctx->params = *params;
+    ctx->max_frames = max_frames; ctx->max_pairs = max_pairs;
+
+    // resize tables
+    size_t tab_ints = 0, tab_u16 = 0;
+    for (int l = 1; l < g.nlevels; l++) { tab_ints += g.lv[l].w + g.lv[l].h; tab_u16 += g.lv[l].w + g.lv[l].h; }
+    std::vector<int> hofs(tab_ints + 1);
+    std::vector<uint16_t> hc(tab_u16 + 1);
+    const size_t int_bytes = (tab_ints + 1) * sizeof(int);
+    HIPCHK(hipMalloc(&ctx->tab_mem, int_bytes + (tab_u16 + 1) * sizeof(uint16_t) + 64));
+    int* d_ofs = (int*)ctx->tab_mem;
+    uint16_t* d_c = (uint16_t*)((char*)ctx->tab_mem + int_bytes);
+    size_t oi = 0;
+    for (int l = 1; l < g.nlevels; l++) {
+        ResizeTab& t = ctx->tabs[l];
+        const LevelGeom &s = g.lv[l - 1], &d = g.lv[l];
+        build_lin_tab(s.w, d.w, &hofs[oi], &hc[oi], &t.min_x, &t.max_x);
+        t.xofs = d_ofs + oi; t.xc1 = d_c + oi; oi += d.w;
+        build_lin_tab(s.h, d.h, &hofs[oi], &hc[oi], &t.min_y, &t.max_y);
+        t.yofs = d_ofs + oi; t.yc1 = d_c + oi; oi += d.h;
+    }
+    HIPCHK(hipMemcpy(d_ofs, hofs.data(), int_bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_c, hc.data(), (tab_u16 + 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
+
+    const size_t F = (size_t)max_frames, fb = (size_t)g.frame_bytes;
+    HIPCHK(hipMalloc((void**)&ctx->pyr, F * fb));
+    HIPCHK(hipMalloc((void**)&ctx->blur, F * fb));
+    HIPCHK(hipMalloc((void**)&ctx->score, F * fb));
+    HIPCHK(hipMemset(ctx->pyr, 0, F * fb));
+    FrameFeat& ff = ctx->ff;
+    HIPCHK(dmalloc(&ff.cand_pos, F * g.cand_total)); HIPCHK(dmalloc(&ff.cand_resp, F * g.cand_total));
+    HIPCHK(dmalloc(&ff.cand_count, F * VO_MAX_LEVELS));
+    HIPCHK(dmalloc(&ff.kp_pos, F * g.kp_cap)); HIPCHK(dmalloc(&ff.kp_level, F * g.kp_cap));
+    HIPCHK(dmalloc(&ff.kp_resp, F * g.kp_cap)); HIPCHK(dmalloc(&ff.kp_angle, F * g.kp_cap));
+    HIPCHK(dmalloc(&ff.kp_xy, F * g.kp_cap * 2)); HIPCHK(dmalloc(&ff.kp_size, F * g.kp_cap));
+    HIPCHK(dmalloc(&ff.desc, F * g.kp_cap * 32));
+    HIPCHK(dmalloc(&ff.kp_count, F)); HIPCHK(dmalloc(&ff.flags, F));
+    HIPCHK(dmalloc(&ff.hist, F * VO_MAX_LEVELS * 256));
+    HIPCHK(hipMemset(ff.kp_count, 0, F * sizeof(int)));
+    HIPCHK(hipMemset(ff.flags, 0, F * sizeof(int)));
+    HIPCHK(alloc_pairbuf(ctx->pb, max_pairs, g.kp_cap, false));
+    ctx->pb_pairs = max_pairs; ctx->pb_cap = g.kp_cap;
+    ctx->configured = true;
+    return VO_OK;
+}
+
+extern "C" int vo_frames_upload(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (row_stride < ctx->w) FAIL(VO_ERR_INVALID, "row_stride < width");
+    HIPCHK(hipSetDevice(ctx->device));
+    const LevelGeom& lv = ctx->g.lv[0];
+    for (int f = 0; f < F; f++) {
+        uint8_t* dst = ctx->pyr + (size_t)(first_slot + f) * ctx->g.frame_bytes + lv.off;
+        HIPCHK(hipMemcpy2DAsync(dst, lv.stride, frames + (size_t)f * frame_stride, row_stride, ctx->w, ctx->h,
+                                hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// stages up to `upto` (0 = pyramid only, 1 = + FAST score map, 2 = everything)
+static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
+{
+    const PyrGeom& g = ctx->g;
+    hipStream_t s = ctx->stream;
+    uint8_t* pyr = ctx->pyr + (size_t)first_slot * g.frame_bytes;
+    uint8_t* blur = ctx->blur + (size_t)first_slot * g.frame_bytes;
+    uint8_t* score = ctx->score + (size_t)first_slot * g.frame_bytes;
+    FrameFeat ff = ctx->ff;
+    ff.cand_pos += (size_t)first_slot * g.cand_total; ff.cand_resp += (size_t)first_slot * g.cand_total;
+    ff.cand_count += (size_t)first_slot * VO_MAX_LEVELS;
+    ff.kp_pos += (size_t)first_slot * g.kp_cap; ff.kp_level += (size_t)first_slot * g.kp_cap;
+    ff.kp_resp += (size_t)first_slot * g.kp_cap; ff.kp_angle += (size_t)first_slot * g.kp_cap;
+    ff.kp_xy += (size_t)first_slot * g.kp_cap * 2; ff.kp_size += (size_t)first_slot * g.kp_cap;
+    ff.desc += (size_t)first_slot * g.kp_cap * 32;
+    ff.kp_count += first_slot; ff.flags += first_slot;
+    ff.hist += (size_t)first_slot * VO_MAX_LEVELS * 256;
+    {
+        StageTimer t(ctx, ST_RESIZE);
+        for (int l = 1; l < g.nlevels; l++) launch_resize(s, pyr, g, l, ctx->tabs[l], F);
+    }
+    if (upto < 1) return VO_OK;
+    {
+        StageTimer t(ctx, ST_MISC);
+        HIPCHK(hipMemsetAsync(ff.hist, 0, (size_t)F * VO_MAX_LEVELS * 256 * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(ff.flags, 0, (size_t)F * sizeof(int), s));
+    }
+    { StageTimer t(ctx, ST_FAST); launch_fast(s, pyr, score, ff.hist, g, F); }
+    if (upto < 2) return VO_OK;
+    { StageTimer t(ctx, ST_SELECT_FAST); launch_select_fast(s, score, g, ff, F); }
+    if (g.score_type == 0) { StageTimer t(ctx, ST_HARRIS); launch_harris(s, pyr, g, ff, F); }
+    { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F); }
+    { StageTimer t(ctx, ST_ANGLE); launch_angle(s, pyr, g, ff, F); }
+    { StageTimer t(ctx, ST_BLUR); launch_blur(s, pyr, blur, g, F); }
+    { StageTimer t(ctx, ST_BRIEF); launch_brief(s, blur, g, ff, F); }
+    return VO_OK;
+}
+
+extern "C" int vo_frames_detect(vo_ctx* ctx, int first_slot, int F)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (F == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = run_detect(ctx, first_slot, F, 2);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+extern "C" int vo_frame_features(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                                 int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (slot < 0 || slot >= ctx->max_frames || !n_out) FAIL(VO_ERR_INVALID, "bad slot");
+    HIPCHK(hipSetDevice(ctx->device));
+    const PyrGeom& g = ctx->g;
+    int n = 0, flags = 0;
+    HIPCHK(hipMemcpy(&n, ctx->ff.kp_count + slot, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&flags, ctx->ff.flags + slot, sizeof(int), hipMemcpyDeviceToHost));
+    int warn = (flags & 1) ? VO_WARN_CAPACITY : VO_OK;
+    if (n > cap) { n = cap; warn = VO_WARN_CAPACITY; }
+    *n_out = n;
+    const size_t o = (size_t)slot * g.kp_cap;
+    if (n > 0) {
+        if (kp_xy) HIPCHK(hipMemcpy(kp_xy, ctx->ff.kp_xy + o * 2, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_size) HIPCHK(hipMemcpy(kp_size, ctx->ff.kp_size + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_angle) HIPCHK(hipMemcpy(kp_angle, ctx->ff.kp_angle + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_response) HIPCHK(hipMemcpy(kp_response, ctx->ff.kp_resp + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_octave) HIPCHK(hipMemcpy(kp_octave, ctx->ff.kp_level + o, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, ctx->ff.desc + o * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    return warn;
+}
+
+// upload one host image (any channel count) into slot 0 and build its gray level 0
+static int load_single(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride, const vo_orb_params* params)
+{
+    if (!img || h < 1 || w < 1) FAIL(VO_ERR_INVALID, "bad image");
+    if (channels != 1 && channels != 3 && channels != 4) FAIL(VO_ERR_INVALID, "channels must be 1, 3 or 4");
+    if (row_stride < w * channels) FAIL(VO_ERR_INVALID, "row_stride too small");
+    int mf = ctx->configured ? ctx->max_frames : 1, mp = ctx->configured ? ctx->max_pairs : 1;
+    int rc = vo_batch_configure(ctx, h, w, params, mf, mp);
+    if (rc) return rc;
+    if (channels == 1) return vo_frames_upload(ctx, img, 1, row_stride, 0, 0);
+    const size_t bytes = (size_t)row_stride * h;
+    if (bytes > ctx->staging_bytes) {
+        if (ctx->staging) (void)hipFree(ctx->staging);
+        ctx->staging = nullptr; ctx->staging_bytes = 0;
+        HIPCHK(hipMalloc((void**)&ctx->staging, bytes));
+        ctx->staging_bytes = bytes;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->staging, img, bytes, hipMemcpyHostToDevice, ctx->stream));
+    { StageTimer t(ctx, ST_GRAY); launch_gray(ctx->stream, ctx->staging, channels, row_stride, 0, ctx->pyr, ctx->g, 1); }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_orb_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                                         const vo_orb_params* params, float* kp_xy, float* kp_size, float* kp_angle,
+                                         float* kp_response, int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!n_out || cap < 0) FAIL(VO_ERR_INVALID, "bad output arguments");
+    int rc = check_params(ctx, params);
+    if (rc) return rc;
+    rc = load_single(ctx, img, h, w, channels, row_stride, params);
+    if (rc) return rc;
+    rc = vo_frames_detect(ctx, 0, 1);
+    if (rc) return rc;
+    return vo_frame_features(ctx, 0, kp_xy, kp_size, kp_angle, kp_response, kp_octave, desc, cap, n_out);
+}
+
+// download a padded per-level buffer of slot 0 into tight packing
+static int download_packed(vo_ctx* ctx, const uint8_t* dev_base, uint8_t* out)
+{
+    const PyrGeom& g = ctx->g;
+    std::vector<uint8_t> tmp((size_t)g.frame_bytes);
+    HIPCHK(hipMemcpy(tmp.data(), dev_base, (size_t)g.frame_bytes, hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& lv = g.lv[l];
+        for (int y = 0; y < lv.h; y++) { memcpy(out + o, tmp.data() + lv.off + (size_t)y * lv.stride, (size_t)lv.w); o += lv.w; }
+    }
+    return VO_OK;
+}
+
+static int stage_common(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                        const vo_orb_params* params, int upto)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    int rc = check_params(ctx, params);
+    if (rc) return rc;
+    rc = load_single(ctx, img, h, w, channels, row_stride, params);
+    if (rc) return rc;
+    rc = run_detect(ctx, 0, 1, upto);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+extern "C" int vo_stage_pyramid(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                                const vo_orb_params* params, uint8_t* out_packed)
+{
+    int rc = stage_common(ctx, img, h, w, channels, row_stride, params, 0);
+    return rc ? rc : download_packed(ctx, ctx->pyr, out_packed);
+}
+
+extern "C" int vo_stage_fast_scores(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                                    const vo_orb_params* params, uint8_t* out_packed)
+{
+    int rc = stage_common(ctx, img, h, w, channels, row_stride, params, 1);
+    return rc ? rc : download_packed(ctx, ctx->score, out_packed);
+}
+
+extern "C" int vo_stage_blur(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
+                             const vo_orb_params* params, uint8_t* out_packed)
+{
+    int rc = stage_common(ctx, img, h, w, channels, row_stride, params, 2);
+    return rc ? rc : download_packed(ctx, ctx->blur, out_packed);
+}
+
+// ------------------------------------------------------------------ pairs
+static int map_select_mode(int match_mode) { return match_mode == 0 ? 1 : 3; }
+
+static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const float* kp_xy, const int* kp_count, int cap,
+                     int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points)
+{
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemsetAsync(pb.res, 0, (size_t)P * sizeof(vo_pair_result), s));
+    {
+        StageTimer t(ctx, ST_MATCH_NN);
+        if (select_mode == 3) launch_match_nn(s, desc, kp_count, cap, pb, P, 1, 1);
+        else launch_match_nn(s, desc, kp_count, cap, pb, P, select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3, 0);
+    }
+    { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
+    if (!do_geometry) return VO_OK;
+    { StageTimer t(ctx, ST_RANSAC); launch_ransac(s, pb, cap, P, rp); }
+    { StageTimer t(ctx, ST_POSE); launch_pose(s, pb, cap, P, rp); }
+    if (want_points) { StageTimer t(ctx, ST_TRIANGULATE); launch_triangulate_pairs(s, pb, cap, P, rp); }
+    return VO_OK;
+}
+
+extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
+                            vo_pair_result* results, double* X, int32_t x_cap)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!pair_slots || !K || !opts || !results || B < 0 || B > ctx->max_pairs) FAIL(VO_ERR_INVALID, "bad pair batch arguments");
+    if (opts->match_mode != 0 && opts->match_mode != 1) FAIL(VO_ERR_INVALID, "match_mode must be 0 or 1");
+    if (!(opts->ransac_prob > 0 && opts->ransac_prob < 1)) FAIL(VO_ERR_INVALID, "ransac_prob must be in (0, 1)");
+    for (int i = 0; i < 2 * B; i++)
+        if (pair_slots[i] < 0 || pair_slots[i] >= ctx->max_frames) FAIL(VO_ERR_INVALID, "pair slot %d out of range", pair_slots[i]);
+    if (B == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int cap = ctx->g.kp_cap;
+    HIPCHK(hipMemcpyAsync(ctx->pb.slots, pair_slots, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    RansacParams rp{};
+    rp.prob = opts->ransac_prob; rp.thresh_px = opts->ransac_thresh; rp.max_iters = opts->ransac_max_iters;
+    rp.seed = opts->ransac_seed; rp.dist_thresh = opts->pose_dist_thresh;
+    memcpy(rp.K, K, sizeof(rp.K));
+    const bool wp = opts->want_points != 0;
+    int rc = run_pairs(ctx, ctx->pb, ctx->ff.desc, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
+                       map_select_mode(opts->match_mode), opts->ratio, rp, true, wp);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(results, ctx->pb.res, (size_t)B * sizeof(vo_pair_result), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    ctx->last_pairs = B;
+    if (X && wp) {
+        if (x_cap < 1) FAIL(VO_ERR_INVALID, "x_cap must be positive");
+        for (int p = 0; p < B; p++) {
+            const int n = results[p].status == VO_OK ? (results[p].n_inl < x_cap ? results[p].n_inl : x_cap) : 0;
+            if (n <= 0) continue;
+            HIPCHK(hipMemcpy2D(X + (size_t)p * 4 * x_cap, (size_t)x_cap * sizeof(double),
+                               ctx->pb.X + (size_t)p * 4 * cap, (size_t)cap * sizeof(double),
+                               (size_t)n * sizeof(double), 4, hipMemcpyDeviceToHost));
+        }
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* dist, uint8_t* inlier_mask,
+                               int cap, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (pair < 0 || pair >= ctx->last_pairs || !n_out) FAIL(VO_ERR_INVALID, "bad pair index");
+    HIPCHK(hipSetDevice(ctx->device));
+    int n = 0;
+    HIPCHK(hipMemcpy(&n, ctx->pb.m_count + pair, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    *n_out = n;
+    const size_t o = (size_t)pair * ctx->g.kp_cap;
+    if (n > 0) {
+        if (qidx) HIPCHK(hipMemcpy(qidx, ctx->pb.m_q + o, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (tidx) HIPCHK(hipMemcpy(tidx, ctx->pb.m_t + o, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (dist) HIPCHK(hipMemcpy(dist, ctx->pb.m_d + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (inlier_mask) HIPCHK(hipMemcpy(inlier_mask, ctx->pb.mask + o, (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------ single-call matcher / geometry
+static int ensure_raw(vo_ctx* ctx, int cap)
+{
+    if (cap <= ctx->raw_cap) return VO_OK;
+    cap = align_up(cap + cap / 4 + 64, 64);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_pairbuf(ctx->raw_pb);
+    void* ptrs[] = {ctx->raw_desc, ctx->raw_xy, ctx->raw_count};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    ctx->raw_desc = nullptr; ctx->raw_xy = nullptr; ctx->raw_count = nullptr; ctx->raw_cap = 0;
+    HIPCHK(dmalloc(&ctx->raw_desc, (size_t)2 * cap * 32));
+    HIPCHK(dmalloc(&ctx->raw_xy, (size_t)2 * cap * 2));
+    HIPCHK(dmalloc(&ctx->raw_count, 2));
+    HIPCHK(hipMemset(ctx->raw_xy, 0, (size_t)2 * cap * 2 * sizeof(float)));
+    HIPCHK(alloc_pairbuf(ctx->raw_pb, 1, cap, true));
+    ctx->raw_cap = cap;
+    return VO_OK;
+}
+
+static int match_raw(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int select_mode, double ratio,
+                     int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!n_out || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t)) FAIL(VO_ERR_INVALID, "bad matcher arguments");
+    *n_out = 0;
+    if (nq == 0 || nt == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_raw(ctx, nq > nt ? nq : nt);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    const int cap = ctx->raw_cap;
+    const int counts[2] = {nq, nt}, slots[2] = {0, 1};
+    const double Kid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    HIPCHK(hipMemcpyAsync(ctx->raw_desc, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->raw_desc + (size_t)cap * 32, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->raw_count, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->raw_pb.slots, slots, sizeof(slots), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->dK, Kid, sizeof(Kid), hipMemcpyHostToDevice, s));
+    RansacParams rp{};
+    rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    int n = 0;
+    HIPCHK(hipMemcpyAsync(&n, ctx->raw_pb.m_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    *n_out = n;
+    if (n > 0) {
+        HIPCHK(hipMemcpy(qidx, ctx->raw_pb.m_q, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tidx, ctx->raw_pb.m_t, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(dist, ctx->raw_pb.m_d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_match_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int cross_check,
+                                int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (cross_check < 0 || cross_check > 2) FAIL(VO_ERR_INVALID, "cross_check must be 0, 1 or 2");
+    return match_raw(ctx, q, nq, t, nt, cross_check, 0.0, qidx, tidx, dist, n_out);
+}
+
+extern "C" int vo_knn2_ratio_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
+                                     int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out)
+{
+    return match_raw(ctx, q, nq, t, nt, 3, ratio, qidx, tidx, dist, n_out);
+}
+
+__global__ void k_prepare_points(PairBuf pb, int M, const double* Kd, int fill_mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) pb.m_count[0] = M;
+    if (i >= M) return;
+    const double ifx = 1. / Kd[0], ify = 1. / Kd[4];
+    const double bx = -Kd[2] * ifx, by = -Kd[5] * ify;
+    pb.xn1[2 * i] = pb.px1[2 * i] * ifx + bx; pb.xn1[2 * i + 1] = pb.px1[2 * i + 1] * ify + by;
+    pb.xn2[2 * i] = pb.px2[2 * i] * ifx + bx; pb.xn2[2 * i + 1] = pb.px2[2 * i + 1] * ify + by;
+    if (fill_mask) pb.mask[i] = 1;
+}
+
+static int upload_points(vo_ctx* ctx, const double* p1, const double* p2, int M, const double* K, int fill_mask)
+{
+    int rc = ensure_raw(ctx, M > 8 ? M : 8);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemsetAsync(ctx->raw_pb.res, 0, sizeof(vo_pair_result), s));
+    if (M > 0) {
+        HIPCHK(hipMemcpyAsync(ctx->raw_pb.px1, p1, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(ctx->raw_pb.px2, p2, (size_t)M * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(ctx->dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_prepare_points, dim3((M + 255) / 256 + 1), dim3(256), 0, s, ctx->raw_pb, M, ctx->dK, fill_mask);
+    return VO_OK;
+}
+
+extern "C" int vo_find_essential_ransac(vo_ctx* ctx, const double* p1, const double* p2, int M, const double* K,
+                                        double prob, double thresh_px, int max_iters, uint64_t seed,
+                                        double* E, uint8_t* mask, int32_t* n_inl, int32_t* n_models)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!p1 || !p2 || !K || !E || !mask || !n_inl || !n_models || M < 0) FAIL(VO_ERR_INVALID, "bad arguments");
+    *n_inl = 0; *n_models = 0;
+    if (M < 5) FAIL(VO_ERR_TOO_FEW, "findEssentialMat needs at least 5 correspondences, got %d", M);
+    if (!(prob > 0 && prob < 1)) FAIL(VO_ERR_INVALID, "prob must be in (0, 1)");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = upload_points(ctx, p1, p2, M, K, 0);
+    if (rc) return rc;
+    RansacParams rp{};
+    rp.prob = prob; rp.thresh_px = thresh_px; rp.max_iters = max_iters; rp.seed = seed; rp.dist_thresh = 50;
+    memcpy(rp.K, K, sizeof(rp.K));
+    { StageTimer t(ctx, ST_RANSAC); launch_ransac(ctx->stream, ctx->raw_pb, ctx->raw_cap, 1, rp); }
+    HIPCHK(hipGetLastError());
+    vo_pair_result res;
+    HIPCHK(hipMemcpyAsync(&res, ctx->raw_pb.res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(mask, ctx->raw_pb.mask, (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_collect(ctx);
+    if (res.status != VO_OK) FAIL(res.status, "essential-matrix RANSAC found no model");
+    *n_inl = res.n_inl;
+    if (M == 5) {
+        const int nm = res.reserved;
+        *n_models = nm;
+        HIPCHK(hipMemcpy(E, ctx->raw_pb.models, (size_t)nm * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+        *n_models = 1;
+        memcpy(E, res.E, sizeof(res.E));
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_recover_pose(vo_ctx* ctx, const double* E, const double* p1, const double* p2, int M, const double* K,
+                               double dist_thresh, double* R, double* t, uint8_t* mask, int32_t* n_good)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!E || !K || !R || !t || !n_good || M < 0 || (M > 0 && (!p1 || !p2))) FAIL(VO_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = upload_points(ctx, p1, p2, M, K, 1);
+    if (rc) return rc;
+    vo_pair_result res{};
+    memcpy(res.E, E, sizeof(res.E));
+    res.status = VO_OK; res.n_match = M;
+    HIPCHK(hipMemcpyAsync(ctx->raw_pb.res, &res, sizeof(res), hipMemcpyHostToDevice, ctx->stream));
+    RansacParams rp{};
+    rp.dist_thresh = dist_thresh; rp.prob = 0.99; rp.thresh_px = 1; rp.max_iters = 1;
+    memcpy(rp.K, K, sizeof(rp.K));
+    { StageTimer tm(ctx, ST_POSE); launch_pose(ctx->stream, ctx->raw_pb, ctx->raw_cap, 1, rp); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&res, ctx->raw_pb.res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    if (mask && M > 0) HIPCHK(hipMemcpyAsync(mask, ctx->raw_pb.pose_mask, (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_collect(ctx);
+    memcpy(R, res.R, sizeof(res.R)); memcpy(t, res.t, sizeof(res.t));
+    *n_good = res.n_good;
+    return VO_OK;
+}
+
+static int ensure_raw_d(vo_ctx* ctx, size_t n)
+{
+    if (n <= ctx->raw_d_n) return VO_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->raw_d) (void)hipFree(ctx->raw_d);
+    ctx->raw_d = nullptr; ctx->raw_d_n = 0;
+    HIPCHK(dmalloc(&ctx->raw_d, n + n / 4 + 64));
+    ctx->raw_d_n = n + n / 4 + 64;
+    if (!ctx->raw_i) HIPCHK(dmalloc(&ctx->raw_i, 16));
+    return VO_OK;
+}
+
+extern "C" int vo_triangulate(vo_ctx* ctx, const double* P1, const double* P2, const double* x1, const double* x2,
+                              int M, double* X)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!P1 || !P2 || M < 0 || (M > 0 && (!x1 || !x2 || !X))) FAIL(VO_ERR_INVALID, "bad arguments");
+    if (M == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_raw_d(ctx, 24 + (size_t)8 * M);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    double* d = ctx->raw_d;
+    double *dP1 = d, *dP2 = d + 12, *dx1 = d + 24, *dx2 = dx1 + 2 * (size_t)M, *dX = dx2 + 2 * (size_t)M;
+    HIPCHK(hipMemcpyAsync(dP1, P1, 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dP2, P2, 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dx1, x1, (size_t)2 * M * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dx2, x2, (size_t)2 * M * sizeof(double), hipMemcpyHostToDevice, s));
+    { StageTimer t(ctx, ST_TRIANGULATE); launch_triangulate_raw(s, dP1, dP2, dx1, dx2, M, dX); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(X, dX, (size_t)4 * M * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+extern "C" int vo_stage_five_point(vo_ctx* ctx, const double* x1, const double* x2, double* E, int32_t* n_models)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!x1 || !x2 || !E || !n_models) FAIL(VO_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_raw_d(ctx, 128);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    double* d = ctx->raw_d;
+    HIPCHK(hipMemcpyAsync(d, x1, 10 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d + 10, x2, 10 * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_five_point_raw(s, d, d + 10, d + 20, ctx->raw_i);
+    HIPCHK(hipGetLastError());
+    int nm = 0;
+    HIPCHK(hipMemcpyAsync(&nm, ctx->raw_i, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_models = nm;
+    if (nm > 0) HIPCHK(hipMemcpy(E, d + 20, (size_t)nm * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+extern "C" int vo_profile_enable(vo_ctx* ctx, int on)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    ctx->prof = on != 0;
+    ctx->n_ev = 0;
+    return VO_OK;
+}
+
+extern "C" int vo_profile_reset(vo_ctx* ctx)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
+    memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
+    ctx->n_ev = 0;
+    return VO_OK;
+}
+
+extern "C" int vo_profile_read(vo_ctx* ctx, float* ms, int32_t* launches)
+{
+    if (!ctx || !ms || !launches) return VO_ERR_INVALID;
+    memcpy(ms, ctx->prof_ms, sizeof(ctx->prof_ms));
+    memcpy(launches, ctx->prof_n, sizeof(ctx->prof_n));
+    return VO_OK;
+}
+
+extern "C" const char* vo_stage_name(int stage)
+{
+    return stage >= 0 && stage < VO_STAGE_COUNT ? k_stage_names[stage] : "?";
+}
+
+// Algorithmic HBM bytes per launch (SURVEY.md 8(d) accounting: u8 pixels = 1 B; each streaming stage reads its
+// input once and writes its output once; padding columns are not counted).
+extern "C" double vo_stage_bytes(vo_ctx* ctx, int stage, int F)
+{
+    if (!ctx || !ctx->configured) return 0.0;
+    const PyrGeom& g = ctx->g;
+    double px[VO_MAX_LEVELS], total = 0;
+    for (int l = 0; l < g.nlevels; l++) { px[l] = (double)g.lv[l].w * g.lv[l].h; total += px[l]; }
+    const double N = g.nfeatures;
+    double b = 0;
+    switch (stage) {
+    case ST_RESIZE: b = (total - px[g.nlevels - 1]) + (total - px[0]); break;   // reads levels 0..L-2, writes 1..L-1
+    case ST_FAST: b = total + total; break;                                       // reads the pyramid, writes the score map
+    case ST_SELECT_FAST: b = total; break;
+    case ST_HARRIS: b = 2 * N * 81 + 2 * N * 4; break;
+    case ST_ANGLE: b = N * 749; break;
+    case ST_BLUR: b = total + total; break;
+    case ST_BRIEF: b = N * 512 + N * 32 + N * 28; break;
+    default: b = 0;
+    }
+    return b * F;
+}

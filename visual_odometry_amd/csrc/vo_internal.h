@@ -1,0 +1,122 @@
+// vo_internal.h — shared declarations of libvo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vo_hip.h"
+
+#define VO_HALF_PATCH 15
+
+// ---- stage ids for vo_profile_* (index into ctx->prof) -------------------------------------
+enum {
+    ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_SELECT_FAST, ST_HARRIS, ST_SELECT_HARRIS, ST_ANGLE,
+    ST_BLUR, ST_BRIEF, ST_MATCH_NN, ST_MATCH_SELECT, ST_RANSAC, ST_POSE, ST_TRIANGULATE,
+    ST_MISC, ST_RESERVED
+};
+
+// ---- pyramid / work geometry, passed to kernels by value ------------------------------------
+struct LevelGeom {
+    int w, h, stride, off;       // level image; off = byte offset inside one frame's pyramid
+    int quota;                   // ORB per-level feature budget
+    float scale;                 // layerScale[l]
+    int ftile_base, ftiles_x;    // FAST tiles (prefix over levels)
+    int btile_base, btiles_x;    // blur tiles
+    int cand_off, cand_cap;      // candidate slots of this level inside a frame's candidate arrays
+};
+
+struct PyrGeom {
+    int nlevels, frame_bytes;    // frame_bytes: pyramid bytes per frame
+    int edge, fast_thr, score_type, nfeatures;
+    int ftiles_total, btiles_total;
+    int cand_total, kp_cap;
+    LevelGeom lv[VO_MAX_LEVELS];
+};
+
+struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (device pointers)
+    const int* xofs; const uint16_t* xc1;
+    const int* yofs; const uint16_t* yc1;
+    int min_x, max_x, min_y, max_y;
+};
+
+#define FAST_TW 64
+#define FAST_TH 16
+#define BLUR_TW 64
+#define BLUR_TH 16
+
+// per-frame feature arrays (device), F = number of slots
+struct FrameFeat {
+    uint32_t* cand_pos;   // [F][cand_total]  (y << 16 | x), level coordinates
+    float*    cand_resp;  // [F][cand_total]
+    int*      cand_count; // [F][VO_MAX_LEVELS]
+    uint32_t* kp_pos;     // [F][kp_cap]
+    int*      kp_level;   // [F][kp_cap]
+    float*    kp_resp;    // [F][kp_cap]
+    float*    kp_angle;   // [F][kp_cap]
+    float*    kp_xy;      // [F][kp_cap][2]   level-0 coordinates (pt * layerScale)
+    float*    kp_size;    // [F][kp_cap]
+    uint8_t*  desc;       // [F][kp_cap][32]
+    int*      kp_count;   // [F]
+    int*      flags;      // [F]  bit0: capacity overflow
+    uint32_t* hist;       // [F][VO_MAX_LEVELS][256] FAST score histogram
+};
+
+// per-pair arrays (device), P = number of pairs
+struct PairBuf {
+    int*      slots;      // [P][2]
+    int*      nn_idx;     // [P][2 dirs][kp_cap]      dir 0: frame1->frame2, dir 1: frame2->frame1
+    int*      nn_dist;    // [P][2][kp_cap]
+    int*      nn_idx2;    // [P][kp_cap] second neighbour (knn2)
+    int*      nn_dist2;   // [P][kp_cap]
+    int*      m_q;        // [P][kp_cap]
+    int*      m_t;        // [P][kp_cap]
+    float*    m_d;        // [P][kp_cap]
+    int*      m_count;    // [P]
+    double*   px1;        // [P][kp_cap][2] pixel coords of matches (float64)
+    double*   px2;
+    double*   xn1;        // [P][kp_cap][2] normalised coords
+    double*   xn2;
+    uint8_t*  mask;       // [P][kp_cap] E-RANSAC inlier mask
+    double*   models;     // [P][64][90] workspace: five-point models of one RANSAC round
+    int*      nmodels;    // [P][64]
+    double*   in1;        // [P][kp_cap][2] normalised inliers
+    double*   in2;
+    double*   ipx1;       // [P][kp_cap][2] pixel inliers
+    double*   ipx2;
+    vo_pair_result* res;  // [P]
+    double*   X;          // [P][4][kp_cap]
+    uint8_t*  pose_mask;  // [P][kp_cap] recoverPose mask (0/255); only allocated for the single-call path
+};
+
+struct RansacParams {
+    double prob, thresh_px;
+    int max_iters;
+    uint64_t seed;
+    double K[9];
+    double dist_thresh;
+};
+
+// ---- launchers (defined in the .hip files) --------------------------------------------------
+void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
+                 uint8_t* pyr, const PyrGeom& g, int F);
+void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F);
+void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F);
+void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F);
+void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
+void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F);
+void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
+void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F);
+void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F);
+
+void launch_match_nn(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb, int P,
+                     int dirs_mask, int knn2);
+void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
+                         int mode, double ratio, const double* K);
+// raw descriptor sets (single-call API): nearest neighbours of a in b
+void launch_nn_raw(hipStream_t s, const uint8_t* a, int na, const uint8_t* b, int nb, int* idx, int* dist,
+                   int* idx2, int* dist2, int knn2);
+
+void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
+void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
+void launch_triangulate_pairs(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
+void launch_triangulate_raw(hipStream_t s, const double* P1, const double* P2, const double* x1, const double* x2,
+                            int M, double* X);
+void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm);

@@ -1,0 +1,113 @@
+"""Batched, device-resident front end: frames live in HBM, ORB + matching + E-RANSAC + pose (+ DLT) run
+batch-major through the C ABI with no host round trip between stages.  This is the throughput path
+bench.py measures; the per-pair order is that of src/visual_slam.py:294-298."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .detector import make_params
+from .geometry import OPENCV_RNG_SEED
+
+MATCH_CROSSCHECK, MATCH_RATIO = 0, 1
+
+
+class FrontEnd:
+    def __init__(self, height, width, max_frames, max_pairs, nfeatures=500, nlevels=8, device=0, ctx=None, **orb_kw):
+        self.ctx = ctx or _lib.Context(device)
+        self.h, self.w = int(height), int(width)
+        self.max_frames, self.max_pairs = int(max_frames), int(max_pairs)
+        self.params = make_params(nfeatures=nfeatures, nlevels=nlevels, **orb_kw)
+        c = self.ctx
+        c.check(c.lib.vo_batch_configure(c.handle, self.h, self.w, C.addressof(self.params), self.max_frames,
+                                         self.max_pairs))
+        self.kp_cap = self.params.nfeatures + max(self.params.nfeatures // 8, 256) + 8
+
+    def upload(self, frames, first_slot=0):
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        if f.ndim == 2:
+            f = f[None]
+        if f.ndim != 3 or f.shape[1:] != (self.h, self.w):
+            raise ValueError(f"frames must be [F, {self.h}, {self.w}] uint8 (gray)")
+        c = self.ctx
+        c.check(c.lib.vo_frames_upload(c.handle, f.ctypes.data, f.shape[0], f.strides[1], f.strides[0], int(first_slot)))
+
+    def detect(self, first_slot, count):
+        c = self.ctx
+        c.check(c.lib.vo_frames_detect(c.handle, int(first_slot), int(count)))
+
+    def features(self, slot):
+        cap = self.kp_cap
+        xy = np.empty((cap, 2), np.float32); size = np.empty(cap, np.float32); ang = np.empty(cap, np.float32)
+        resp = np.empty(cap, np.float32); octv = np.empty(cap, np.int32); desc = np.empty((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        c = self.ctx
+        rc = c.check(c.lib.vo_frame_features(c.handle, int(slot), xy.ctypes.data, size.ctypes.data, ang.ctypes.data,
+                                             resp.ctypes.data, octv.ctypes.data, desc.ctypes.data, cap, C.addressof(n)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=ang[:k].copy(), response=resp[:k].copy(),
+                    octave=octv[:k].copy(), desc=desc[:k].copy(), truncated=(rc == _lib.VO_WARN_CAPACITY))
+
+    def make_opts(self, match_mode=MATCH_CROSSCHECK, ratio=0.75, prob=0.99, thresh=1.0, max_iters=1000,
+                  seed=OPENCV_RNG_SEED, dist_thresh=50.0, want_points=False):
+        return _lib.PairOpts(int(match_mode), float(ratio), float(prob), float(thresh), int(max_iters), int(seed),
+                             float(dist_thresh), int(bool(want_points)))
+
+    def run_pairs(self, pair_slots, K, opts=None, want_points=False):
+        """pair_slots: [B, 2] int32 of detected slots. Returns (results structured array [B], X or None)."""
+        ps = np.ascontiguousarray(pair_slots, dtype=np.int32).reshape(-1, 2)
+        B = len(ps)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        opts = opts or self.make_opts(want_points=want_points)
+        res = np.zeros(B, _lib.PAIR_RESULT_DTYPE)
+        X = np.zeros((B, 4, self.kp_cap)) if opts.want_points else None
+        c = self.ctx
+        c.check(c.lib.vo_pairs_run(c.handle, ps.ctypes.data, B, K.ctypes.data, C.addressof(opts), res.ctypes.data,
+                                   _lib.ptr(X), self.kp_cap))
+        return res, X
+
+    def pair_matches(self, pair):
+        cap = self.kp_cap
+        qi = np.empty(cap, np.int32); ti = np.empty(cap, np.int32); d = np.empty(cap, np.float32)
+        m = np.empty(cap, np.uint8); n = C.c_int32(0)
+        c = self.ctx
+        c.check(c.lib.vo_pair_matches(c.handle, int(pair), qi.ctypes.data, ti.ctypes.data, d.ctypes.data,
+                                      m.ctypes.data, cap, C.addressof(n)))
+        k = n.value
+        return qi[:k].copy(), ti[:k].copy(), d[:k].copy(), m[:k].copy()
+
+    # ---- measurement ------------------------------------------------------------------------
+    def profile(self, on=True):
+        c = self.ctx
+        c.check(c.lib.vo_profile_enable(c.handle, int(on)))
+        c.check(c.lib.vo_profile_reset(c.handle))
+
+    def profile_read(self):
+        ms = np.zeros(_lib.VO_STAGE_COUNT, np.float32); n = np.zeros(_lib.VO_STAGE_COUNT, np.int32)
+        c = self.ctx
+        c.check(c.lib.vo_profile_read(c.handle, ms.ctypes.data, n.ctypes.data))
+        names = [c.lib.vo_stage_name(i).decode() for i in range(_lib.VO_STAGE_COUNT)]
+        return {names[i]: (float(ms[i]), int(n[i])) for i in range(_lib.VO_STAGE_COUNT) if n[i] > 0}
+
+    def stage_bytes(self, stage_name, frames):
+        c = self.ctx
+        for i in range(_lib.VO_STAGE_COUNT):
+            if c.lib.vo_stage_name(i).decode() == stage_name:
+                return float(c.lib.vo_stage_bytes(c.handle, i, int(frames)))
+        raise KeyError(stage_name)
+
+
+def chain_poses(R, t):
+    """Compose relative poses x_{k+1} ~ R_k x_k + t_k into camera-to-world 4x4 matrices (unit-norm t: the
+    scale of every step is unobservable, as in the reference's monocular front end)."""
+    T = np.eye(4)
+    out = [T.copy()]
+    for Rk, tk in zip(R, t):
+        step = np.eye(4)
+        step[:3, :3] = Rk
+        step[:3, 3] = np.asarray(tk).ravel()
+        T = T @ np.linalg.inv(step)
+        out.append(T.copy())
+    return np.stack(out)

@@ -1,0 +1,75 @@
+"""Brute-force Hamming matcher with cv2.BFMatcher's call surface, backed by HIP kernels.
+
+Stands in for `cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True)` as injected into ImagePair
+(reference: src/visual_slam.py:18,294, src/image_and_keypoints.py:9, src/image_pair.py:234-236) and adds
+knnMatch(k=2) + the ratio rule of src/feature_detection.py:20-26.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .types import DMatch
+
+NORM_HAMMING = 6
+
+
+def _desc(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2 or a.shape[1] != 32:
+        raise ValueError("descriptors must be an N x 32 uint8 array (ORB, 256 bits)")
+    return a
+
+
+class HammingMatcher:
+    def __init__(self, crossCheck: bool = False, strict_mutual: bool = False, ctx: _lib.Context | None = None):
+        self.crossCheck = bool(crossCheck)
+        self.strict_mutual = bool(strict_mutual)
+        self._ctx = ctx
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
+
+    def match_arrays(self, query, train):
+        q, t = _desc(query), _desc(train)
+        nq = len(q)
+        qi = np.empty(max(nq, 1), np.int32); ti = np.empty(max(nq, 1), np.int32); d = np.empty(max(nq, 1), np.float32)
+        n = C.c_int32(0)
+        mode = 0 if not self.crossCheck else (2 if self.strict_mutual else 1)
+        ctx = self.ctx
+        ctx.check(ctx.lib.vo_match_hamming(ctx.handle, q.ctypes.data, nq, t.ctypes.data, len(t), mode,
+                                           qi.ctypes.data, ti.ctypes.data, d.ctypes.data, C.addressof(n)))
+        k = n.value
+        return qi[:k].copy(), ti[:k].copy(), d[:k].copy()
+
+    def match(self, queryDescriptors, trainDescriptors):
+        qi, ti, d = self.match_arrays(queryDescriptors, trainDescriptors)
+        return [DMatch(a, b, c) for a, b, c in zip(qi.tolist(), ti.tolist(), d.tolist())]
+
+    def ratio_match_arrays(self, query, train, ratio):
+        q, t = _desc(query), _desc(train)
+        nq = len(q)
+        qi = np.empty(max(nq, 1), np.int32); ti = np.empty(max(nq, 1), np.int32); d = np.empty(max(nq, 1), np.float32)
+        n = C.c_int32(0)
+        ctx = self.ctx
+        ctx.check(ctx.lib.vo_knn2_ratio_hamming(ctx.handle, q.ctypes.data, nq, t.ctypes.data, len(t), float(ratio),
+                                                qi.ctypes.data, ti.ctypes.data, d.ctypes.data, C.addressof(n)))
+        k = n.value
+        return qi[:k].copy(), ti[:k].copy(), d[:k].copy()
+
+    def ratio_match(self, queryDescriptors, trainDescriptors, ratio=0.75):
+        """knnMatch(k=2) followed by `m.distance < ratio * n.distance` (feature_detection.py:24-26)."""
+        qi, ti, d = self.ratio_match_arrays(queryDescriptors, trainDescriptors, ratio)
+        return [DMatch(a, b, c) for a, b, c in zip(qi.tolist(), ti.tolist(), d.tolist())]
+
+
+def BFMatcher(normType=NORM_HAMMING, crossCheck=False) -> HammingMatcher:
+    """cv2.BFMatcher look-alike (Hamming only)."""
+    if normType != NORM_HAMMING:
+        raise NotImplementedError("only NORM_HAMMING is implemented (ORB descriptors)")
+    return HammingMatcher(crossCheck=crossCheck)
