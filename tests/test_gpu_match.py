@@ -1,0 +1,77 @@
+"""GPU parity: brute-force Hamming matcher (bit-exact index pairs) against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _descs(seed, n, dup_from=None, flip_bits=0):
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    if dup_from is not None:
+        m = min(n, len(dup_from))
+        d[:m] = dup_from[rng.permutation(len(dup_from))[:m]]
+        for i in range(m):                      # perturb a few bits so distances are small but not all zero
+            for b in rng.integers(0, 256, rng.integers(0, flip_bits + 1)):
+                d[i, b // 8] ^= 1 << (b % 8)
+    return d
+
+
+def _matcher(**kw):
+    from visual_odometry_amd.matcher import HammingMatcher
+    return HammingMatcher(**kw)
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(500, 500, 1), (2000, 2000, 2), (1, 7, 3), (257, 1023, 4), (2200, 1900, 5)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_match_modes_bit_exact(oracle, ctx, nq, nt, seed, mode):
+    t = _descs(seed, nt)
+    q = _descs(seed + 100, nq, dup_from=t, flip_bits=40)
+    m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+    gq, gt, gd = m.match_arrays(q, t)
+    rq, rt, rd = oracle.match_hamming(q, t, mode)
+    assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
+
+
+def test_ties_prefer_lowest_index(oracle, ctx):
+    # many exact duplicates: every tie must resolve to the lowest index, in both directions
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, (16, 32), dtype=np.uint8)
+    q = base[rng.integers(0, 16, 300)]
+    t = base[rng.integers(0, 16, 280)]
+    for mode in (0, 1, 2):
+        m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+        gq, gt, gd = m.match_arrays(q, t)
+        rq, rt, rd = oracle.match_hamming(q, t, mode)
+        assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
+
+
+@pytest.mark.parametrize("ratio", [0.3, 0.75, 0.9, 1.0])
+def test_knn2_ratio_bit_exact(oracle, ctx, ratio):
+    t = _descs(11, 1500)
+    q = _descs(12, 1700, dup_from=t, flip_bits=60)
+    gq, gt, gd = _matcher().ratio_match_arrays(q, t, ratio)
+    rq, rt, rd = oracle.knn2_ratio_hamming(q, t, ratio)
+    assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
+
+
+def test_empty_and_single(oracle, ctx):
+    m = _matcher(crossCheck=True)
+    e = np.zeros((0, 32), np.uint8)
+    one = _descs(1, 1)
+    assert m.match(e, one) == [] and m.match(one, e) == []
+    assert _matcher().ratio_match(one, one, 0.75) == []      # fewer than two train rows: no (m, n) pair
+    got = m.match(one, one)
+    assert len(got) == 1 and (got[0].queryIdx, got[0].trainIdx, got[0].distance) == (0, 0, 0.0)
+
+
+def test_real_descriptors(oracle, ctx, seq_small):
+    from visual_odometry_amd.detector import OrbDetector
+    det = OrbDetector(nfeatures=500)
+    d1 = det.detect_arrays(seq_small["frames"][0])["desc"]
+    d2 = det.detect_arrays(seq_small["frames"][1])["desc"]
+    gq, gt, gd = _matcher(crossCheck=True).match_arrays(d1, d2)
+    rq, rt, rd = oracle.match_hamming(d1, d2, 1)
+    assert len(gq) > 100
+    assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
+    assert np.all(np.diff(gq) > 0)       # ascending queryIdx, as BFMatcher.match returns them

@@ -1,0 +1,100 @@
+"""GPU parity of the whole per-pair path (batched, device resident) and of the drop-in ImagePair classes
+against the CPU oracle's restatement of src/visual_slam.py:294-298."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_pair(res, X, ref):
+    assert res["status"] == 0 and ref["rc"] == 0
+    assert (res["n_kp1"], res["n_kp2"], res["n_match"], res["n_inl"], res["n_good"]) == \
+           (ref["n_kp1"], ref["n_kp2"], ref["n_match"], ref["n_inl"], ref["n_good"])
+    got_rt = np.hstack([res["R"].reshape(3, 3), res["t"].reshape(3, 1)])
+    assert np.linalg.norm(got_rt - np.hstack([ref["R"], ref["t"]])) < 1e-4
+    n = ref["n_inl"]
+    rel = np.linalg.norm(X[:3, :n] - ref["X"][:3, :n], axis=0) / np.linalg.norm(ref["X"][:3, :n], axis=0)
+    assert rel.max() < 1e-3
+    assert np.allclose(X[3, :n], 1.0)
+
+
+@pytest.mark.parametrize("match_mode", [0, 1])
+def test_batched_pairs_match_oracle(oracle, seq_small, match_mode):
+    from visual_odometry_amd.frontend import FrontEnd
+    frames, K = seq_small["frames"], seq_small["K"]
+    fe = FrontEnd(480, 640, max_frames=4, max_pairs=4, nfeatures=500)
+    fe.upload(frames)
+    fe.detect(0, 4)
+    pairs = [[0, 1], [1, 2], [2, 3], [0, 3]]
+    opts = fe.make_opts(match_mode=match_mode, ratio=0.8, want_points=True)
+    res, X = fe.run_pairs(pairs, K, opts)
+    p = oracle.orb_params(nfeatures=500)
+    for i, (a, b) in enumerate(pairs):
+        ref = oracle.pair(frames[a], frames[b], p, K, match_mode=match_mode, ratio=0.8)
+        _check_pair(res[i], X[i], ref)
+        qi, ti, d, m = fe.pair_matches(i)
+        d1 = oracle.orb_detect_and_compute(frames[a], p)["desc"]; d2 = oracle.orb_detect_and_compute(frames[b], p)["desc"]
+        rq, rt, rd = oracle.match_hamming(d1, d2, 1) if match_mode == 0 else oracle.knn2_ratio_hamming(d1, d2, 0.8)
+        assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(d, rd)   # bit-exact match pairs
+
+
+def test_batch_is_independent_of_batching(seq_small):
+    """The same pair gives identical results alone and inside a batch (no cross-pair state)."""
+    from visual_odometry_amd.frontend import FrontEnd
+    frames, K = seq_small["frames"], seq_small["K"]
+    fe = FrontEnd(480, 640, max_frames=4, max_pairs=3, nfeatures=500)
+    fe.upload(frames); fe.detect(0, 4)
+    a, _ = fe.run_pairs([[0, 1], [1, 2], [2, 3]], K)
+    b, _ = fe.run_pairs([[1, 2]], K)
+    assert a[1].tobytes() == b[0].tobytes()
+
+
+def test_dropin_image_pair_flow(oracle, seq_small, capsys):
+    """FrameGenerator + ImagePair driven exactly as visual_slam.py:294-298 drives them."""
+    from visual_odometry_amd import FrameGenerator, ImagePair, ORB_create, BFMatcher
+    from visual_odometry_amd.matcher import NORM_HAMMING
+    frames, K = seq_small["frames"], seq_small["K"]
+    gen = FrameGenerator(ORB_create(nfeatures=500))
+    bf = BFMatcher(NORM_HAMMING, crossCheck=True)
+    f1, f2 = gen.make_frame(frames[0]), gen.make_frame(frames[1])
+    assert (f1.id, f2.id) == (0, 1) and f1.features[3].feature_id == (0, 3)
+    ip = ImagePair(f1, f2, bf, K)
+    ip.match_features()
+    ess = ip.determine_essential_matrix(ip.filtered_matches)
+    ip.estimate_camera_movement(ess)
+    ip.reconstruct_3d_points(ess)
+    out = capsys.readouterr().out
+    assert "relative movement in image pair" in out and "Reconstructed points" in out
+    ref = oracle.pair(frames[0], frames[1], oracle.orb_params(nfeatures=500), K)
+    assert len(ip.raw_matches) == ref["n_match"] and len(ess) == ref["n_inl"]
+    assert ip.t.shape == (3, 1) and ip.R.shape == (3, 3) and ip.relative_pose.shape == (4, 4)
+    assert np.linalg.norm(np.hstack([ip.R, ip.t]) - np.hstack([ref["R"], ref["t"]])) < 1e-4
+    X = ip.points3d_reconstr
+    assert X.shape == (4, len(ess)) and np.allclose(X[3], 1.0)
+    rel = np.linalg.norm(X[:3] - ref["X"][:3], axis=0) / np.linalg.norm(ref["X"][:3], axis=0)
+    assert rel.max() < 1e-3
+    m3 = ip.matches_with_3d_information[0]
+    assert m3.point == (X[0, 0], X[1, 0], X[2, 0]) and m3.featureid1[0] == 0 and m3.featureid2[0] == 1
+    # second entry, as add_information_to_map re-enters (visual_slam.py:165-172): explicit projection matrices
+    again = ip.determine_essential_matrix(ip.filtered_matches)
+    assert len(again) == len(ess)                       # fixed RANSAC seed: same inliers on the same data
+    ip.reconstruct_3d_points(again, np.eye(4)[:3], ip.relative_pose[:3])
+    assert ip.points3d_reconstr.shape == (4, len(ess))
+    vis = ip.visualize_matches(ess[:20])
+    assert vis.shape[1] == 2 * frames[0].shape[1]
+
+
+def test_too_few_matches_raises(ctx):
+    from visual_odometry_amd import Frame, ImagePair, BFMatcher, Feature, KeyPoint
+    from visual_odometry_amd.matcher import NORM_HAMMING
+
+    def mk(i, n):
+        f = Frame(np.zeros((64, 64), np.uint8)); f.id = i
+        f.keypoints = tuple(KeyPoint(10 + k, 10 + 2 * k) for k in range(n))
+        f.descriptors = np.random.default_rng(i).integers(0, 256, (n, 32), dtype=np.uint8)
+        f.features = [Feature(kp, d, (i, k)) for k, (kp, d) in enumerate(zip(f.keypoints, f.descriptors))]
+        return f
+    ip = ImagePair(mk(0, 3), mk(1, 3), BFMatcher(NORM_HAMMING, crossCheck=True), np.eye(3))
+    ip.match_features()
+    with pytest.raises(ValueError):
+        ip.determine_essential_matrix(ip.filtered_matches)
