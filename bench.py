@@ -49,7 +49,7 @@ def cpu_baseline(frames, K, nfeatures, nlevels, match_mode, ratio, budget_s=12.0
     t0 = time.perf_counter()
     O.pair(frames[0], frames[1], p, K, match_mode=match_mode, ratio=ratio, want_points=True)   # warm + cost probe
     one = time.perf_counter() - t0
-    sample = int(max(cores, min(n_pairs * 4, cores * max(1, int(budget_s / max(one, 1e-3))))))
+    sample = int(max(cores, min(4000, cores * max(1, int(budget_s / max(one, 1e-3))))))
     jobs = [(i % n_pairs) for i in range(sample)]
 
     def work(i):

@@ -1,0 +1,166 @@
+"""CPU: properties that pin the oracle's stages independently of any golden vector."""
+import numpy as np
+import pytest
+
+from conftest import random_image
+
+
+def test_resize_identity_and_constant(oracle):
+    img = random_image(1, 50, 70)
+    assert np.array_equal(oracle.resize_linear_exact(img, 70, 50), img)          # scale 1: coefficients (256, 0)
+    flat = np.full((60, 90), 137, np.uint8)
+    assert np.all(oracle.resize_linear_exact(flat, 75, 50) == 137)               # weights sum to one exactly
+
+
+def test_resize_is_separable_bilinear_within_rounding(oracle):
+    img = random_image(2, 120, 160)
+    out = oracle.resize_linear_exact(img, 133, 100).astype(np.float64)
+    sy = 120 / 100; sx = 160 / 133
+    ys = (np.arange(100) + 0.5) * sy - 0.5; xs = (np.arange(133) + 0.5) * sx - 0.5
+    y0 = np.clip(np.floor(ys).astype(int), 0, 118); x0 = np.clip(np.floor(xs).astype(int), 0, 158)
+    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    f = img.astype(np.float64)
+    ref = (f[y0][:, x0] * (1 - fx) + f[y0][:, x0 + 1] * fx) * (1 - fy) + (f[y0 + 1][:, x0] * (1 - fx) + f[y0 + 1][:, x0 + 1] * fx) * fy
+    assert np.abs(out - ref).max() <= 1.6        # 8-bit coefficient quantisation + final rounding
+
+
+def test_fast_score_definition(oracle):
+    """Score = the largest threshold at which the pixel is still a corner, NMS keeps strict local maxima."""
+    img = random_image(3, 64, 80)
+    s20 = oracle.fast_score_nms(img, 20)
+    ys, xs = np.nonzero(s20)
+    assert len(ys) > 0
+    assert s20[:3].sum() == 0 and s20[-3:].sum() == 0 and s20[:, :3].sum() == 0 and s20[:, -3:].sum() == 0
+    for y, x in list(zip(ys, xs))[:40]:
+        s = int(s20[y, x])
+        assert s >= 20
+        nb = s20[y - 1:y + 2, x - 1:x + 2].astype(int).copy(); nb[1, 1] = 0
+        assert nb.max() == 0                                  # two NMS survivors are never adjacent
+        if s < 254:
+            assert oracle.fast_score_nms(img, s)[y, x] in (s, 0)   # still a corner at threshold s (NMS may differ)
+    # raising the threshold never creates corners
+    s40 = oracle.fast_score_nms(img, 40)
+    assert np.count_nonzero(s40) <= np.count_nonzero(s20)
+
+
+def test_blur_constant_and_symmetry(oracle):
+    flat = np.full((40, 50), 200, np.uint8)
+    assert np.all(oracle.gaussian_blur7(flat) == 202)          # taps sum to 257: 200*257^2 >> 16 rounds to 202
+    img = random_image(4, 45, 61)
+    assert np.array_equal(oracle.gaussian_blur7(img[::-1, ::-1])[::-1, ::-1], oracle.gaussian_blur7(img))
+    assert np.array_equal(oracle.gaussian_blur7(img.T.copy()).T, oracle.gaussian_blur7(img))
+
+
+def test_detect_keeps_border_and_quota(oracle):
+    img = random_image(5, 300, 400)
+    p = oracle.orb_params(nfeatures=300)
+    d = oracle.orb_detect_and_compute(img, p)
+    lw, lh, ls, q = oracle.level_geometry(300, 400, p)
+    assert len(d["xy"]) <= 300 + 32 and len(d["xy"]) > 100
+    for l in range(8):
+        m = d["octave"] == l
+        if not m.any():
+            continue
+        x = d["xy"][m, 0] / ls[l]; y = d["xy"][m, 1] / ls[l]
+        assert x.min() >= 30.99 and x.max() < lw[l] - 31 + 0.01 and y.min() >= 30.99 and y.max() < lh[l] - 31 + 0.01
+        assert m.sum() >= min(q[l], m.sum())
+        key = np.rint(y).astype(np.int64) * 100000 + np.rint(x).astype(np.int64)
+        assert np.all(np.diff(key) > 0)                        # canonical (y, x) order inside a level
+    assert np.all(np.diff(d["octave"]) >= 0)
+    assert np.all((d["angle"] >= 0) & (d["angle"] < 360.001))
+
+
+def test_descriptor_rotation_covariance(oracle):
+    """Rotating the image by 180 degrees rotates keypoint angles by 180 and keeps most descriptor bits."""
+    img = random_image(6, 260, 260)
+    p = oracle.orb_params(nfeatures=200, nlevels=1)
+    a = oracle.orb_detect_and_compute(img, p)
+    b = oracle.orb_detect_and_compute(img[::-1, ::-1].copy(), p)
+    pos_b = {(259 - x, 259 - y): i for i, (x, y) in enumerate(b["xy"].astype(int).tolist())}
+    hits = 0
+    for i, (x, y) in enumerate(a["xy"].astype(int).tolist()):
+        j = pos_b.get((x, y))
+        if j is None:
+            continue
+        hits += 1
+        da = (a["angle"][i] - b["angle"][j]) % 360
+        assert abs(da - 180) < 1.0
+        assert np.unpackbits(a["desc"][i] ^ b["desc"][j]).sum() <= 40
+    assert hits > 50
+
+
+def test_matcher_semantics(oracle):
+    rng = np.random.default_rng(7)
+    t = rng.integers(0, 256, (60, 32), dtype=np.uint8)
+    q = t[rng.permutation(60)[:40]].copy()
+    qi, ti, d = oracle.match_hamming(q, t, 0)
+    assert np.array_equal(qi, np.arange(40)) and np.all(d == 0) and np.all((t[ti] == q).all(axis=1))
+    q1, t1, d1 = oracle.match_hamming(q, t, 1); q2, t2, d2 = oracle.match_hamming(q, t, 2)
+    assert np.array_equal(q1, q2) and np.array_equal(t1, t2)   # distinct exact matches: both cross-check rules agree
+    # cv2 crossCheck keeps a query as soon as SOME train row chose it; strict mutual NN can drop it
+    q = np.zeros((2, 32), np.uint8); t = np.zeros((2, 32), np.uint8)
+    q[1, 0] = 0b111; t[0, 0] = 0b1; t[1, 0] = 0b11111
+    a = oracle.match_hamming(q, t, 1); b = oracle.match_hamming(q, t, 2)
+    assert a[0].tolist() == [0, 1] and a[1].tolist() == [0, 1] and b[0].tolist() == [0] and b[1].tolist() == [0]
+    # ratio rule is strict
+    q = np.zeros((1, 32), np.uint8); t = np.zeros((2, 32), np.uint8); t[0, 0] = 1; t[1, 0] = 3
+    assert len(oracle.knn2_ratio_hamming(q, t, 0.5)[0]) == 0 and len(oracle.knn2_ratio_hamming(q, t, 0.51)[0]) == 1
+
+
+def rot(ax, ang):
+    ax = np.asarray(ax, float) / np.linalg.norm(ax)
+    k = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(ang) * k + (1 - np.cos(ang)) * k @ k
+
+
+def test_five_point_contains_true_essential(oracle):
+    rng = np.random.default_rng(8)
+    dists = []
+    for _ in range(60):
+        R = rot(rng.normal(size=3), rng.uniform(0, 0.3)); t = rng.normal(size=3); t /= np.linalg.norm(t)
+        X = rng.uniform(-2, 2, (5, 3)) + np.array([0, 0, 6])
+        x1 = X[:, :2] / X[:, 2:]; X2 = X @ R.T + t; x2 = X2[:, :2] / X2[:, 2:]
+        Es = oracle.five_point(x1, x2)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Et = tx @ R; Et /= np.linalg.norm(Et)
+        assert 1 <= len(Es) <= 10
+        dists.append(min(min(np.linalg.norm(E - Et), np.linalg.norm(E + Et)) for E in Es))
+        assert dists[-1] < 1e-3              # near-double roots of the degree-10 polynomial amplify rounding
+        for E in Es:
+            assert abs(np.linalg.norm(E) - 1) < 1e-12
+            assert max(abs(np.r_[x2[i], 1] @ E @ np.r_[x1[i], 1]) for i in range(5)) < 1e-7
+            assert np.linalg.norm(2 * E @ E.T @ E - np.trace(E @ E.T) * E) < 1e-2
+    assert np.percentile(dists, 90) < 1e-8
+
+
+def test_ransac_seed_and_iteration_rule(oracle):
+    rng = np.random.default_rng(9)
+    K = np.array([[700, 0, 300], [0, 700, 200], [0, 0, 1.0]])
+    R = rot([0, 1, 0.2], 0.04); t = np.array([1, 0, 0.1]); t /= np.linalg.norm(t)
+    X = rng.uniform(-3, 3, (300, 3)) + np.array([0, 0, 9])
+    p1 = ((X / X[:, 2:]) @ K.T)[:, :2]; X2 = X @ R.T + t; p2 = ((X2 / X2[:, 2:]) @ K.T)[:, :2]
+    rc, E, mask, n = oracle.find_essential_ransac(p1, p2, K)
+    assert rc == 0 and n == 300 and mask.all()                     # noise free: the first sample explains everything
+    a = oracle.find_essential_ransac(p1, p2, K); b = oracle.find_essential_ransac(p1, p2, K)
+    assert np.array_equal(a[1], b[1])                              # fixed seed -> deterministic
+    assert oracle.find_essential_ransac(p1[:4], p2[:4], K)[0] == -3    # < 5 points: cv2 returns None
+    ng, Rr, tr, pm = oracle.recover_pose(E[0], p1, p2, K)
+    assert ng == 300 and np.linalg.norm(Rr - R) < 1e-6 and np.linalg.norm(tr.ravel() - t) < 1e-6
+
+
+def test_triangulation_recovers_points(oracle):
+    rng = np.random.default_rng(10)
+    K = np.array([[700, 0, 300], [0, 700, 200], [0, 0, 1.0]])
+    R = rot([0.1, 1, 0], 0.1); t = np.array([[1.0], [0.2], [0.0]])
+    X = rng.uniform(-3, 3, (50, 3)) + np.array([0, 0, 9])
+    P0 = K @ np.eye(3, 4); P1 = K @ np.hstack([R, t])
+    x0 = P0 @ np.vstack([X.T, np.ones(50)]); x1 = P1 @ np.vstack([X.T, np.ones(50)])
+    Xr = oracle.triangulate(P0, P1, x0[:2] / x0[2], x1[:2] / x1[2])
+    assert np.abs(Xr[:3] / Xr[3] - X.T).max() < 1e-8
+
+
+@pytest.mark.parametrize("bad", ["first_level", "wta_k", "patch_size"])
+def test_unsupported_params_are_rejected(oracle, bad):
+    kw = {bad: {"first_level": 1, "wta_k": 3, "patch_size": 21}[bad]}
+    with pytest.raises(RuntimeError):
+        oracle.orb_detect_and_compute(random_image(11, 100, 100), oracle.orb_params(**kw))
