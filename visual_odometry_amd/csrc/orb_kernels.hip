@@ -126,10 +126,25 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 }
 
 // ------------------------------------------------------------------ FAST-9/16 + cornerScore + 3x3 NMS
-// fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  Tile FAST_TW x FAST_TH per workgroup, halo 4 in
-// LDS.  is_corner <=> a 9-arc of the 16-ring is all darker than v-t or all brighter than v+t, tested on
-// two 16-bit masks; score = max(A, B) - 1 with A/B the best arc minimum of (v - ring) / (ring - v).
-__device__ __forceinline__ bool has_arc9(uint32_t m)
+// fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  One workgroup = a FAST_TW x FAST_TH output tile.
+//  A. the tile + halo is staged in LDS with 16-byte global loads (rows are 64-byte aligned in HBM);
+//  B. high-speed pre-test, one lane = 4 horizontally adjacent pixels read as dwords from LDS and compared
+//     two at a time with packed 16-bit subtractions (v_perm_b32 + v_pk_sub_i16): a 9-arc of the 16-ring
+//     always contains two adjacent compass pixels (ring 0, 4, 8, 12), so a pixel can only be a corner if
+//     two adjacent compass pixels are both brighter than v+t or both darker than v-t (the same early-out
+//     OpenCV's FAST applies).  Survivors (a few % of pixels) are appended to an LDS queue;
+//  C. only queued pixels run the exact test (two 16-bit ring masks, 9 contiguous bits) and, if they are
+//     corners, cornerScore: max(A, B) - 1 with A/B the best 9-arc minimum of (v - ring) / (ring - v);
+//  D. 3x3 non-max suppression from the LDS score tile, dense dword stores of the score map, and the
+//     per-level score histogram that retainBest needs (LDS atomics, one global atomic per non-empty bin).
+#define FT_PXW 160                       // LDS pixel tile: columns x0-16 .. x0+143
+#define FT_PXH (FAST_TH + 8)             // rows y0-4 .. y0+TH+3
+#define FT_SCW 144                       // LDS score tile: columns x0-4 .. x0+139 (dword aligned with the output)
+#define FT_SCH (FAST_TH + 2)             // rows y0-1 .. y0+TH
+#define FT_GROUPS_X 34                   // dword groups covering x0-4 .. x0+131
+#define FT_QCAP (130 * (FAST_TH + 2))
+
+__device__ __forceinline__ bool has_arc9(uint32_t m)     // 16-bit ring mask: 9 cyclically contiguous bits set?
 {
     m |= m << 16;
     uint32_t x = m & (m >> 1);
@@ -139,24 +154,19 @@ __device__ __forceinline__ bool has_arc9(uint32_t m)
     return x != 0;
 }
 
-#define FT_LW (FAST_TW + 8)
-#define FT_LH (FAST_TH + 8)
-#define FT_SW (FAST_TW + 2)
-#define FT_SH (FAST_TH + 2)
-
-__device__ __forceinline__ int fast_score_at(const uint8_t* c, int t)   // c: centre in an LDS tile of row stride FT_LW
+// exact corner test + cornerScore<16>; 0 when the pixel is no corner. c: centre in the LDS pixel tile
+__device__ __forceinline__ int fast_corner_score(const uint8_t* c, int t)
 {
-    int v = c[0];
+    const int v = c[0];
     int d[16];
-    d[0]  = v - c[3 * FT_LW];      d[1]  = v - c[3 * FT_LW + 1];  d[2]  = v - c[2 * FT_LW + 2];  d[3]  = v - c[FT_LW + 3];
-    d[4]  = v - c[3];              d[5]  = v - c[-FT_LW + 3];     d[6]  = v - c[-2 * FT_LW + 2]; d[7]  = v - c[-3 * FT_LW + 1];
-    d[8]  = v - c[-3 * FT_LW];     d[9]  = v - c[-3 * FT_LW - 1]; d[10] = v - c[-2 * FT_LW - 2]; d[11] = v - c[-FT_LW - 3];
-    d[12] = v - c[-3];             d[13] = v - c[FT_LW - 3];      d[14] = v - c[2 * FT_LW - 2];  d[15] = v - c[3 * FT_LW - 1];
+    d[0]  = v - c[3 * FT_PXW];      d[1]  = v - c[3 * FT_PXW + 1];  d[2]  = v - c[2 * FT_PXW + 2];  d[3]  = v - c[FT_PXW + 3];
+    d[4]  = v - c[3];               d[5]  = v - c[-FT_PXW + 3];     d[6]  = v - c[-2 * FT_PXW + 2]; d[7]  = v - c[-3 * FT_PXW + 1];
+    d[8]  = v - c[-3 * FT_PXW];     d[9]  = v - c[-3 * FT_PXW - 1]; d[10] = v - c[-2 * FT_PXW - 2]; d[11] = v - c[-FT_PXW - 3];
+    d[12] = v - c[-3];              d[13] = v - c[FT_PXW - 3];      d[14] = v - c[2 * FT_PXW - 2];  d[15] = v - c[3 * FT_PXW - 1];
     uint32_t dark = 0, bright = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) { dark |= (uint32_t)(d[k] > t) << k; bright |= (uint32_t)(d[k] < -t) << k; }
     if (!has_arc9(dark) && !has_arc9(bright)) return 0;
-    // arc minima / maxima of 9 consecutive ring differences by doubling
     int mn[16], mx[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
@@ -166,19 +176,31 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* c, int t)   // c: ce
     int A = -256, B = -256;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        int a = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int b = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int a = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int b = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
         A = max(A, a);
         B = max(B, -b);
     }
     return max(A, B) - 1;
 }
 
+typedef short vo_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) - __builtin_bit_cast(vo_s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) + __builtin_bit_cast(vo_s16x2, b));
+}
+
 __global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g)
 {
-    __shared__ uint8_t s_px[FT_LH * FT_LW];
-    __shared__ uint8_t s_sc[FT_SH * FT_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
+    __shared__ uint16_t s_q[FT_QCAP];
     __shared__ uint32_t s_hist[256];
+    __shared__ int s_qn;
     const int f = blockIdx.y, tid = threadIdx.x;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].ftile_base) l++;
@@ -186,43 +208,92 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score
     const int tile = blockIdx.x - lv.ftile_base;
     const int x0 = (tile % lv.ftiles_x) * FAST_TW, y0 = (tile / lv.ftiles_x) * FAST_TH;
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
+    const int t = g.fast_thr;
+
+    // A. stage pixels (16-byte loads), clear the score tile, histogram and queue
     s_hist[tid] = 0;
-    // tile + halo 4, dword loads (x0 - 4 is 4-byte aligned, rows are 64-byte aligned)
-    for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
-        const int ry = i / (FT_LW / 4), rx4 = (i % (FT_LW / 4)) * 4;
-        const int gy = y0 - 4 + ry, gx = x0 - 4 + rx4;
-        uint32_t v = 0;
-        if (gy >= 0 && gy < lv.h && gx >= 0 && gx < lv.stride) v = *(const uint32_t*)(img + (size_t)gy * lv.stride + gx);
-        *(uint32_t*)(s_px + ry * FT_LW + rx4) = v;
+    if (tid == 0) s_qn = 0;
+    for (int i = tid; i < FT_SCH * FT_SCW / 16; i += 256) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < FT_PXH * (FT_PXW / 16); i += 256) {
+        const int ry = i / (FT_PXW / 16), rx = (i % (FT_PXW / 16)) * 16;
+        const int gy = y0 - 4 + ry, gx = x0 - 16 + rx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy >= 0 && gy < lv.h && gx >= 0 && gx + 16 <= lv.stride) v = *(const uint4*)(img + (size_t)gy * lv.stride + gx);
+        *(uint4*)(s_px + ry * FT_PXW + rx) = v;
     }
     __syncthreads();
-    // raw scores on the tile + 1 ring
-    for (int i = tid; i < FT_SH * FT_SW; i += 256) {
-        const int sy = i / FT_SW, sx = i % FT_SW;
-        const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-        int sc = 0;
-        if (gx >= 3 && gx < lv.w - 3 && gy >= 3 && gy < lv.h - 3)
-            sc = fast_score_at(s_px + (sy + 3) * FT_LW + (sx + 3), g.fast_thr);
-        s_sc[sy * FT_LW + sx] = (uint8_t)sc;
-    }
-    __syncthreads();
-    // NMS, 4 pixels per thread, one dword store
-    const int tx = tid & 15, ty = tid >> 4;
-    const int gy = y0 + ty;
-    uint32_t out = 0;
+
+    // B. compass pre-test on the tile + 1 ring, 4 pixels per lane, two pixels per packed 16-bit operation
+    const uint32_t T2 = (uint32_t)t * 0x00010001u;
+    const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
+    for (int gi = tid; gi < FT_GROUPS_X * FT_SCH; gi += 256) {
+        const int gr = gi / FT_GROUPS_X, gc = gi - gr * FT_GROUPS_X;
+        const int gy = y0 - 1 + gr;
+        const uint32_t* rowp = (const uint32_t*)(s_px + (gr + 3) * FT_PXW) + 3 + gc;     // dword of the group itself
+        const uint32_t c = rowp[0], wl = rowp[-1], wr = rowp[1];
+        const uint32_t up = rowp[-3 * (FT_PXW / 4)], dn = rowp[3 * (FT_PXW / 4)];
+        // even pixels (0, 2) / odd pixels (1, 3) widened to 16-bit lanes
+        const uint32_t c_e = c & 0x00ff00ffu, c_o = (c >> 8) & 0x00ff00ffu;
+        const uint32_t hi_e = pk_add16(c_e, T2), hi_o = pk_add16(c_o, T2);
+        const uint32_t lo_e = pk_sub16(c_e, T2), lo_o = pk_sub16(c_o, T2);
+        // ring 0 (0,+3) and ring 8 (0,-3): aligned dwords; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
+        const uint32_t r0_e = dn & 0x00ff00ffu, r0_o = (dn >> 8) & 0x00ff00ffu;
+        const uint32_t r8_e = up & 0x00ff00ffu, r8_o = (up >> 8) & 0x00ff00ffu;
+        const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, 0x0c050c03u), r4_o = __builtin_amdgcn_perm(wr, c, 0x0c060c04u);
+        const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, 0x0c030c01u), r12_o = __builtin_amdgcn_perm(c, wl, 0x0c040c02u);
+        // sign bit of each 16-bit lane: ring > v + t (bright) / ring < v - t (dark)
+        const uint32_t br_e = (pk_sub16(hi_e, r0_e) | pk_sub16(hi_e, r8_e)) & (pk_sub16(hi_e, r4_e) | pk_sub16(hi_e, r12_e));
+        const uint32_t br_o = (pk_sub16(hi_o, r0_o) | pk_sub16(hi_o, r8_o)) & (pk_sub16(hi_o, r4_o) | pk_sub16(hi_o, r12_o));
+        const uint32_t dk_e = (pk_sub16(r0_e, lo_e) | pk_sub16(r8_e, lo_e)) & (pk_sub16(r4_e, lo_e) | pk_sub16(r12_e, lo_e));
+        const uint32_t dk_o = (pk_sub16(r0_o, lo_o) | pk_sub16(r8_o, lo_o)) & (pk_sub16(r4_o, lo_o) | pk_sub16(r12_o, lo_o));
+        const uint32_t ce = (br_e | dk_e) & 0x80008000u, co = (br_o | dk_o) & 0x80008000u;
+        if ((ce | co) && gy >= 3 && gy < lv.h - 3) {
+            const int gx0 = x0 - 4 + 4 * gc;
+            const uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int lx = tx * 4 + b;
-        const uint8_t* c = s_sc + (ty + 1) * FT_LW + (lx + 1);
-        const int s = c[0];
-        if (s && s > c[-1] && s > c[1] && s > c[-FT_LW - 1] && s > c[-FT_LW] && s > c[-FT_LW + 1] &&
-            s > c[FT_LW - 1] && s > c[FT_LW] && s > c[FT_LW + 1]) {
-            out |= (uint32_t)s << (8 * b);
-            const int gx = x0 + lx;
-            if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[s], 1u);
+            for (int i = 0; i < 4; i++) {
+                if ((bits >> i) & 1u) {
+                    const int gx = gx0 + i;
+                    if (gx >= xlo && gx <= xhi) {
+                        const int pos = atomicAdd(&s_qn, 1);
+                        s_q[pos] = (uint16_t)(gr * 256 + 4 * gc + i);      // (score-tile row, column relative to x0-4)
+                    }
+                }
+            }
         }
     }
-    if (gy < lv.h) *(uint32_t*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 4) = out;
+    __syncthreads();
+
+    // C. exact test + cornerScore for the queued candidates only
+    const int nq = s_qn;
+    for (int e = tid; e < nq; e += 256) {
+        const int q = s_q[e], gr = q >> 8, cx = q & 255;                  // cx: column relative to x0-4
+        s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(s_px + (gr + 3) * FT_PXW + 12 + cx, t);
+    }
+    __syncthreads();
+
+    // D. NMS + dense store: 8 pixels (two dwords) per thread, 16 threads per row
+    const int tx = tid & 15, ty = tid >> 4, gy = y0 + ty;
+    uint32_t out[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int cx = 4 + tx * 8 + h * 4;                                // score-tile column of the dword
+        const uint8_t* c = s_sc + (ty + 1) * FT_SCW + cx;
+        if (*(const uint32_t*)c) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int s = c[b];
+                if (s && s > c[b - 1] && s > c[b + 1] && s > c[b - FT_SCW - 1] && s > c[b - FT_SCW] && s > c[b - FT_SCW + 1] &&
+                    s > c[b + FT_SCW - 1] && s > c[b + FT_SCW] && s > c[b + FT_SCW + 1]) {
+                    out[h] |= (uint32_t)s << (8 * b);
+                    const int gx = x0 + tx * 8 + h * 4 + b;
+                    if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[s], 1u);
+                }
+            }
+        }
+    }
+    if (gy < lv.h && x0 + tx * 8 < lv.stride)
+        *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(out[0], out[1]);
     __syncthreads();
     const uint32_t hv = s_hist[tid];
     if (hv) atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + tid], hv);

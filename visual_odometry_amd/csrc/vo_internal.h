@@ -37,7 +37,7 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
     int min_x, max_x, min_y, max_y;
 };
 
-#define FAST_TW 64
+#define FAST_TW 128
 #define FAST_TH 16
 #define BLUR_TW 64
 #define BLUR_TH 16
