@@ -15,6 +15,9 @@
 #include <float.h>
 
 #define WAVE 64
+#ifndef VO_DK_ITERS
+#define VO_DK_ITERS 300
+#endif
 
 // ------------------------------------------------------------------ one-sided Jacobi SVD
 // At: N rows of length M (row i = column i of the M x N matrix). Returns At rows = sigma_i u_i,
@@ -181,14 +184,21 @@ __device__ __forceinline__ void conv(const double* a, const double* b, double* r
         for (int j = 0; j <= NB; j++) r[i + j] += a[i] * b[j];
 }
 
-// cv::solvePoly's Durand-Kerner sweeps. FULL: degree 10 (the normal case, static indices).
+// cv::solvePoly's Durand-Kerner sweeps (Gauss-Seidel updates from the starting points (1+i)^k).
+// FULL: degree 10 (the normal case, static indices).  OpenCV always runs its 300 sweeps (its exit test is
+// maxDiff <= 0).  Here a lane stops as soon as further sweeps can only move rounding noise: every correction
+// below 4 ulp of its root, or the largest correction has been small and has stopped shrinking for two sweeps
+// (the noise floor of an ill-conditioned / multiple root).  The roots agree with the full iteration to
+// that noise floor; the exit is per lane, so a sample's result does not depend on its wave mates.
 template <bool FULL>
 __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, double* ri)
 {
+    double prev = 1e300;
+    int stall = 0;
 #pragma unroll 1
-    for (int iter = 0; iter < 300; iter++) {
+    for (int iter = 0; iter < VO_DK_ITERS; iter++) {
         bool conv_all = true;
-        double max_diff = 0;
+        double max_diff = 0, max_mag = 0;
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             if (FULL || i < n) {
@@ -217,20 +227,30 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
                 }
                 num = cdiv(num, denom);
                 rr[i] = p.re - num.re; ri[i] = p.im - num.im;
-                double ab = sqrt(num.re * num.re + num.im * num.im);
+                const double ab = sqrt(num.re * num.re + num.im * num.im);
                 max_diff = fmax(max_diff, ab);
-                double mag = fabs(rr[i]) + fabs(ri[i]);
+                const double mag = fabs(rr[i]) + fabs(ri[i]);
+                max_mag = fmax(max_mag, mag);
                 conv_all &= ab <= 4 * DBL_EPSILON * mag;
             }
         }
         if (max_diff <= 0 || conv_all) break;
+        if (max_diff < 1e-7 * (1.0 + max_mag)) {
+            if (max_diff > 0.5 * prev) { if (++stall >= 2) break; }
+            else stall = 0;
+        }
+        prev = max_diff;
     }
 }
 
 // ------------------------------------------------------------------ five-point solver, one sample per lane
 // x1, x2: 5 normalised correspondences (interleaved x,y). Writes up to 10 row-major 3x3 models
 // (x2^T E x1 = 0, unit Frobenius norm) to Eout and returns their number.
-__device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout)
+// cm: this lane's slice of the 10x20 elimination matrix in LDS, element (r, k) at cm[(r*20 + k) * FP_LANES]
+// (consecutive lanes hold consecutive doubles: conflict-free ds_read/write_b64).
+#define FP_LANES 64
+#define CM(r, k) cm[((r) * 20 + (k)) * FP_LANES]
+__device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout, double* cm)
 {
     double basis[36];
     {
@@ -291,7 +311,6 @@ __device__ __noinline__ int five_point_solve(const double* x1, const double* x2,
     }
 
     // 10 cubic constraints in (x, y, z): det(E) = 0 and (E E^T - 0.5 tr(E E^T) I) E = 0
-    double C[10][20];
     {
         double E[3][3][4];
 #pragma unroll
@@ -315,7 +334,7 @@ __device__ __noinline__ int five_point_solve(const double* x1, const double* x2,
                 mul21_acc(m, E[0][c], 1.0, row);
             }
 #pragma unroll
-            for (int i = 0; i < 20; i++) C[0][i] = row[i];
+            for (int i = 0; i < 20; i++) CM(0, i) = row[i];
         }
         double L[3][3][10];
 #pragma unroll
@@ -344,7 +363,7 @@ __device__ __noinline__ int five_point_solve(const double* x1, const double* x2,
 #pragma unroll
                 for (int k = 0; k < 3; k++) mul21_acc(L[r][k], E[k][c], 1.0, row);
 #pragma unroll
-                for (int i = 0; i < 20; i++) C[1 + r * 3 + c][i] = row[i];
+                for (int i = 0; i < 20; i++) CM(1 + r * 3 + c, i) = row[i];
             }
     }
 
@@ -352,23 +371,26 @@ __device__ __noinline__ int five_point_solve(const double* x1, const double* x2,
 #pragma unroll 1
     for (int col = 0; col < 10; col++) {
         int piv = col;
-        double best = fabs(C[col][col]);
+        double best = fabs(CM(col, col));
 #pragma unroll 1
-        for (int r = col + 1; r < 10; r++) { double v = fabs(C[r][col]); if (v > best) { best = v; piv = r; } }
+        for (int r = col + 1; r < 10; r++) { double v = fabs(CM(r, col)); if (v > best) { best = v; piv = r; } }
         if (best < 1e-300) return 0;
-        if (piv != col)
-#pragma unroll 1
-            for (int k = 0; k < 20; k++) { double t = C[col][k]; C[col][k] = C[piv][k]; C[piv][k] = t; }
-        double inv = 1.0 / C[col][col];
-#pragma unroll 1
-        for (int k = 0; k < 20; k++) C[col][k] *= inv;
+        double prow[20];
+        const double inv = 1.0 / CM(piv, col);
+#pragma unroll
+        for (int k = 0; k < 20; k++) {
+            const double a = CM(piv, k), b = CM(col, k);
+            prow[k] = a * inv;
+            CM(piv, k) = b;                      // row swap (no-op when piv == col)
+            CM(col, k) = prow[k];
+        }
 #pragma unroll 1
         for (int r = 0; r < 10; r++) {
             if (r == col) continue;
-            double f = C[r][col];
+            const double f = CM(r, col);
             if (f == 0) continue;
-#pragma unroll 1
-            for (int k = 0; k < 20; k++) C[r][k] -= f * C[col][k];
+#pragma unroll
+            for (int k = 0; k < 20; k++) CM(r, k) -= f * prow[k];
         }
     }
 
@@ -376,8 +398,9 @@ __device__ __noinline__ int five_point_solve(const double* x1, const double* x2,
     double Bx[3][4], By[3][4], Bc[3][5];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double* r1 = &C[2 * i + 4][10];
-        const double* r2 = &C[2 * i + 5][10];
+        double r1[10], r2[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) { r1[k] = CM(2 * i + 4, 10 + k); r2[k] = CM(2 * i + 5, 10 + k); }
         Bx[i][3] = -r2[0]; Bx[i][2] = r1[0] - r2[1]; Bx[i][1] = r1[1] - r2[2]; Bx[i][0] = r1[2];
         By[i][3] = -r2[3]; By[i][2] = r1[3] - r2[4]; By[i][1] = r1[4] - r2[5]; By[i][0] = r1[5];
         Bc[i][4] = -r2[6]; Bc[i][3] = r1[6] - r2[7]; Bc[i][2] = r1[7] - r2[8]; Bc[i][1] = r1[8] - r2[9]; Bc[i][0] = r1[9];
@@ -481,12 +504,13 @@ __device__ __forceinline__ float sampson_err(const double* E, double u1, double 
     return (float)(d * d / (Ex0 * Ex0 + Ex1 * Ex1 + Et0 * Et0 + Et1 * Et1));
 }
 
+// inliers of one model counted by one wavefront (ballot + popcount); optionally writes the mask
 __device__ __forceinline__ int count_inliers(const double* E, const double* x1, const double* x2, int M, float t,
-                                             int lane, uint8_t* mask_out)
+                                             int lane, int stride, int first, uint8_t* mask_out)
 {
     int good = 0;
-    for (int base = 0; base < M; base += WAVE) {
-        int i = base + lane;
+    for (int base = first; base < M; base += stride) {
+        const int i = base + lane;
         bool f = false;
         if (i < M) {
             f = sampson_err(E, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]) <= t;
@@ -497,116 +521,186 @@ __device__ __forceinline__ int count_inliers(const double* E, const double* x1, 
     return good;
 }
 
-// ------------------------------------------------------------------ RANSACPointSetRegistrator::run, one wave per pair
-__global__ __launch_bounds__(WAVE) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp)
+// ------------------------------------------------------------------ RANSACPointSetRegistrator::run, one workgroup (4 waves) per pair
+// Round = 64 minimal samples.  (1) sample indices: the RNG stream (OpenCV's MWC, data independent) is read
+// from a table, `% M` is taken by all threads in parallel, thread 0 only applies the repeat rejection;
+// (2) wave 0 solves the 64 samples, one per lane, elimination matrices and models in LDS; (3) the models
+// are scored four at a time (one per wave, ballot + popcount over the correspondences) and consumed strictly
+// in OpenCV's order, so the adaptive iteration count and the strict `>` rule behave as in the serial loop.
+#define RS_STREAM 448
+
+struct RansacShared {
+    double cm[200 * FP_LANES];          // 102400 B
+    double models[64 * 90];             //  46080 B
+    uint32_t stream[RS_STREAM];
+    int sub[64][5];
+    int nm[64];
+    int off[65];
+    uint8_t eh[640];
+    int cnt[2][4];
+    int used;
+};
+
+__global__ __launch_bounds__(256) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp, const uint32_t* rng_tab, int rng_n)
 {
-    const int p = blockIdx.x, lane = threadIdx.x;
+    __shared__ RansacShared sh;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = pb.m_count[p];
     const double* x1 = pb.xn1 + (size_t)p * kp_cap * 2;
     const double* x2 = pb.xn2 + (size_t)p * kp_cap * 2;
     uint8_t* mask = pb.mask + (size_t)p * kp_cap;
-    double* models = pb.models + (size_t)p * 64 * 90;
     vo_pair_result* res = pb.res + p;
-    __shared__ int s_sub[64][5];
-    __shared__ int s_nm[64];
 
     if (M < 5) {
-        if (lane == 0) { res->status = VO_ERR_TOO_FEW; res->n_inl = 0; res->ransac_iters = 0; }
-        for (int i = lane; i < M; i += WAVE) mask[i] = 0;
+        if (tid == 0) { res->status = VO_ERR_TOO_FEW; res->n_inl = 0; res->ransac_iters = 0; }
+        for (int i = tid; i < M; i += 256) mask[i] = 0;
         return;
     }
     const double threshold = rp.thresh_px / ((rp.K[0] + rp.K[4]) / 2);
     const float t = (float)(threshold * threshold);
-    uint64_t state = rp.seed ? rp.seed : 0xffffffffULL;
 
     if (M == 5) {       // ptsetreg.cpp: count == modelPoints -> all solutions, every point an inlier
-        if (lane == 0) {
-            int nm = five_point_solve(x1, x2, models);
+        if (tid == 0) {
+            double* models = pb.models + (size_t)p * 64 * 90;
+            int nm = five_point_solve(x1, x2, models, sh.cm);
             for (int k = 0; k < 9; k++) res->E[k] = nm > 0 ? models[k] : 0.0;
             res->status = nm > 0 ? VO_OK : VO_ERR_NO_MODEL;
             res->n_inl = nm > 0 ? 5 : 0;
             res->reserved = nm;          // number of stacked models left in pb.models
             res->ransac_iters = 0;
         }
-        if (lane < 5) mask[lane] = 1;
+        if (tid < 5) mask[tid] = 1;
         return;
     }
 
+    // every thread carries the same copy of the sequential state
     int niters = rp.max_iters > 1 ? rp.max_iters : 1;
-    int max_good = 0, iters_done = 0;
+    int max_good = 0, iters_done = 0, pos = 0;
     double bestE[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) bestE[k] = 0;
 
-    for (int r0 = 0; r0 < niters; r0 += WAVE) {
-        const int nh = min(WAVE, niters - r0);
-        if (lane == 0) {
+#ifdef VO_EXP_TIMING
+    long long tA = clock64(), tB = 0, tC = 0, tD = 0, tE = 0;
+#endif
+    for (int r0 = 0; r0 < niters; r0 += 64) {
+        const int nh = min(64, niters - r0);
+        // (1) sample indices
+        for (int i = tid; i < RS_STREAM; i += 256) sh.stream[i] = pos + i < rng_n ? rng_tab[pos + i] % (uint32_t)M : 0u;
+        __syncthreads();
+        if (tid == 0) {
+            int used = 0;
             for (int h = 0; h < nh; h++) {
                 int idx[5];
                 for (int i = 0; i < 5; i++) {
                     int v; bool dup;
                     do {
-                        v = (int)(rng_next(state) % (uint32_t)M);
+                        if (used < RS_STREAM && pos + used < rng_n) v = (int)sh.stream[used];
+                        else {                              // beyond the staged window / table: recompute directly
+                            uint64_t st = rp.seed ? rp.seed : 0xffffffffULL;
+                            uint32_t x = 0;
+                            if (pos + used < rng_n) x = rng_tab[pos + used];
+                            else { for (int q = 0; q <= pos + used; q++) x = rng_next(st); }
+                            v = (int)(x % (uint32_t)M);
+                        }
+                        used++;
                         dup = false;
                         for (int k = 0; k < i; k++) dup |= idx[k] == v;
                     } while (dup);
                     idx[i] = v;
-                    s_sub[h][i] = v;
+                    sh.sub[h][i] = v;
                 }
             }
+            sh.used = used;
         }
         __syncthreads();
-        int nm = 0;
-        if (lane < nh) {
-            double s1[10], s2[10];
+        pos += sh.used;
+#ifdef VO_EXP_TIMING
+        if (r0 == 0) tB = clock64();
+#endif
+        // (2) solve
+        if (wave == 0) {
+            int nm = 0;
+            if (lane < nh) {
+                double s1[10], s2[10];
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
-                int v = s_sub[lane][i];
-                s1[2 * i] = x1[2 * v]; s1[2 * i + 1] = x1[2 * v + 1];
-                s2[2 * i] = x2[2 * v]; s2[2 * i + 1] = x2[2 * v + 1];
+                for (int i = 0; i < 5; i++) {
+                    const int v = sh.sub[lane][i];
+                    s1[2 * i] = x1[2 * v]; s1[2 * i + 1] = x1[2 * v + 1];
+                    s2[2 * i] = x2[2 * v]; s2[2 * i + 1] = x2[2 * v + 1];
+                }
+                nm = five_point_solve(s1, s2, sh.models + lane * 90, sh.cm + lane);
             }
-            nm = five_point_solve(s1, s2, models + (size_t)lane * 90);
+            sh.nm[lane] = nm;
+            // exclusive prefix of the model counts + flattened (sample, model) list
+            int inc = nm;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+            sh.off[lane] = inc - nm;
+            if (lane == 63) sh.off[64] = inc;
+            for (int m = 0; m < nm; m++) sh.eh[inc - nm + m] = (uint8_t)lane;
         }
-        s_nm[lane] = nm;
-        __threadfence_block();
         __syncthreads();
-        // score in OpenCV's sequential order; niters shrinks as better models appear
-        for (int h = 0; h < nh; h++) {
-            if (r0 + h >= niters) break;
-            iters_done = r0 + h + 1;
-            const int nmh = s_nm[h];
-            for (int m = 0; m < nmh; m++) {
+#ifdef VO_EXP_TIMING
+        if (r0 == 0) tC = clock64();
+#endif
+        // (3) score four models at a time, consume in order
+        const int T = sh.off[64];
+        bool done = false;
+        for (int b = 0; b * 4 < T && !done; b++) {
+            const int e = b * 4 + wave;
+            if (e < T) {
+                const int h = sh.eh[e], m = e - sh.off[h];
                 double E[9];
 #pragma unroll
-                for (int k = 0; k < 9; k++) E[k] = models[(size_t)h * 90 + m * 9 + k];
-                int good = count_inliers(E, x1, x2, M, t, lane, nullptr);
+                for (int k = 0; k < 9; k++) E[k] = sh.models[h * 90 + m * 9 + k];
+                const int good = count_inliers(E, x1, x2, M, t, lane, 64, 0, nullptr);
+                if (lane == 0) sh.cnt[b & 1][wave] = good;
+            }
+            __syncthreads();
+            for (int w = 0; w < 4; w++) {
+                const int e2 = b * 4 + w;
+                if (e2 >= T) break;
+                const int h = sh.eh[e2];
+                if (r0 + h >= niters) { done = true; break; }
+                iters_done = r0 + h + 1;
+                const int good = sh.cnt[b & 1][w];
                 if (good > max(max_good, 4)) {
+                    const int m = e2 - sh.off[h];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) bestE[k] = E[k];
+                    for (int k = 0; k < 9; k++) bestE[k] = sh.models[h * 90 + m * 9 + k];
                     max_good = good;
                     niters = ransac_update_num_iters(rp.prob, (double)(M - good) / M, 5, niters);
                 }
             }
         }
+        if (!done) iters_done = min(r0 + nh, niters);
         __syncthreads();
+#ifdef VO_EXP_TIMING
+        if (r0 == 0) tD = clock64();
+#endif
     }
 
     if (max_good > 0) {
-        int good = count_inliers(bestE, x1, x2, M, t, lane, mask);
-        if (lane == 0) {
+        count_inliers(bestE, x1, x2, M, t, tid, 256, 0, mask);
+        if (tid == 0) {
 #pragma unroll
             for (int k = 0; k < 9; k++) res->E[k] = bestE[k];
-            res->n_inl = good; res->status = VO_OK; res->ransac_iters = iters_done; res->reserved = 1;
+            res->n_inl = max_good; res->status = VO_OK; res->ransac_iters = iters_done; res->reserved = 1;
+#ifdef VO_EXP_TIMING
+            tE = clock64();
+            res->n_kp1 = (int)(tB - tA); res->n_kp2 = (int)(tC - tB); res->n_match = (int)(tD - tC); res->n_good = (int)(tE - tD); res->reserved = iters_done;
+#endif
         }
     } else {
-        for (int i = lane; i < M; i += WAVE) mask[i] = 0;
-        if (lane == 0) { res->n_inl = 0; res->status = VO_ERR_NO_MODEL; res->ransac_iters = iters_done; res->reserved = 0; }
+        for (int i = tid; i < M; i += 256) mask[i] = 0;
+        if (tid == 0) { res->n_inl = 0; res->status = VO_ERR_NO_MODEL; res->ransac_iters = iters_done; res->reserved = 0; }
     }
 }
 
-void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
+void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp, const uint32_t* rng_tab, int rng_n)
 {
-    hipLaunchKernelGGL(k_ransac, dim3(P), dim3(WAVE), 0, s, pb, kp_cap, rp);
+    hipLaunchKernelGGL(k_ransac, dim3(P), dim3(256), 0, s, pb, kp_cap, rp, rng_tab, rng_n);
 }
 
 // ------------------------------------------------------------------ triangulation (DLT, 4x4 SVD per point)
@@ -738,13 +832,28 @@ __device__ void decompose_essential(const double* E, double* R1, double* R2, dou
 }
 
 // The E-RANSAC inliers are compacted in order (determine_essential_matrix returns them as a list,
-// image_pair.py:288-290), then the four (R, t) candidates are cheirality-tested on them.
-__global__ __launch_bounds__(WAVE) void k_pose(PairBuf pb, int kp_cap, RansacParams rp)
+// image_pair.py:288-290), then the four (R, t) candidates are cheirality-tested on them: one workgroup per
+// pair, every thread triangulates its share of the points (4x4 Jacobi SVD per point and candidate), the
+// per-candidate counts are wavefront ballots + popcounts summed through LDS.
+__device__ __forceinline__ bool cheirality(const double* P0, const double* P, const double* a, const double* b, double dist)
 {
-    const int p = blockIdx.x, lane = threadIdx.x;
+    double Q[4];
+    triangulate_one(P0, P, a[0], a[1], b[0], b[1], Q);
+    bool m = Q[2] * Q[3] > 0;
+    const double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
+    m = m && (q2 < dist);
+    const double z = P[8] * q0 + P[9] * q1 + P[10] * q2 + P[11] * q3;
+    return m && (z > 0) && (z < dist);
+}
+
+__global__ __launch_bounds__(256) void k_pose(PairBuf pb, int kp_cap, RansacParams rp)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_good[4];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     vo_pair_result* res = pb.res + p;
     if (res->status != VO_OK) {
-        if (lane == 0) res->n_good = 0;
+        if (tid == 0) res->n_good = 0;
         return;
     }
     const int M = pb.m_count[p];
@@ -752,28 +861,33 @@ __global__ __launch_bounds__(WAVE) void k_pose(PairBuf pb, int kp_cap, RansacPar
     const uint8_t* mask = pb.mask + (size_t)p * kp_cap;
     double* in1 = pb.in1 + base2; double* in2 = pb.in2 + base2;
     double* ip1 = pb.ipx1 + base2; double* ip2 = pb.ipx2 + base2;
+    if (tid < 4) s_good[tid] = 0;
     int ninl = 0;
-    for (int b = 0; b < M; b += WAVE) {
-        int i = b + lane;
-        bool f = i < M && mask[i] != 0;
-        uint64_t bal = __ballot(f);
+    for (int b = 0; b < M; b += 256) {
+        const int i = b + tid;
+        const bool f = i < M && mask[i] != 0;
+        const unsigned long long bal = __ballot(f);
+        __syncthreads();
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int c = s_w[w]; if (w < wave) off += c; tot += c; }
         if (f) {
-            int pos = ninl + __popcll(bal & ((1ULL << lane) - 1));
+            const int pos = ninl + off + __popcll(bal & ((1ULL << lane) - 1));
             in1[2 * pos] = pb.xn1[base2 + 2 * i]; in1[2 * pos + 1] = pb.xn1[base2 + 2 * i + 1];
             in2[2 * pos] = pb.xn2[base2 + 2 * i]; in2[2 * pos + 1] = pb.xn2[base2 + 2 * i + 1];
             ip1[2 * pos] = pb.px1[base2 + 2 * i]; ip1[2 * pos + 1] = pb.px1[base2 + 2 * i + 1];
             ip2[2 * pos] = pb.px2[base2 + 2 * i]; ip2[2 * pos + 1] = pb.px2[base2 + 2 * i + 1];
         }
-        ninl += __popcll(bal);
+        ninl += tot;
     }
-    __threadfence_block();
     __syncthreads();
     double E[9], R1[9], R2[9], tt[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) E[k] = res->E[k];
     decompose_essential(E, R1, R2, tt);
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    int good[4];
 #pragma unroll 1
     for (int c = 0; c < 4; c++) {
         const double* Rc = (c & 1) ? R2 : R1;
@@ -786,26 +900,19 @@ __global__ __launch_bounds__(WAVE) void k_pose(PairBuf pb, int kp_cap, RansacPar
             P[r * 4 + 3] = sgn * tt[r];
         }
         int g = 0;
-        for (int b = 0; b < ninl; b += WAVE) {
-            int i = b + lane;
-            bool m = false;
-            if (i < ninl) {
-                double Q[4];
-                triangulate_one(P0, P, in1[2 * i], in1[2 * i + 1], in2[2 * i], in2[2 * i + 1], Q);
-                m = Q[2] * Q[3] > 0;
-                double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
-                m = m && (q2 < rp.dist_thresh);
-                double z = P[8] * q0 + P[9] * q1 + P[10] * q2 + P[11] * q3;
-                m = m && (z > 0) && (z < rp.dist_thresh);
-            }
+        for (int b = 0; b < ninl; b += 256) {
+            const int i = b + tid;
+            const bool m = i < ninl && cheirality(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh);
             g += __popcll(__ballot(m));
         }
-        good[c] = g;
+        if (lane == 0 && g) atomicAdd(&s_good[c], g);
     }
+    __syncthreads();
+    const int g0 = s_good[0], g1 = s_good[1], g2 = s_good[2], g3 = s_good[3];
     int best;
-    if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) best = 0;
-    else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) best = 1;
-    else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) best = 2;
+    if (g0 >= g1 && g0 >= g2 && g0 >= g3) best = 0;
+    else if (g1 >= g0 && g1 >= g2 && g1 >= g3) best = 1;
+    else if (g2 >= g0 && g2 >= g1 && g2 >= g3) best = 2;
     else best = 3;
     if (pb.pose_mask) {      // single-call cv2.recoverPose mask: rebuild the winning candidate's test
         const double* Rc = (best & 1) ? R2 : R1;
@@ -818,37 +925,29 @@ __global__ __launch_bounds__(WAVE) void k_pose(PairBuf pb, int kp_cap, RansacPar
             P[r * 4 + 3] = sgn * tt[r];
         }
         uint8_t* pm = pb.pose_mask + (size_t)p * kp_cap;
-        for (int i = lane; i < ninl; i += WAVE) {
-            double Q[4];
-            triangulate_one(P0, P, in1[2 * i], in1[2 * i + 1], in2[2 * i], in2[2 * i + 1], Q);
-            bool m = Q[2] * Q[3] > 0;
-            double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
-            m = m && (q2 < rp.dist_thresh);
-            double z = P[8] * q0 + P[9] * q1 + P[10] * q2 + P[11] * q3;
-            m = m && (z > 0) && (z < rp.dist_thresh);
-            pm[i] = m ? 255 : 0;
-        }
+        for (int i = tid; i < ninl; i += 256) pm[i] = cheirality(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh) ? 255 : 0;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         const double* Rb = (best & 1) ? R2 : R1;
 #pragma unroll
         for (int k = 0; k < 9; k++) res->R[k] = Rb[k];
 #pragma unroll
         for (int k = 0; k < 3; k++) res->t[k] = best >= 2 ? -tt[k] : tt[k];
-        res->n_good = good[best];
+        res->n_good = best == 0 ? g0 : best == 1 ? g1 : best == 2 ? g2 : g3;
         res->n_inl = ninl;
     }
 }
 
 void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
 {
-    hipLaunchKernelGGL(k_pose, dim3(P), dim3(WAVE), 0, s, pb, kp_cap, rp);
+    hipLaunchKernelGGL(k_pose, dim3(P), dim3(256), 0, s, pb, kp_cap, rp);
 }
 
 // ------------------------------------------------------------------ single five-point sample (stage test)
-__global__ void k_five_point_raw(const double* x1, const double* x2, double* E, int* nm)
+__global__ __launch_bounds__(64) void k_five_point_raw(const double* x1, const double* x2, double* E, int* nm)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E);
+    __shared__ double s_cm[200 * FP_LANES];
+    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E, s_cm);
 }
 
 void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm)

@@ -557,13 +557,19 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
-#define BL_LW (BLUR_TW + 8)
-#define BL_LH (BLUR_TH + 6)
+// Tile BLUR_TW x BLUR_TH per workgroup. The input tile + halo is staged in LDS with 16-byte loads (rows are
+// reflected when staged, the <= 3 halo columns outside the image are patched from their mirror columns);
+// horizontal pass: one lane = 4 pixels, 7 taps as two v_dot4_u32_u8 on byte-aligned windows
+// (v_alignbyte_b32), 16-bit row sums kept in LDS; vertical pass: one lane = 4 columns x 4 rows, the
+// 10 row sums it needs are read once (ds_read_b64) and reused from registers.
+#define BL_INW 160                        // staged columns x0-16 .. x0+143
+#define BL_INH (BLUR_TH + 6)              // staged rows y0-3 .. y0+TH+2
+#define BL_ROWS_PER_LANE (BLUR_TH / 8)
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur, PyrGeom g)
 {
-    __shared__ uint8_t s_in[BL_LH * BL_LW];
-    __shared__ uint16_t s_h[BL_LH * BLUR_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[BL_INH * BL_INW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[BL_INH * BLUR_TW];
     const int f = blockIdx.y, tid = threadIdx.x;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].btile_base) l++;
@@ -571,41 +577,76 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
     const int tile = blockIdx.x - lv.btile_base;
     const int x0 = (tile % lv.btiles_x) * BLUR_TW, y0 = (tile / lv.btiles_x) * BLUR_TH;
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
-    const bool interior = x0 >= 4 && x0 + BLUR_TW + 4 <= lv.w && y0 >= 3 && y0 + BLUR_TH + 3 <= lv.h;
-    if (interior) {
-        for (int i = tid; i < BL_LH * (BL_LW / 4); i += 256) {
-            const int ry = i / (BL_LW / 4), rx4 = (i % (BL_LW / 4)) * 4;
-            *(uint32_t*)(s_in + ry * BL_LW + rx4) = *(const uint32_t*)(img + (size_t)(y0 - 3 + ry) * lv.stride + x0 - 4 + rx4);
+    if (lv.w >= 16 && lv.h >= 4) {
+        for (int i = tid; i < BL_INH * (BL_INW / 16); i += 256) {
+            const int ry = i / (BL_INW / 16), rx = (i % (BL_INW / 16)) * 16;
+            const int gy = reflect101(y0 - 3 + ry, lv.h), gx = x0 - 16 + rx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gx >= 0 && gx + 16 <= lv.stride) v = *(const uint4*)(img + (size_t)gy * lv.stride + gx);
+            *(uint4*)(s_in + ry * BL_INW + rx) = v;
         }
-    } else {
-        for (int i = tid; i < BL_LH * BL_LW; i += 256) {
-            const int ry = i / BL_LW, rx = i % BL_LW;
-            const int gy = reflect101(y0 - 3 + ry, lv.h), gx = reflect101(x0 - 4 + rx, lv.w);
-            s_in[i] = img[(size_t)gy * lv.stride + gx];
+        const bool left = x0 == 0, right = x0 + BLUR_TW + 3 > lv.w;
+        if (left || right) {
+            __syncthreads();
+            for (int i = tid; i < BL_INH * 6; i += 256) {
+                const int ry = i / 6, k = i % 6;
+                if (k < 3) {                              // x = -3..-1 mirrors to 3..1
+                    if (left) s_in[ry * BL_INW + 16 - 3 + k] = s_in[ry * BL_INW + 16 + 3 - k];
+                } else if (right) {                       // x = w..w+2 mirrors to w-2..w-4
+                    const int x = lv.w + (k - 3), sx = 2 * lv.w - 2 - x;
+                    if (x - x0 + 16 < BL_INW && sx - x0 + 16 >= 0) s_in[ry * BL_INW + x - x0 + 16] = s_in[ry * BL_INW + sx - x0 + 16];
+                }
+            }
+        }
+    } else {                                              // tiny levels: generic per-byte staging
+        for (int i = tid; i < BL_INH * BL_INW; i += 256) {
+            const int ry = i / BL_INW, rx = i % BL_INW;
+            s_in[i] = img[(size_t)reflect101(y0 - 3 + ry, lv.h) * lv.stride + reflect101(x0 - 16 + rx, lv.w)];
         }
     }
     __syncthreads();
-    for (int i = tid; i < BL_LH * BLUR_TW; i += 256) {
-        const int ry = i / BLUR_TW, rx = i % BLUR_TW;
-        const uint8_t* p = s_in + ry * BL_LW + rx + 1;       // column x0 + rx - 3
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) s += c_gauss7[k] * p[k];
-        s_h[i] = (uint16_t)s;
+    // horizontal pass: taps {18,34,49,55 | 49,34,18,0}
+    const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
+    for (int i = tid; i < BL_INH * (BLUR_TW / 4); i += 256) {
+        const int ry = i / (BLUR_TW / 4), cg = i % (BLUR_TW / 4);
+        const uint32_t* wp = (const uint32_t*)(s_in + ry * BL_INW) + 4 + cg;      // dword holding pixels x0+4cg..+3
+        const uint32_t w0 = wp[-1], w1 = wp[0], w2 = wp[1];
+        // pixel i needs window bytes 1+i .. 7+i of {w0,w1,w2}
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), a1 = __builtin_amdgcn_alignbyte(w1, w0, 2);
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), a3 = w1;
+        const uint32_t b0 = __builtin_amdgcn_alignbyte(w2, w1, 1), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+        const uint32_t b2 = __builtin_amdgcn_alignbyte(w2, w1, 3), b3 = w2;
+        const uint32_t h0 = __builtin_amdgcn_udot4(a0, TA, __builtin_amdgcn_udot4(b0, TB, 0u, false), false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(a1, TA, __builtin_amdgcn_udot4(b1, TB, 0u, false), false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(a2, TA, __builtin_amdgcn_udot4(b2, TB, 0u, false), false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(a3, TA, __builtin_amdgcn_udot4(b3, TB, 0u, false), false);
+        *(uint2*)(s_h + ry * BLUR_TW + cg * 4) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
     }
     __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4, gy = y0 + ty;
-    uint32_t out = 0;
+    // vertical pass: lane = 4 columns x BL_ROWS_PER_LANE rows
+    const int cg = tid & 31, strip = tid >> 5;
+    uint32_t hv[BL_ROWS_PER_LANE + 6][4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int lx = tx * 4 + b;
-        int s = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) s += c_gauss7[k] * s_h[(ty + k) * BLUR_TW + lx];
-        s = (s + (1 << 15)) >> 16;
-        out |= (uint32_t)(s > 255 ? 255 : s) << (8 * b);
+    for (int r = 0; r < BL_ROWS_PER_LANE + 6; r++) {
+        const uint2 v = *(const uint2*)(s_h + (strip * BL_ROWS_PER_LANE + r) * BLUR_TW + cg * 4);
+        hv[r][0] = v.x & 0xffffu; hv[r][1] = v.x >> 16; hv[r][2] = v.y & 0xffffu; hv[r][3] = v.y >> 16;
     }
-    if (gy < lv.h) *(uint32_t*)(blur + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 4) = out;
+    const uint32_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
+    const int gx = x0 + cg * 4;
+#pragma unroll
+    for (int r = 0; r < BL_ROWS_PER_LANE; r++) {
+        const int gy = y0 + strip * BL_ROWS_PER_LANE + r;
+        uint32_t out = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t sum = 1u << 15;
+#pragma unroll
+            for (int k = 0; k < 7; k++) sum += taps[k] * hv[r + k][b];
+            sum >>= 16;
+            out |= (sum > 255u ? 255u : sum) << (8 * b);
+        }
+        if (gy < lv.h && gx < lv.stride) *(uint32_t*)(blur + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + gx) = out;
+    }
 }
 
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F)

@@ -33,6 +33,7 @@ struct vo_ctx {
     uint8_t* raw_desc = nullptr; float* raw_xy = nullptr; int* raw_count = nullptr;
     PairBuf raw_pb{};
     double* raw_d = nullptr; size_t raw_d_n = 0;     // generic double scratch
+    uint32_t* rng_tab = nullptr; uint64_t rng_seed = 0; bool rng_valid = false;   // OpenCV RNG stream for the RANSAC seed
     int* raw_i = nullptr;
 
     bool prof = false;
@@ -243,7 +244,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_config(ctx);
     free_pairbuf(ctx->raw_pb);
-    void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i};
+    void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
     (void)hipStreamDestroy(ctx->stream);
@@ -500,6 +501,24 @@ extern "C" int vo_stage_blur(vo_ctx* ctx, const uint8_t* img, int h, int w, int 
 }
 
 // ------------------------------------------------------------------ pairs
+// cv::RNG (multiply-with-carry, core/operations.hpp RNG::next) output stream for `seed`; it depends on
+// nothing but the seed, so it is tabulated once and shared by every pair of every batch.
+#define RNG_TAB_N 8192
+static int ensure_rng(vo_ctx* ctx, uint64_t seed)
+{
+    if (ctx->rng_valid && ctx->rng_seed == seed) return VO_OK;
+    if (!ctx->rng_tab) HIPCHK(dmalloc(&ctx->rng_tab, RNG_TAB_N));
+    std::vector<uint32_t> tab(RNG_TAB_N);
+    uint64_t st = seed ? seed : 0xffffffffULL;
+    for (int i = 0; i < RNG_TAB_N; i++) {
+        st = (uint64_t)(uint32_t)st * 4164903690ULL + (uint32_t)(st >> 32);
+        tab[i] = (uint32_t)st;
+    }
+    HIPCHK(hipMemcpy(ctx->rng_tab, tab.data(), RNG_TAB_N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->rng_seed = seed; ctx->rng_valid = true;
+    return VO_OK;
+}
+
 static int map_select_mode(int match_mode) { return match_mode == 0 ? 1 : 3; }
 
 static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const float* kp_xy, const int* kp_count, int cap,
@@ -514,7 +533,8 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const float* 
     }
     { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
     if (!do_geometry) return VO_OK;
-    { StageTimer t(ctx, ST_RANSAC); launch_ransac(s, pb, cap, P, rp); }
+    { int rc = ensure_rng(ctx, rp.seed); if (rc) return rc; }
+    { StageTimer t(ctx, ST_RANSAC); launch_ransac(s, pb, cap, P, rp, ctx->rng_tab, RNG_TAB_N); }
     { StageTimer t(ctx, ST_POSE); launch_pose(s, pb, cap, P, rp); }
     if (want_points) { StageTimer t(ctx, ST_TRIANGULATE); launch_triangulate_pairs(s, pb, cap, P, rp); }
     return VO_OK;
@@ -694,7 +714,9 @@ extern "C" int vo_find_essential_ransac(vo_ctx* ctx, const double* p1, const dou
     RansacParams rp{};
     rp.prob = prob; rp.thresh_px = thresh_px; rp.max_iters = max_iters; rp.seed = seed; rp.dist_thresh = 50;
     memcpy(rp.K, K, sizeof(rp.K));
-    { StageTimer t(ctx, ST_RANSAC); launch_ransac(ctx->stream, ctx->raw_pb, ctx->raw_cap, 1, rp); }
+    rc = ensure_rng(ctx, rp.seed);
+    if (rc) return rc;
+    { StageTimer t(ctx, ST_RANSAC); launch_ransac(ctx->stream, ctx->raw_pb, ctx->raw_cap, 1, rp, ctx->rng_tab, RNG_TAB_N); }
     HIPCHK(hipGetLastError());
     vo_pair_result res;
     HIPCHK(hipMemcpyAsync(&res, ctx->raw_pb.res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));

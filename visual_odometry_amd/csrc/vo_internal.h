@@ -39,8 +39,8 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
 
 #define FAST_TW 128
 #define FAST_TH 16
-#define BLUR_TW 64
-#define BLUR_TH 16
+#define BLUR_TW 128
+#define BLUR_TH 32
 
 // per-frame feature arrays (device), F = number of slots
 struct FrameFeat {
@@ -114,7 +114,7 @@ void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count,
 void launch_nn_raw(hipStream_t s, const uint8_t* a, int na, const uint8_t* b, int nb, int* idx, int* dist,
                    int* idx2, int* dist2, int knn2);
 
-void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
+void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp, const uint32_t* rng_tab, int rng_n);
 void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
 void launch_triangulate_pairs(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
 void launch_triangulate_raw(hipStream_t s, const double* P1, const double* P2, const double* x1, const double* x2,
