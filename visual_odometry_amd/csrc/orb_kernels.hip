@@ -305,82 +305,147 @@ void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hi
 }
 
 // ------------------------------------------------------------------ retainBest by FAST score
-// KeyPointsFilter::runByImageBorder + retainBest(2*quota): the kept SET is {score >= n-th largest};
-// the n-th largest comes from the 256-bin histogram, and the score map is swept in raster order with
-// an ordered compaction, so candidates come out in canonical (y, x) order.
-__global__ __launch_bounds__(1024) void k_select_fast(const uint8_t* score, PyrGeom g, FrameFeat ff)
+// KeyPointsFilter::runByImageBorder + retainBest(2*quota): the kept SET is {score >= n-th largest score}.
+// (1) k_sel_threshold: the n-th largest score per (frame, level) from the 256-bin histogram;
+// (2) k_sel_count: the score map inside the border is cut into chunks of SEL_ROWS rows, one wavefront per
+//     chunk streams it with 16-byte loads and counts the kept pixels (packed byte compare + popcount);
+// (3) k_sel_emit: each wavefront sums the counts of the chunks before it (its output offset), streams its
+//     chunk again and writes the kept (x, y, score) in raster order (wave prefix sums) — canonical (y, x)
+//     order with no workgroup barrier anywhere.
+
+__device__ __forceinline__ uint32_t bytes_ge(uint32_t x, uint32_t t7, uint32_t tnot, uint32_t t)
 {
-    __shared__ int s_w[17];
-    __shared__ int s_suffix[257];
-    __shared__ int s_T;
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-    const LevelGeom lv = g.lv[l];
-    const int want = g.score_type == 0 ? 2 * lv.quota : lv.quota;
-    const int edge = g.edge;
-    int* count_out = ff.cand_count + f * VO_MAX_LEVELS + l;
-    if (lv.w <= 2 * edge || lv.h <= 2 * edge || want <= 0) {
-        if (tid == 0) *count_out = 0;
-        return;
-    }
-    if (tid < 256) s_suffix[tid] = (int)ff.hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + tid];
-    if (tid == 0) s_suffix[256] = 0;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0, T = 1;
-        bool found = false;
-        for (int v = 255; v >= 1; v--) {
-            acc += s_suffix[v];
-            if (!found && acc >= want) { T = v; found = true; }
-        }
-        s_T = T;                       // fewer than `want` candidates: keep them all
-    }
-    __syncthreads();
-    const int T = s_T;
-    const uint8_t* sc = score + (size_t)f * g.frame_bytes + lv.off;
-    const int d_lo = edge >> 2, d_hi = (lv.w - edge - 1) >> 2, ndw = d_hi - d_lo + 1;
-    const int nrows = lv.h - 2 * edge, total_items = nrows * ndw;
-    uint32_t* out_pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
-    float* out_resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
-    int base_out = 0;
-    bool overflow = false;
-    for (int base = 0; base < total_items; base += 1024) {
-        const int idx = base + tid;
-        uint32_t v = 0; int x4 = 0, y = 0, keep = 0;
-        if (idx < total_items) {
-            const int row = idx / ndw, dc = idx - row * ndw + d_lo;
-            y = edge + row; x4 = dc * 4;
-            v = *(const uint32_t*)(sc + (size_t)y * lv.stride + x4);
-        }
-        if (v) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int s = (v >> (8 * b)) & 255, x = x4 + b;
-                if (s >= T && x >= edge && x < lv.w - edge) keep |= 1 << b;
-            }
-        }
-        int tot;
-        int pos = base_out + block_excl_scan(__popc(keep), s_w, &tot);
-        if (keep) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if (keep & (1 << b)) {
-                    if (pos < lv.cand_cap) {
-                        out_pos[pos] = ((uint32_t)y << 16) | (uint32_t)(x4 + b);
-                        out_resp[pos] = (float)((v >> (8 * b)) & 255);
-                    } else overflow = true;
-                    pos++;
-                }
-            }
-        }
-        base_out += tot;
-    }
-    if (overflow) atomicOr(&ff.flags[f], 1);
-    if (tid == 0) *count_out = min(base_out, lv.cand_cap);
+    // per byte: 0x80 where x >= t (t7 = t & 0x7f7f7f7f, tnot = ~t), no carries between bytes
+    const uint32_t d = (x | 0x80808080u) - t7;
+    return ((x & tnot) | (~(x ^ t) & d)) & 0x80808080u;
 }
 
-void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F)
+// 16-bit mask of the bytes of v that are >= T, bit i = byte i
+__device__ __forceinline__ uint32_t mask16_ge(uint4 v, uint32_t t)
 {
-    hipLaunchKernelGGL(k_select_fast, dim3(g.nlevels, F), dim3(1024), 0, s, score, g, ff);
+    const uint32_t t7 = t & 0x7f7f7f7fu, tn = ~t;
+    const uint32_t a = (bytes_ge(v.x, t7, tn, t) >> 7) * 0x01020408u >> 24;
+    const uint32_t b = (bytes_ge(v.y, t7, tn, t) >> 7) * 0x01020408u >> 24;
+    const uint32_t c = (bytes_ge(v.z, t7, tn, t) >> 7) * 0x01020408u >> 24;
+    const uint32_t d = (bytes_ge(v.w, t7, tn, t) >> 7) * 0x01020408u >> 24;
+    return (a & 15u) | ((b & 15u) << 4) | ((c & 15u) << 8) | ((d & 15u) << 12);
+}
+
+__global__ __launch_bounds__(64) void k_sel_threshold(PyrGeom g, FrameFeat ff, int* thr)
+{
+    const int l = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    const LevelGeom lv = g.lv[l];
+    const int want = g.score_type == 0 ? 2 * lv.quota : lv.quota;
+    const uint32_t* h = ff.hist + ((size_t)f * VO_MAX_LEVELS + l) * 256;
+    // lane j owns scores 255-4j .. 252-4j (descending), so an inclusive scan over lanes is a suffix sum
+    uint32_t c[4];
+    int own = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { c[k] = h[255 - 4 * lane - k]; own += (int)c[k]; }
+    int inc = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+    int acc = inc - own, T = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        acc += (int)c[k];
+        const int score = 255 - 4 * lane - k;
+        if (T == 0 && acc >= want && score >= 1) T = score;
+    }
+    // the largest score whose suffix count reaches `want` lives in the lowest lane that found one
+    const unsigned long long found = __ballot(T != 0);
+    int result = 1;                                   // fewer than `want` candidates: keep them all
+    if (found) result = __shfl(T, __ffsll((long long)found) - 1, 64);
+    if (want <= 0 || lv.w <= 2 * g.edge || lv.h <= 2 * g.edge) result = 256;      // keep nothing
+    if (lane == 0) {
+        thr[f * VO_MAX_LEVELS + l] = result;
+        if (result > 255) ff.cand_count[f * VO_MAX_LEVELS + l] = 0;     // such a level may own no scan chunk at all
+    }
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void k_sel_scan(const uint8_t* score, PyrGeom g, FrameFeat ff, const int* thr,
+                                                 int* chunk_count)
+{
+    const int f = blockIdx.y, lane = threadIdx.x;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].sel_chunk_base) l++;
+    const LevelGeom lv = g.lv[l];
+    const int chunk = blockIdx.x - lv.sel_chunk_base;
+    const int T = thr[f * VO_MAX_LEVELS + l];
+    int* my_count = chunk_count + (size_t)f * g.sel_chunks_total + blockIdx.x;
+    const int nchunks = (l + 1 < g.nlevels ? g.lv[l + 1].sel_chunk_base : g.sel_chunks_total) - lv.sel_chunk_base;
+    if (T > 255) {
+        if (!EMIT && lane == 0) *my_count = 0;
+        if (EMIT && chunk == 0 && lane == 0) ff.cand_count[f * VO_MAX_LEVELS + l] = 0;
+        return;
+    }
+    const int edge = g.edge, xlo = edge, xhi = lv.w - edge;            // kept columns [xlo, xhi)
+    const int y_first = edge + chunk * SEL_ROWS, y_last = min(y_first + SEL_ROWS, lv.h - edge);
+    const int seg_lo = xlo >> 4, nseg = ((xhi - 1) >> 4) - seg_lo + 1;   // 16-byte segments per row
+    const uint8_t* sc = score + (size_t)f * g.frame_bytes + lv.off;
+    const uint32_t t4 = (uint32_t)T * 0x01010101u;
+    int base = 0;
+    if (EMIT) {
+        const int* cc = chunk_count + (size_t)f * g.sel_chunks_total + lv.sel_chunk_base;
+        for (int c = lane; c < chunk; c += 64) base += cc[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) base += __shfl_xor(base, d, 64);
+    }
+    uint32_t* out_pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
+    float* out_resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
+    int total = 0;
+    bool overflow = false;
+    for (int y = y_first; y < y_last; y++) {
+        const uint8_t* row = sc + (size_t)y * lv.stride;
+        for (int s0 = 0; s0 < nseg; s0 += 64) {
+            const int seg = s0 + lane;
+            uint32_t m = 0;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int sx = (seg_lo + seg) * 16;
+            if (seg < nseg) {
+                v = *(const uint4*)(row + sx);
+                if (v.x | v.y | v.z | v.w) {
+                    m = mask16_ge(v, t4);
+                    const int lo = max(xlo - sx, 0), hi = min(xhi - sx, 16);
+                    m &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                }
+            }
+            const int cnt = __popc(m);
+            if (!EMIT) { total += cnt; continue; }
+            int inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+            int pos = base + total + inc - cnt;
+            total += __shfl(inc, 63, 64);
+            while (m) {
+                const int b = __ffs((int)m) - 1;
+                m &= m - 1;
+                const uint32_t word = b < 4 ? v.x : b < 8 ? v.y : b < 12 ? v.z : v.w;
+                if (pos < lv.cand_cap) {
+                    out_pos[pos] = ((uint32_t)y << 16) | (uint32_t)(sx + b);
+                    out_resp[pos] = (float)((word >> (8 * (b & 3))) & 255u);
+                } else overflow = true;
+                pos++;
+            }
+        }
+    }
+    if (!EMIT) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
+        if (lane == 0) *my_count = total;
+    } else {
+        if (overflow) atomicOr(&ff.flags[f], 1);
+        if (chunk == nchunks - 1 && lane == 0) ff.cand_count[f * VO_MAX_LEVELS + l] = min(base + total, lv.cand_cap);
+    }
+}
+
+void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count)
+{
+    hipLaunchKernelGGL(k_sel_threshold, dim3(g.nlevels, F), dim3(64), 0, s, g, ff, thr);
+    if (g.sel_chunks_total <= 0) return;
+    hipLaunchKernelGGL(k_sel_scan<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, score, g, ff, thr, chunk_count);
+    hipLaunchKernelGGL(k_sel_scan<true>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, score, g, ff, thr, chunk_count);
 }
 
 // ------------------------------------------------------------------ Harris response (orb.cpp HarrisResponses)

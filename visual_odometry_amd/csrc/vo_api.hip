@@ -21,6 +21,7 @@ struct vo_ctx {
     ResizeTab tabs[VO_MAX_LEVELS]{};
     void* tab_mem = nullptr;
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
+    int *sel_thr = nullptr, *sel_chunk_count = nullptr;
     size_t staging_bytes = 0;
     FrameFeat ff{};
     PairBuf pb{};
@@ -121,7 +122,7 @@ static int make_geometry(vo_ctx* ctx, int h, int w, const vo_orb_params* p, PyrG
     const double sf = (double)p->scale_factor;
     const float factor = (float)(1.0 / sf);
     float nd = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
-    int sum = 0, off = 0, ft = 0, bt = 0, co = 0;
+    int sum = 0, off = 0, ft = 0, bt = 0, co = 0, sc = 0;
     for (int l = 0; l < L; l++) {
         LevelGeom& lv = g->lv[l];
         lv.scale = (float)pow(sf, (double)l);
@@ -139,6 +140,8 @@ static int make_geometry(vo_ctx* ctx, int h, int w, const vo_orb_params* p, PyrG
         lv.btile_base = bt; lv.btiles_x = (lv.w + BLUR_TW - 1) / BLUR_TW;
         bt += lv.btiles_x * ((lv.h + BLUR_TH - 1) / BLUR_TH);
         const int want = p->score_type == 0 ? 2 * lv.quota : lv.quota;
+        lv.sel_chunk_base = sc;
+        { const int rows = lv.h - 2 * p->edge_threshold; if (rows > 0 && lv.w > 2 * p->edge_threshold) sc += (rows + SEL_ROWS - 1) / SEL_ROWS; }
         lv.cand_off = co;
         lv.cand_cap = align_up(want + (want > 1024 ? want : 1024), 8);
         co += lv.cand_cap;
@@ -146,6 +149,7 @@ static int make_geometry(vo_ctx* ctx, int h, int w, const vo_orb_params* p, PyrG
     g->frame_bytes = align_up(off, 256);
     g->ftiles_total = ft; g->btiles_total = bt;
     g->cand_total = co;
+    g->sel_chunks_total = sc;
     g->kp_cap = align_up(p->nfeatures + (p->nfeatures / 8 > 256 ? p->nfeatures / 8 : 256), 8);
     return VO_OK;
 }
@@ -207,9 +211,9 @@ static void free_config(vo_ctx* c)
 {
     void* ptrs[] = {c->tab_mem, c->pyr, c->blur, c->score, c->ff.cand_pos, c->ff.cand_resp, c->ff.cand_count,
                     c->ff.kp_pos, c->ff.kp_level, c->ff.kp_resp, c->ff.kp_angle, c->ff.kp_xy, c->ff.kp_size,
-                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist};
+                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->sel_thr, c->sel_chunk_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr;
+    c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr; c->sel_thr = c->sel_chunk_count = nullptr;
     memset(&c->ff, 0, sizeof(c->ff));
     free_pairbuf(c->pb);
     c->pb_pairs = c->pb_cap = 0;
@@ -307,6 +311,8 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     HIPCHK(dmalloc(&ff.desc, F * g.kp_cap * 32));
     HIPCHK(dmalloc(&ff.kp_count, F)); HIPCHK(dmalloc(&ff.flags, F));
     HIPCHK(dmalloc(&ff.hist, F * VO_MAX_LEVELS * 256));
+    HIPCHK(dmalloc(&ctx->sel_thr, F * VO_MAX_LEVELS));
+    HIPCHK(dmalloc(&ctx->sel_chunk_count, F * (size_t)(g.sel_chunks_total + 1)));
     HIPCHK(hipMemset(ff.kp_count, 0, F * sizeof(int)));
     HIPCHK(hipMemset(ff.flags, 0, F * sizeof(int)));
     HIPCHK(alloc_pairbuf(ctx->pb, max_pairs, g.kp_cap, false));
@@ -361,7 +367,7 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     }
     { StageTimer t(ctx, ST_FAST); launch_fast(s, pyr, score, ff.hist, g, F); }
     if (upto < 2) return VO_OK;
-    { StageTimer t(ctx, ST_SELECT_FAST); launch_select_fast(s, score, g, ff, F); }
+    { StageTimer t(ctx, ST_SELECT_FAST); launch_select_fast(s, score, g, ff, F, ctx->sel_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->sel_chunk_count + (size_t)first_slot * g.sel_chunks_total); }
     if (g.score_type == 0) { StageTimer t(ctx, ST_HARRIS); launch_harris(s, pyr, g, ff, F); }
     { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F); }
     { StageTimer t(ctx, ST_ANGLE); launch_angle(s, pyr, g, ff, F); }

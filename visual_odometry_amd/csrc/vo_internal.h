@@ -21,6 +21,7 @@ struct LevelGeom {
     int ftile_base, ftiles_x;    // FAST tiles (prefix over levels)
     int btile_base, btiles_x;    // blur tiles
     int cand_off, cand_cap;      // candidate slots of this level inside a frame's candidate arrays
+    int sel_chunk_base;          // first selection chunk (SEL_ROWS rows inside the border) of this level
 };
 
 struct PyrGeom {
@@ -28,6 +29,7 @@ struct PyrGeom {
     int edge, fast_thr, score_type, nfeatures;
     int ftiles_total, btiles_total;
     int cand_total, kp_cap;
+    int sel_chunks_total;
     LevelGeom lv[VO_MAX_LEVELS];
 };
 
@@ -41,6 +43,7 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
 #define FAST_TH 16
 #define BLUR_TW 128
 #define BLUR_TH 32
+#define SEL_ROWS 8
 
 // per-frame feature arrays (device), F = number of slots
 struct FrameFeat {
@@ -99,7 +102,7 @@ void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride
                  uint8_t* pyr, const PyrGeom& g, int F);
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F);
 void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F);
-void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F);
+void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count);
 void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
 void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F);
 void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
