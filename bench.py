@@ -115,7 +115,7 @@ def main():
 
     def step():
         nonlocal gathered
-        fe.detect(0, C + 1)                               # each frame detected once (sequence mode)
+        fe.detect(0, C + 1, wait=False)                   # each frame detected once (sequence mode)
         res, _ = fe.run_pairs(pairs, K, opts)
         if world > 1:                                     # trajectory gather over RCCL / xGMI: 128 B per pair
             rec[:, :9] = res["R"]; rec[:, 9:12] = res["t"]

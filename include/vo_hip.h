@@ -13,6 +13,7 @@
  */
 #ifndef VO_HIP_H
 #define VO_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -129,6 +130,13 @@ int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params* params, i
 int vo_frames_upload(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot);
 /* detect + describe slots [first_slot, first_slot+F); results stay on the device */
 int vo_frames_detect(vo_ctx* ctx, int first_slot, int F);
+/* same, but only enqueued on the ctx stream (the next synchronous call, e.g. vo_pairs_run, waits for it) */
+int vo_frames_detect_async(vo_ctx* ctx, int first_slot, int F);
+/* keypoint / match capacity per frame of the current configuration (row length of X in vo_pairs_run) */
+int vo_batch_kp_capacity(vo_ctx* ctx);
+/* page-locked host memory for result buffers (full-rate D2H copies); plain malloc'ed memory also works */
+int  vo_host_alloc(size_t bytes, void** out);
+void vo_host_free(void* p);
 /* download one slot's keypoints / descriptors (capacity cap) */
 int vo_frame_features(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
                       int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);

@@ -45,6 +45,7 @@ def test_batch_is_independent_of_batching(seq_small):
     fe = FrontEnd(480, 640, max_frames=4, max_pairs=3, nfeatures=500)
     fe.upload(frames); fe.detect(0, 4)
     a, _ = fe.run_pairs([[0, 1], [1, 2], [2, 3]], K)
+    a = a.copy()                       # run_pairs returns views of reused page-locked buffers
     b, _ = fe.run_pairs([[1, 2]], K)
     assert a[1].tobytes() == b[0].tobytes()
 

@@ -53,6 +53,10 @@ _SIGS = {
     "vo_batch_configure": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
     "vo_frames_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int]),
     "vo_frames_detect": (C.c_int, [_P, C.c_int, C.c_int]),
+    "vo_frames_detect_async": (C.c_int, [_P, C.c_int, C.c_int]),
+    "vo_batch_kp_capacity": (C.c_int, [_P]),
+    "vo_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "vo_host_free": (None, [_P]),
     "vo_frame_features": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "vo_pairs_run": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
@@ -135,3 +139,27 @@ def default_context(device: int = 0) -> Context:
 
 def ptr(a):
     return None if a is None else a.ctypes.data
+
+
+class PinnedArray:
+    """numpy view over page-locked host memory from vo_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype):
+        lib = load()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = _P()
+        if lib.vo_host_alloc(max(n, 1), C.byref(p)) != 0 or not p:
+            raise MemoryError(f"vo_host_alloc({n}) failed")
+        self._lib, self._ptr = lib, p
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self.array = None
+                self._lib.vo_host_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass

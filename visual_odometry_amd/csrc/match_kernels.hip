@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_nn_pairs(const uint8_t* desc, const int
 {
     const int p = blockIdx.y, dir = dir_first + blockIdx.z;
     const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
-    const int na = kp_count[fa], nb = kp_count[fb];
+    const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
     if ((int)(blockIdx.x * blockDim.x) >= na) return;
     const size_t o = ((size_t)p * 2 + dir) * kp_cap;
     nn_body<KNN2>(desc + (size_t)fa * kp_cap * 32, na, desc + (size_t)fb * kp_cap * 32, nb,
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_match_select(const float* kp_xy, const 
     __shared__ int s_w[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int f1 = pb.slots[2 * p], f2 = pb.slots[2 * p + 1];
-    const int nq = kp_count[f1], nt = kp_count[f2];
+    const int nq = min(kp_count[f1], kp_cap), nt = min(kp_count[f2], kp_cap);
     const size_t o0 = ((size_t)p * 2) * kp_cap, o1 = o0 + kp_cap, op = (size_t)p * kp_cap;
     const int* fidx = pb.nn_idx + o0; const int* fdist = pb.nn_dist + o0;
     const int* ridx = pb.nn_idx + o1; const int* rdist = pb.nn_dist + o1;

@@ -454,7 +454,7 @@ __global__ void k_harris(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
     const int l = blockIdx.y, f = blockIdx.z;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const LevelGeom lv = g.lv[l];
-    if (i >= ff.cand_count[f * VO_MAX_LEVELS + l]) return;
+    if (i >= min(ff.cand_count[f * VO_MAX_LEVELS + l], lv.cand_cap)) return;
     const size_t ci = (size_t)f * g.cand_total + lv.cand_off + i;
     const uint32_t pos = ff.cand_pos[ci];
     const int x0 = pos & 0xffff, y0 = pos >> 16, st = lv.stride;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_select_harris(PyrGeom g, FrameFeat ff)
     float* kp_resp = ff.kp_resp + (size_t)f * g.kp_cap;
     for (int l = 0; l < g.nlevels; l++) {
         const LevelGeom lv = g.lv[l];
-        const int n = ff.cand_count[f * VO_MAX_LEVELS + l];
+        const int n = min(ff.cand_count[f * VO_MAX_LEVELS + l], lv.cand_cap);
         const uint32_t* pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
         const float* resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
         float thr = -FLT_MAX;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, Fr
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= ff.kp_count[f]) return;
+    if (k >= min(ff.kp_count[f], g.kp_cap)) return;
     const size_t ki = (size_t)f * g.kp_cap + k;
     const uint32_t pos = ff.kp_pos[ki];
     const LevelGeom lv = g.lv[ff.kp_level[ki]];
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= ff.kp_count[f]) return;
+    if (k >= min(ff.kp_count[f], g.kp_cap)) return;
     const size_t ki = (size_t)f * g.kp_cap + k;
     const uint32_t pos = ff.kp_pos[ki];
     const int level = ff.kp_level[ki];

@@ -376,6 +376,36 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     return VO_OK;
 }
 
+extern "C" int vo_batch_kp_capacity(vo_ctx* ctx)
+{
+    return ctx && ctx->configured ? ctx->g.kp_cap : 0;
+}
+
+extern "C" int vo_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return VO_ERR_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? VO_OK : VO_ERR_HIP;
+}
+
+extern "C" void vo_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" int vo_frames_detect_async(vo_ctx* ctx, int first_slot, int F)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (F == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = run_detect(ctx, first_slot, F, 2);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return VO_OK;
+}
+
 extern "C" int vo_frames_detect(vo_ctx* ctx, int first_slot, int F)
 {
     if (!ctx) return VO_ERR_INVALID;
@@ -572,11 +602,13 @@ extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results, ctx->pb.res, (size_t)B * sizeof(vo_pair_result), hipMemcpyDeviceToHost, s));
+    const bool whole_x = X && wp && x_cap == cap;       // caller's layout equals the device layout: one copy
+    if (X && wp && x_cap < 1) FAIL(VO_ERR_INVALID, "x_cap must be positive");
+    if (whole_x) HIPCHK(hipMemcpyAsync(X, ctx->pb.X, (size_t)B * 4 * cap * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (ctx->prof) prof_collect(ctx);
     ctx->last_pairs = B;
-    if (X && wp) {
-        if (x_cap < 1) FAIL(VO_ERR_INVALID, "x_cap must be positive");
+    if (X && wp && !whole_x) {
         for (int p = 0; p < B; p++) {
             const int n = results[p].status == VO_OK ? (results[p].n_inl < x_cap ? results[p].n_inl : x_cap) : 0;
             if (n <= 0) continue;

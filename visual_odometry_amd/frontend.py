@@ -23,7 +23,9 @@ class FrontEnd:
         c = self.ctx
         c.check(c.lib.vo_batch_configure(c.handle, self.h, self.w, C.addressof(self.params), self.max_frames,
                                          self.max_pairs))
-        self.kp_cap = self.params.nfeatures + max(self.params.nfeatures // 8, 256) + 8
+        self.kp_cap = int(c.lib.vo_batch_kp_capacity(c.handle))
+        self._res = _lib.PinnedArray((self.max_pairs,), _lib.PAIR_RESULT_DTYPE)      # page-locked result buffers,
+        self._X = None                                                                # reused by every run_pairs call
 
     def upload(self, frames, first_slot=0):
         f = np.ascontiguousarray(frames, dtype=np.uint8)
@@ -34,9 +36,12 @@ class FrontEnd:
         c = self.ctx
         c.check(c.lib.vo_frames_upload(c.handle, f.ctypes.data, f.shape[0], f.strides[1], f.strides[0], int(first_slot)))
 
-    def detect(self, first_slot, count):
+    def detect(self, first_slot, count, wait=True):
+        """ORB detect + describe of `count` resident slots. wait=False only enqueues the work on the ctx stream;
+        the next run_pairs (same stream) is ordered after it."""
         c = self.ctx
-        c.check(c.lib.vo_frames_detect(c.handle, int(first_slot), int(count)))
+        fn = c.lib.vo_frames_detect if wait else c.lib.vo_frames_detect_async
+        c.check(fn(c.handle, int(first_slot), int(count)))
 
     def features(self, slot):
         cap = self.kp_cap
@@ -61,12 +66,18 @@ class FrontEnd:
         B = len(ps)
         K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
         opts = opts or self.make_opts(want_points=want_points)
-        res = np.zeros(B, _lib.PAIR_RESULT_DTYPE)
-        X = np.zeros((B, 4, self.kp_cap)) if opts.want_points else None
+        if B > self.max_pairs:
+            raise ValueError(f"{B} pairs > max_pairs={self.max_pairs}")
+        res = self._res.array[:B]
+        X = None
+        if opts.want_points:
+            if self._X is None:
+                self._X = _lib.PinnedArray((self.max_pairs, 4, self.kp_cap), np.float64)
+            X = self._X.array[:B]
         c = self.ctx
         c.check(c.lib.vo_pairs_run(c.handle, ps.ctypes.data, B, K.ctypes.data, C.addressof(opts), res.ctypes.data,
                                    _lib.ptr(X), self.kp_cap))
-        return res, X
+        return res, X      # views of reused page-locked buffers: copy them if they must outlive the next call
 
     def pair_matches(self, pair):
         cap = self.kp_cap
