@@ -118,9 +118,80 @@ __global__ void k_resize(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom
     *(uint32_t*)(dp + (size_t)dy * dst.stride + dx0) = out;
 }
 
+// Tiled version for scale factors up to 4/3 (tab.tiled): a RS_TW x RS_TH destination tile per workgroup.
+// The source rows/columns the tile needs are staged in LDS with 16-byte loads; horizontal pass: one lane =
+// 4 destination pixels, their 4+4 source bytes are picked out of a 12-byte window with two v_perm_b32
+// (selector built once per lane from the offset table) and blended in 8.8 fixed point; the 16-bit row
+// results stay in LDS; vertical pass blends two of them per destination row (16.16, round half up).
+// Edge replication needs no special case: the tables hold (offset 0 / last, weight 0) there.
+#define RS_TW 128
+#define RS_TH 16
+#define RS_LW 192
+#define RS_LH 24
+
+__global__ __launch_bounds__(256) void k_resize_tiled(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom dst, ResizeTab tab)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_LH * RS_LW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[RS_LH * RS_TW];
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * RS_TW, y0 = blockIdx.y * RS_TH;
+    const int x_last = min(x0 + RS_TW, dst.w) - 1, y_last = min(y0 + RS_TH, dst.h) - 1;
+    const int sx0 = tab.xofs[x0] & ~15, sy0 = tab.yofs[y0];
+    const int nrows = min(tab.yofs[y_last] + 2 - sy0, RS_LH);
+    const int ncol16 = min((tab.xofs[x_last] + 2 - sx0 + 15) >> 4, RS_LW / 16);
+    const uint8_t* sp = pyr + (size_t)f * frame_bytes + src.off;
+    for (int i = tid; i < nrows * (RS_LW / 16); i += 256) {
+        const int ry = i / (RS_LW / 16), c = i % (RS_LW / 16);
+        const int gy = sy0 + ry, gx = sx0 + 16 * c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < ncol16 && gy < src.h && gx + 16 <= src.stride) v = *(const uint4*)(sp + (size_t)gy * src.stride + gx);
+        *(uint4*)(s_src + ry * RS_LW + 16 * c) = v;
+    }
+    const int dxg = tid & 31, rl = tid >> 5, dx = x0 + 4 * dxg;
+    int o[4], c1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int xi = min(dx + i, dst.w - 1); o[i] = tab.xofs[xi] - sx0; c1[i] = tab.xc1[xi]; }
+    const int base = o[0] & ~3;
+    const uint32_t sel = (uint32_t)(o[0] - base) | ((uint32_t)(o[1] - base) << 8) | ((uint32_t)(o[2] - base) << 16) | ((uint32_t)(o[3] - base) << 24);
+    __syncthreads();
+    for (int r = rl; r < nrows; r += 8) {
+        const uint32_t* wp = (const uint32_t*)(s_src + r * RS_LW + base);
+        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        const uint32_t lo = __builtin_amdgcn_perm(w1, w0, sel);
+        const uint32_t hi = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(w2, w1, 1), __builtin_amdgcn_alignbyte(w1, w0, 1), sel);
+        uint32_t h[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int a = (lo >> (8 * i)) & 255, b = (hi >> (8 * i)) & 255;
+            h[i] = (uint32_t)((a << 8) + c1[i] * (b - a));          // (256 - c1) * a + c1 * b
+        }
+        *(uint2*)(s_h + r * RS_TW + 4 * dxg) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    }
+    __syncthreads();
+    uint8_t* dp = pyr + (size_t)f * frame_bytes + dst.off;
+    for (int rr = rl; rr < RS_TH; rr += 8) {
+        const int dy = y0 + rr;
+        if (dy >= dst.h) break;
+        const int r0 = tab.yofs[dy] - sy0;
+        const uint32_t w1 = tab.yc1[dy], w0 = 256 - w1;
+        const uint2 a = *(const uint2*)(s_h + r0 * RS_TW + 4 * dxg), b = *(const uint2*)(s_h + (r0 + 1) * RS_TW + 4 * dxg);
+        const uint32_t v0 = ((a.x & 0xffffu) * w0 + (b.x & 0xffffu) * w1 + 32768u) >> 16;
+        const uint32_t v1 = ((a.x >> 16) * w0 + (b.x >> 16) * w1 + 32768u) >> 16;
+        const uint32_t v2 = ((a.y & 0xffffu) * w0 + (b.y & 0xffffu) * w1 + 32768u) >> 16;
+        const uint32_t v3 = ((a.y >> 16) * w0 + (b.y >> 16) * w1 + 32768u) >> 16;
+        if (dx < dst.stride)
+            *(uint32_t*)(dp + (size_t)dy * dst.stride + dx) = min(v0, 255u) | (min(v1, 255u) << 8) | (min(v2, 255u) << 16) | (min(v3, 255u) << 24);
+    }
+}
+
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F)
 {
     const LevelGeom& d = g.lv[level];
+    if (tab.tiled) {
+        dim3 grid((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, F);
+        hipLaunchKernelGGL(k_resize_tiled, grid, dim3(256), 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
+        return;
+    }
     dim3 block(64, 4), grid((d.stride / 4 + 63) / 64, (d.h + 3) / 4, F);
     hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
 }

@@ -37,6 +37,7 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
     const int* xofs; const uint16_t* xc1;
     const int* yofs; const uint16_t* yc1;
     int min_x, max_x, min_y, max_y;
+    int tiled;                   // 1: geometry fits k_resize_tiled's LDS tile (scale factor <= 4/3)
 };
 
 #define FAST_TW 128
