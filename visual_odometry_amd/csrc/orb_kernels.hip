@@ -213,7 +213,8 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 #define FT_SCW 144                       // LDS score tile: columns x0-4 .. x0+139 (dword aligned with the output)
 #define FT_SCH (FAST_TH + 2)             // rows y0-1 .. y0+TH
 #define FT_GROUPS_X 34                   // dword groups covering x0-4 .. x0+131
-#define FT_QCAP (130 * (FAST_TH + 2))
+#define FT_QCAP 1024                     // candidate queue (compass survivors); a tile that overflows it takes the dense path
+#define FT_Q2CAP 512                     // corner queue
 
 __device__ __forceinline__ bool has_arc9(uint32_t m)     // 16-bit ring mask: 9 cyclically contiguous bits set?
 {
@@ -225,19 +226,32 @@ __device__ __forceinline__ bool has_arc9(uint32_t m)     // 16-bit ring mask: 9 
     return x != 0;
 }
 
-// exact corner test + cornerScore<16>; 0 when the pixel is no corner. c: centre in the LDS pixel tile
-__device__ __forceinline__ int fast_corner_score(const uint8_t* c, int t)
+// ring differences v - ring[k] of the pixel at c (centre in the LDS pixel tile)
+__device__ __forceinline__ void fast_ring_diffs(const uint8_t* c, int* d)
 {
     const int v = c[0];
-    int d[16];
     d[0]  = v - c[3 * FT_PXW];      d[1]  = v - c[3 * FT_PXW + 1];  d[2]  = v - c[2 * FT_PXW + 2];  d[3]  = v - c[FT_PXW + 3];
     d[4]  = v - c[3];               d[5]  = v - c[-FT_PXW + 3];     d[6]  = v - c[-2 * FT_PXW + 2]; d[7]  = v - c[-3 * FT_PXW + 1];
     d[8]  = v - c[-3 * FT_PXW];     d[9]  = v - c[-3 * FT_PXW - 1]; d[10] = v - c[-2 * FT_PXW - 2]; d[11] = v - c[-FT_PXW - 3];
     d[12] = v - c[-3];              d[13] = v - c[FT_PXW - 3];      d[14] = v - c[2 * FT_PXW - 2];  d[15] = v - c[3 * FT_PXW - 1];
+}
+
+// exact FAST-9/16 test: 9 contiguous ring pixels all darker than v - t or all brighter than v + t
+__device__ __forceinline__ bool fast_is_corner(const uint8_t* c, int t)
+{
+    int d[16];
+    fast_ring_diffs(c, d);
     uint32_t dark = 0, bright = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) { dark |= (uint32_t)(d[k] > t) << k; bright |= (uint32_t)(d[k] < -t) << k; }
-    if (!has_arc9(dark) && !has_arc9(bright)) return 0;
+    return has_arc9(dark) || has_arc9(bright);
+}
+
+// cornerScore<16> of a corner: max(A, B) - 1
+__device__ __forceinline__ int fast_corner_score(const uint8_t* c)
+{
+    int d[16];
+    fast_ring_diffs(c, d);
     int mn[16], mx[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
@@ -265,11 +279,13 @@ __device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) + __builtin_bit_cast(vo_s16x2, b));
 }
 
-__global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g)
+__global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
     __shared__ uint16_t s_q[FT_QCAP];
+    __shared__ uint16_t s_q2[FT_Q2CAP];
+    __shared__ int s_q2n;
     __shared__ uint32_t s_hist[256];
     __shared__ int s_qn;
     const int f = blockIdx.y, tid = threadIdx.x;
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score
 
     // A. stage pixels (16-byte loads), clear the score tile, histogram and queue
     s_hist[tid] = 0;
-    if (tid == 0) s_qn = 0;
+    if (tid == 0) { s_qn = 0; s_q2n = 0; }
     for (int i = tid; i < FT_SCH * FT_SCW / 16; i += 256) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < FT_PXH * (FT_PXW / 16); i += 256) {
         const int ry = i / (FT_PXW / 16), rx = (i % (FT_PXW / 16)) * 16;
@@ -297,6 +313,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score
     // B. compass pre-test on the tile + 1 ring, 4 pixels per lane, two pixels per packed 16-bit operation
     const uint32_t T2 = (uint32_t)t * 0x00010001u;
     const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
+#pragma unroll
     for (int gi = tid; gi < FT_GROUPS_X * FT_SCH; gi += 256) {
         const int gr = gi / FT_GROUPS_X, gc = gi - gr * FT_GROUPS_X;
         const int gy = y0 - 1 + gr;
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score
                     const int gx = gx0 + i;
                     if (gx >= xlo && gx <= xhi) {
                         const int pos = atomicAdd(&s_qn, 1);
-                        s_q[pos] = (uint16_t)(gr * 256 + 4 * gc + i);      // (score-tile row, column relative to x0-4)
+                        if (pos < FT_QCAP) s_q[pos] = (uint16_t)(gr * 256 + 4 * gc + i);   // (score-tile row, column relative to x0-4)
                     }
                 }
             }
@@ -335,36 +352,68 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t* pyr, uint8_t* score
     }
     __syncthreads();
 
-    // C. exact test + cornerScore for the queued candidates only
+    // C. exact test for the queued candidates; the corners among them are compacted into a second queue
+    //    so that cornerScore runs on full wavefronts of corners only
     const int nq = s_qn;
-    for (int e = tid; e < nq; e += 256) {
-        const int q = s_q[e], gr = q >> 8, cx = q & 255;                  // cx: column relative to x0-4
-        s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(s_px + (gr + 3) * FT_PXW + 12 + cx, t);
+    if (nq <= FT_QCAP) {
+        for (int e = tid; e - (tid & 63) < nq; e += 256) {
+            bool corner = false;
+            int q = 0;
+            if (e < nq) {
+                q = s_q[e];
+                corner = fast_is_corner(s_px + ((q >> 8) + 3) * FT_PXW + 12 + (q & 255), t);
+            }
+            if (corner) {
+                const int pos = atomicAdd(&s_q2n, 1);
+                if (pos < FT_Q2CAP) s_q2[pos] = (uint16_t)q;
+            }
+        }
+        __syncthreads();
+    }
+    const int nc = s_q2n;
+    if (nq <= FT_QCAP && nc <= FT_Q2CAP) {
+        for (int e = tid; e < nc; e += 256) {
+            const int q = s_q2[e], gr = q >> 8, cx = q & 255;                  // cx: column relative to x0-4
+            s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(s_px + (gr + 3) * FT_PXW + 12 + cx);
+        }
+    } else {
+        // a queue overflowed (extremely corner-dense tile): test and score every pixel of the tile + ring
+        for (int i = tid; i < FT_SCH * 130; i += 256) {
+            const int gr = i / 130, cx = 3 + i % 130;
+            const int gx = x0 - 4 + cx, gy = y0 - 1 + gr;
+            if (gx < xlo || gx > xhi || gy < 3 || gy >= lv.h - 3) continue;
+            const uint8_t* c = s_px + (gr + 3) * FT_PXW + 12 + cx;
+            if (fast_is_corner(c, t)) s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(c);
+        }
     }
     __syncthreads();
 
-    // D. NMS + dense store: 8 pixels (two dwords) per thread, 16 threads per row
-    const int tx = tid & 15, ty = tid >> 4, gy = y0 + ty;
-    uint32_t out[2] = {0, 0};
+    // D. NMS + dense store: 8 pixels (two dwords) per thread, 16 threads per row, 16 rows per pass
+    const int tx = tid & 15;
+#pragma unroll 1
+    for (int ty = tid >> 4; ty < FAST_TH; ty += 16) {
+        const int gy = y0 + ty;
+        uint32_t out[2] = {0, 0};
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int cx = 4 + tx * 8 + h * 4;                                // score-tile column of the dword
-        const uint8_t* c = s_sc + (ty + 1) * FT_SCW + cx;
-        if (*(const uint32_t*)c) {
+        for (int h = 0; h < 2; h++) {
+            const int cx = 4 + tx * 8 + h * 4;                                // score-tile column of the dword
+            const uint8_t* c = s_sc + (ty + 1) * FT_SCW + cx;
+            if (*(const uint32_t*)c) {
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int s = c[b];
-                if (s && s > c[b - 1] && s > c[b + 1] && s > c[b - FT_SCW - 1] && s > c[b - FT_SCW] && s > c[b - FT_SCW + 1] &&
-                    s > c[b + FT_SCW - 1] && s > c[b + FT_SCW] && s > c[b + FT_SCW + 1]) {
-                    out[h] |= (uint32_t)s << (8 * b);
-                    const int gx = x0 + tx * 8 + h * 4 + b;
-                    if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[s], 1u);
+                for (int b = 0; b < 4; b++) {
+                    const int s = c[b];
+                    if (s && s > c[b - 1] && s > c[b + 1] && s > c[b - FT_SCW - 1] && s > c[b - FT_SCW] && s > c[b - FT_SCW + 1] &&
+                        s > c[b + FT_SCW - 1] && s > c[b + FT_SCW] && s > c[b + FT_SCW + 1]) {
+                        out[h] |= (uint32_t)s << (8 * b);
+                        const int gx = x0 + tx * 8 + h * 4 + b;
+                        if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[s], 1u);
+                    }
                 }
             }
         }
+        if (gy < lv.h && x0 + tx * 8 < lv.stride)
+            *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(out[0], out[1]);
     }
-    if (gy < lv.h && x0 + tx * 8 < lv.stride)
-        *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(out[0], out[1]);
     __syncthreads();
     const uint32_t hv = s_hist[tid];
     if (hv) atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + tid], hv);

@@ -41,7 +41,7 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
 };
 
 #define FAST_TW 128
-#define FAST_TH 16
+#define FAST_TH 32
 #define BLUR_TW 128
 #define BLUR_TH 32
 #define SEL_ROWS 8
