@@ -569,7 +569,9 @@ void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, F
 }
 
 // ------------------------------------------------------------------ Harris response (orb.cpp HarrisResponses)
-__global__ void k_harris(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
+// One lane per candidate; the 9x9 neighbourhood is fetched as 9 rows x 3 unaligned dwords and kept in
+// registers, the 49 Sobel pairs are evaluated from there (no per-tap memory access).
+__global__ __launch_bounds__(256) void k_harris(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
 {
     const int l = blockIdx.y, f = blockIdx.z;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -578,17 +580,30 @@ __global__ void k_harris(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
     const size_t ci = (size_t)f * g.cand_total + lv.cand_off + i;
     const uint32_t pos = ff.cand_pos[ci];
     const int x0 = pos & 0xffff, y0 = pos >> 16, st = lv.stride;
-    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
-    int a = 0, b = 0, c = 0;
-    for (int yy = -3; yy <= 3; yy++) {
-        const uint8_t* p = img + (size_t)(y0 + yy) * st + x0 - 3;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off + (size_t)(y0 - 4) * st + (x0 - 4);
+    // p[r][c] = pixel (x0 - 4 + c, y0 - 4 + r), r, c in 0..8
+    int dxr[9][7], sxr[9][7];          // horizontal difference / smoothing of row r at columns 1..7
 #pragma unroll
-        for (int xx = 0; xx < 7; xx++, p++) {
-            int Ix = (p[1] - p[-1]) * 2 + (p[-st + 1] - p[-st - 1]) + (p[st + 1] - p[st - 1]);
-            int Iy = (p[st] - p[-st]) * 2 + (p[st - 1] - p[-st - 1]) + (p[st + 1] - p[-st + 1]);
+    for (int r = 0; r < 9; r++) {
+        uint32_t w0, w1, w2;
+        __builtin_memcpy(&w0, img + (size_t)r * st, 4);
+        __builtin_memcpy(&w1, img + (size_t)r * st + 4, 4);
+        __builtin_memcpy(&w2, img + (size_t)r * st + 8, 4);
+        int px[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) px[c] = (int)(((c < 4 ? w0 : c < 8 ? w1 : w2) >> (8 * (c & 3))) & 255u);
+#pragma unroll
+        for (int c = 0; c < 7; c++) { dxr[r][c] = px[c + 2] - px[c]; sxr[r][c] = px[c] + 2 * px[c + 1] + px[c + 2]; }
+    }
+    int a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int r = 1; r < 8; r++)
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int Ix = dxr[r - 1][k] + 2 * dxr[r][k] + dxr[r + 1][k];
+            const int Iy = sxr[r + 1][k] - sxr[r - 1][k];
             a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
         }
-    }
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
     ff.cand_resp[ci] = ((float)a * (float)b - (float)c * (float)c - 0.04f * ((float)a + (float)b) * ((float)a + (float)b)) * scale_sq_sq;
@@ -699,8 +714,20 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-// one wavefront per keypoint: lanes 0..30 sweep the columns of rows v = -15..-1? no: lane = column u,
-// the wave walks the 31 rows; integer moments are order independent, reduced with shuffles.
+// One wavefront per keypoint. The 31 x 32-byte patch rows are read as unaligned dwords starting at x0 - 15
+// (248 dwords = 4 per lane); a per-(|v|, dword) byte mask cuts the radius-15 disc; v_dot4_u32_u8 gives the
+// dword's pixel sum and its 0,1,2,3-weighted sum, so m10 and m01 cost two dot products per dword.
+// The integer moments are order independent and are reduced with shuffles.
+__constant__ uint32_t c_disc_mask[16][8] = {
+#define DM(u0, um) ((((u0) >= -(um) && (u0) <= (um)) ? 0x000000ffu : 0u) | (((u0) + 1 >= -(um) && (u0) + 1 <= (um)) ? 0x0000ff00u : 0u) | \
+                    (((u0) + 2 >= -(um) && (u0) + 2 <= (um)) ? 0x00ff0000u : 0u) | (((u0) + 3 >= -(um) && (u0) + 3 <= (um)) ? 0xff000000u : 0u))
+#define DROW(um) {DM(-15, um), DM(-11, um), DM(-7, um), DM(-3, um), DM(1, um), DM(5, um), DM(9, um), DM(13, um)}
+    DROW(15), DROW(15), DROW(15), DROW(15), DROW(14), DROW(14), DROW(14), DROW(13),
+    DROW(13), DROW(12), DROW(11), DROW(10), DROW(9), DROW(8), DROW(6), DROW(3)
+#undef DROW
+#undef DM
+};
+
 __global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
@@ -710,17 +737,20 @@ __global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, Fr
     const uint32_t pos = ff.kp_pos[ki];
     const LevelGeom lv = g.lv[ff.kp_level[ki]];
     const int x0 = pos & 0xffff, y0 = pos >> 16;
-    const uint8_t* center = pyr + (size_t)f * g.frame_bytes + lv.off + (size_t)y0 * lv.stride + x0;
-    // lanes 0..30: u = lane - 15 on rows v = -15..15 (upper half of the wave takes odd rows)
-    const int u = (lane & 31) - 15, half = lane >> 5;
+    const uint8_t* corner = pyr + (size_t)f * g.frame_bytes + lv.off + (size_t)(y0 - 15) * lv.stride + (x0 - 15);
     int m10 = 0, m01 = 0;
-    if ((lane & 31) < 31) {
-        for (int r = half; r < 31; r += 2) {
-            const int v = r - 15, av = v < 0 ? -v : v;
-            if (u >= -c_umax[av] && u <= c_umax[av]) {
-                const int I = center[v * lv.stride + u];
-                m10 += u * I; m01 += v * I;
-            }
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int idx = it * 64 + lane;
+        if (idx < 248) {
+            const int r = idx >> 3, j = idx & 7, v = r - 15, av = v < 0 ? -v : v;
+            uint32_t w;
+            __builtin_memcpy(&w, corner + (size_t)r * lv.stride + 4 * j, 4);
+            w &= c_disc_mask[av][j];
+            const int sum = (int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
+            const int wsum = (int)__builtin_amdgcn_udot4(w, 0x03020100u, 0u, false);
+            m10 += (4 * j - 15) * sum + wsum;
+            m01 += v * sum;
         }
     }
 #pragma unroll
