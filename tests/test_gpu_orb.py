@@ -110,3 +110,19 @@ def test_detect_and_compute_object_surface(ctx, seq_small):
     kps, desc = _det().detectAndCompute(seq_small["frames"][0], None)
     assert len(kps) == len(desc) and desc.dtype == np.uint8 and desc.shape[1] == 32
     assert isinstance(kps[0].pt, tuple) and len(kps[0].pt) == 2
+
+
+def test_fast_corner_dense_tiles_take_the_fallback_path(oracle, ctx):
+    """Salt-and-pepper blocks make > 25 % of the pixels pass the compass pre-test, which overflows the per-tile
+    candidate queue of the FAST kernel and exercises its dense path; results must not change."""
+    rng = np.random.default_rng(21)
+    img = (rng.integers(0, 2, (90, 120)) * 255).astype(np.uint8)
+    img = np.kron(img, np.ones((3, 3), np.uint8))[:256, :352]
+    p = oracle.orb_params(nfeatures=500, nlevels=3)
+    sizes = _level_sizes(oracle, 256, 352, p)
+    got = _det(500, 3).stage_levels("vo_stage_fast_scores", img, sizes)
+    for l, lvl in enumerate(oracle.pyramid(img, p)):
+        assert np.array_equal(got[l], oracle.fast_score_nms(lvl, 20)), f"level {l}"
+    ref = oracle.orb_detect_and_compute(img, p)
+    g = _det(500, 3).detect_arrays(img)
+    assert np.array_equal(g["xy"], ref["xy"]) and np.array_equal(g["desc"], ref["desc"])

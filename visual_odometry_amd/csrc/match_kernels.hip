@@ -18,18 +18,27 @@ __device__ __forceinline__ int hamming(const Desc& x, const uint4& ya, const uin
            __popc(x.b.x ^ yb.x) + __popc(x.b.y ^ yb.y) + __popc(x.b.z ^ yb.z) + __popc(x.b.w ^ yb.w);
 }
 
-// nearest (and optionally second nearest) row of B for every row of A; one thread per A row, B streamed
-// through LDS in tiles read as wave-wide broadcasts.
+// nearest (and optionally second nearest) row of B for every row of A.  One lane holds NN_Q rows of A in
+// registers; B is streamed through LDS in tiles and read as wave-wide broadcasts (ds_read_b128, one read
+// serves NN_Q distances); 256-bit Hamming distance = 8 x (v_xor, v_bcnt accumulate).
+#define NN_Q 2
+#define NN_ROWS_PER_BLOCK (256 * NN_Q)
+
 template <bool KNN2>
 __device__ __forceinline__ void nn_body(const uint8_t* A, int na, const uint8_t* B, int nb,
                                         int* idx, int* dist, int* idx2, int* dist2)
 {
     __shared__ uint4 s_b[NN_TILE * 2];
-    const int tid = threadIdx.x, i = blockIdx.x * blockDim.x + tid;
-    Desc me;
-    me.a = make_uint4(0, 0, 0, 0); me.b = me.a;
-    if (i < na) { me.a = *(const uint4*)(A + (size_t)i * 32); me.b = *(const uint4*)(A + (size_t)i * 32 + 16); }
-    int d0 = INT_MAX, i0 = -1, d1 = INT_MAX, i1 = -1;
+    const int tid = threadIdx.x;
+    Desc me[NN_Q];
+    int row[NN_Q], d0[NN_Q], i0[NN_Q], d1[NN_Q], i1[NN_Q];
+#pragma unroll
+    for (int q = 0; q < NN_Q; q++) {
+        row[q] = blockIdx.x * NN_ROWS_PER_BLOCK + q * 256 + tid;
+        me[q].a = make_uint4(0, 0, 0, 0); me[q].b = me[q].a;
+        if (row[q] < na) { me[q].a = *(const uint4*)(A + (size_t)row[q] * 32); me[q].b = *(const uint4*)(A + (size_t)row[q] * 32 + 16); }
+        d0[q] = INT_MAX; i0[q] = -1; d1[q] = INT_MAX; i1[q] = -1;
+    }
     for (int base = 0; base < nb; base += NN_TILE) {
         const int j = base + tid;
         __syncthreads();
@@ -38,18 +47,25 @@ __device__ __forceinline__ void nn_body(const uint8_t* A, int na, const uint8_t*
         const int lim = min(NN_TILE, nb - base);
 #pragma unroll 4
         for (int k = 0; k < lim; k++) {
-            const int d = hamming(me, s_b[2 * k], s_b[2 * k + 1]);
-            if (KNN2) {
-                if (d < d1) {
-                    if (d0 > d) { d1 = d0; i1 = i0; d0 = d; i0 = base + k; }
-                    else { d1 = d; i1 = base + k; }
-                }
-            } else if (d < d0) { d0 = d; i0 = base + k; }
+            const uint4 ba = s_b[2 * k], bb = s_b[2 * k + 1];
+#pragma unroll
+            for (int q = 0; q < NN_Q; q++) {
+                const int d = hamming(me[q], ba, bb);
+                if (KNN2) {
+                    if (d < d1[q]) {
+                        if (d0[q] > d) { d1[q] = d0[q]; i1[q] = i0[q]; d0[q] = d; i0[q] = base + k; }
+                        else { d1[q] = d; i1[q] = base + k; }
+                    }
+                } else if (d < d0[q]) { d0[q] = d; i0[q] = base + k; }
+            }
         }
     }
-    if (i < na) {
-        idx[i] = i0; dist[i] = d0;
-        if (KNN2) { idx2[i] = i1; dist2[i] = d1; }
+#pragma unroll
+    for (int q = 0; q < NN_Q; q++) {
+        if (row[q] < na) {
+            idx[row[q]] = i0[q]; dist[row[q]] = d0[q];
+            if (KNN2) { idx2[row[q]] = i1[q]; dist2[row[q]] = d1[q]; }
+        }
     }
 }
 
@@ -64,7 +80,7 @@ void launch_nn_raw(hipStream_t s, const uint8_t* a, int na, const uint8_t* b, in
                    int* idx2, int* dist2, int knn2)
 {
     if (na <= 0) return;
-    dim3 grid((na + 255) / 256), block(256);
+    dim3 grid((na + NN_ROWS_PER_BLOCK - 1) / NN_ROWS_PER_BLOCK), block(256);
     if (knn2) hipLaunchKernelGGL(k_nn_raw<true>, grid, block, 0, s, a, na, b, nb, idx, dist, idx2, dist2);
     else hipLaunchKernelGGL(k_nn_raw<false>, grid, block, 0, s, a, na, b, nb, idx, dist, idx2, dist2);
 }
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(256) void k_nn_pairs(const uint8_t* desc, const int
     const int p = blockIdx.y, dir = dir_first + blockIdx.z;
     const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
     const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
-    if ((int)(blockIdx.x * blockDim.x) >= na) return;
+    if ((int)(blockIdx.x * NN_ROWS_PER_BLOCK) >= na) return;
     const size_t o = ((size_t)p * 2 + dir) * kp_cap;
     nn_body<KNN2>(desc + (size_t)fa * kp_cap * 32, na, desc + (size_t)fb * kp_cap * 32, nb,
                   pb.nn_idx + o, pb.nn_dist + o, pb.nn_idx2 + (size_t)p * kp_cap, pb.nn_dist2 + (size_t)p * kp_cap);
@@ -89,7 +105,7 @@ void launch_match_nn(hipStream_t s, const uint8_t* desc, const int* kp_count, in
 {
     if (P <= 0) return;
     dim3 block(256);
-    const int gx = (kp_cap + 255) / 256;
+    const int gx = (kp_cap + NN_ROWS_PER_BLOCK - 1) / NN_ROWS_PER_BLOCK;
     if (knn2) {
         hipLaunchKernelGGL(k_nn_pairs<true>, dim3(gx, P, 1), block, 0, s, desc, kp_count, kp_cap, pb, 0);
         return;

@@ -337,14 +337,17 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
         const uint32_t ce = (br_e | dk_e) & 0x80008000u, co = (br_o | dk_o) & 0x80008000u;
         if ((ce | co) && gy >= 3 && gy < lv.h - 3) {
             const int gx0 = x0 - 4 + 4 * gc;
-            const uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
+            uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
+            const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
+            bits &= hi_b >= lo_b ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
+            if (bits) {
+                int pos = atomicAdd(&s_qn, (int)__popc(bits));       // one LDS atomic per group
+                const int entry = gr * 256 + 4 * gc;                  // (score-tile row, column relative to x0-4)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if ((bits >> i) & 1u) {
-                    const int gx = gx0 + i;
-                    if (gx >= xlo && gx <= xhi) {
-                        const int pos = atomicAdd(&s_qn, 1);
-                        if (pos < FT_QCAP) s_q[pos] = (uint16_t)(gr * 256 + 4 * gc + i);   // (score-tile row, column relative to x0-4)
+                for (int i = 0; i < 4; i++) {
+                    if ((bits >> i) & 1u) {
+                        if (pos < FT_QCAP) s_q[pos] = (uint16_t)(entry + i);
+                        pos++;
                     }
                 }
             }
@@ -371,13 +374,49 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
         __syncthreads();
     }
     const int nc = s_q2n;
-    if (nq <= FT_QCAP && nc <= FT_Q2CAP) {
+    const bool queued = nq <= FT_QCAP && nc <= FT_Q2CAP;
+    if (queued) {
         for (int e = tid; e < nc; e += 256) {
             const int q = s_q2[e], gr = q >> 8, cx = q & 255;                  // cx: column relative to x0-4
             s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(s_px + (gr + 3) * FT_PXW + 12 + cx);
         }
+        __syncthreads();
+        // D. 3x3 non-max suppression, corners only (at most FT_Q2CAP = 2 per thread): decide, then clear losers
+        bool lose[2] = {false, false};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int e = tid + k * 256;
+            if (e < nc) {
+                const int q = s_q2[e], gr = q >> 8, cx = q & 255;
+                const uint8_t* c = s_sc + gr * FT_SCW + cx;
+                const int sv = c[0];
+                const int gx = x0 - 4 + cx, gy = y0 - 1 + gr;
+                const bool inside = gr >= 1 && gr <= FAST_TH && cx >= 4 && cx < 4 + FAST_TW;      // the tile proper, not its ring
+                const bool win = inside && sv > c[-1] && sv > c[1] && sv > c[-FT_SCW - 1] && sv > c[-FT_SCW] && sv > c[-FT_SCW + 1] &&
+                                 sv > c[FT_SCW - 1] && sv > c[FT_SCW] && sv > c[FT_SCW + 1];
+                lose[k] = !win;
+                if (win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[sv], 1u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int e = tid + k * 256;
+            if (e < nc && lose[k]) { const int q = s_q2[e]; s_sc[(q >> 8) * FT_SCW + (q & 255)] = 0; }
+        }
+        __syncthreads();
+        // dense store of the tile rows: 8 pixels per thread, 16 threads per row
+        const int tx = tid & 15;
+#pragma unroll 1
+        for (int ty = tid >> 4; ty < FAST_TH; ty += 16) {
+            const int gy = y0 + ty;
+            const uint32_t* c = (const uint32_t*)(s_sc + (ty + 1) * FT_SCW + 4 + tx * 8);
+            if (gy < lv.h && x0 + tx * 8 < lv.stride)
+                *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(c[0], c[1]);
+        }
     } else {
-        // a queue overflowed (extremely corner-dense tile): test and score every pixel of the tile + ring
+        // a queue overflowed (extremely corner-dense tile): test and score every pixel of the tile + ring,
+        // then the dense NMS + store
         for (int i = tid; i < FT_SCH * 130; i += 256) {
             const int gr = i / 130, cx = 3 + i % 130;
             const int gx = x0 - 4 + cx, gy = y0 - 1 + gr;
@@ -385,34 +424,32 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
             const uint8_t* c = s_px + (gr + 3) * FT_PXW + 12 + cx;
             if (fast_is_corner(c, t)) s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(c);
         }
-    }
-    __syncthreads();
-
-    // D. NMS + dense store: 8 pixels (two dwords) per thread, 16 threads per row, 16 rows per pass
-    const int tx = tid & 15;
+        __syncthreads();
+        const int tx = tid & 15;
 #pragma unroll 1
-    for (int ty = tid >> 4; ty < FAST_TH; ty += 16) {
-        const int gy = y0 + ty;
-        uint32_t out[2] = {0, 0};
+        for (int ty = tid >> 4; ty < FAST_TH; ty += 16) {
+            const int gy = y0 + ty;
+            uint32_t out[2] = {0, 0};
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int cx = 4 + tx * 8 + h * 4;                                // score-tile column of the dword
-            const uint8_t* c = s_sc + (ty + 1) * FT_SCW + cx;
-            if (*(const uint32_t*)c) {
+            for (int h = 0; h < 2; h++) {
+                const int cx = 4 + tx * 8 + h * 4;                                // score-tile column of the dword
+                const uint8_t* c = s_sc + (ty + 1) * FT_SCW + cx;
+                if (*(const uint32_t*)c) {
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int s = c[b];
-                    if (s && s > c[b - 1] && s > c[b + 1] && s > c[b - FT_SCW - 1] && s > c[b - FT_SCW] && s > c[b - FT_SCW + 1] &&
-                        s > c[b + FT_SCW - 1] && s > c[b + FT_SCW] && s > c[b + FT_SCW + 1]) {
-                        out[h] |= (uint32_t)s << (8 * b);
-                        const int gx = x0 + tx * 8 + h * 4 + b;
-                        if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[s], 1u);
+                    for (int b = 0; b < 4; b++) {
+                        const int sv = c[b];
+                        if (sv && sv > c[b - 1] && sv > c[b + 1] && sv > c[b - FT_SCW - 1] && sv > c[b - FT_SCW] && sv > c[b - FT_SCW + 1] &&
+                            sv > c[b + FT_SCW - 1] && sv > c[b + FT_SCW] && sv > c[b + FT_SCW + 1]) {
+                            out[h] |= (uint32_t)sv << (8 * b);
+                            const int gx = x0 + tx * 8 + h * 4 + b;
+                            if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[sv], 1u);
+                        }
                     }
                 }
             }
+            if (gy < lv.h && x0 + tx * 8 < lv.stride)
+                *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(out[0], out[1]);
         }
-        if (gy < lv.h && x0 + tx * 8 < lv.stride)
-            *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(out[0], out[1]);
     }
     __syncthreads();
     const uint32_t hv = s_hist[tid];
@@ -627,69 +664,103 @@ __device__ __forceinline__ float key2f(uint32_t k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-__global__ __launch_bounds__(256) void k_select_harris(PyrGeom g, FrameFeat ff)
+// (1) per (frame, level): the quota-th largest response by a 32-bit radix select (8 bits per pass, LDS
+//     histogram) and the number of candidates at or above it; (2) per (frame, level): output offset = kept
+//     counts of the lower levels, then an ordered compaction (keeps the canonical (level, y, x) order).
+__global__ __launch_bounds__(256) void k_harris_threshold(PyrGeom g, FrameFeat ff, float* thr_out, int* kept_out)
 {
-    __shared__ int s_w[17];
     __shared__ int s_hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_remaining;
-    const int f = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_kept;
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom lv = g.lv[l];
+    const int n = min(ff.cand_count[f * VO_MAX_LEVELS + l], lv.cand_cap);
+    const float* resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
+    float thr = -FLT_MAX;
+    if (lv.quota <= 0) thr = FLT_MAX;                      // retainBest(n_points == 0) clears
+    else if (n > lv.quota && g.score_type == 0) {
+        if (tid == 0) { s_prefix = 0; s_remaining = lv.quota; }
+        uint32_t maskbits = 0;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            s_hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            for (int i = tid; i < n; i += 256) {
+                const uint32_t k = f2key(resp[i]);
+                if ((k & maskbits) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // lane j owns digits 255-4j .. 252-4j; suffix counts by a wave scan
+                int c[4], own = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { c[k] = s_hist[255 - 4 * tid - k]; own += c[k]; }
+                int inc = own;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { int v = __shfl_up(inc, d, 64); if (tid >= d) inc += v; }
+                const int rem = s_remaining;
+                int acc = inc - own, digit = -1, before = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (digit < 0 && acc + c[k] >= rem) { digit = 255 - 4 * tid - k; before = acc; }
+                    acc += c[k];
+                }
+                const unsigned long long found = __ballot(digit >= 0);
+                const int src = found ? __ffsll((long long)found) - 1 : 63;
+                const int dsel = __shfl(digit, src, 64), bsel = __shfl(before, src, 64);
+                if (tid == 0) { s_prefix = prefix | ((uint32_t)(dsel < 0 ? 0 : dsel) << shift); s_remaining = rem - bsel; }
+            }
+            maskbits |= 255u << shift;
+            __syncthreads();
+        }
+        thr = key2f(s_prefix);
+    }
+    if (tid == 0) s_kept = 0;
+    __syncthreads();
+    int kept = 0;
+    for (int i = tid; i < n; i += 256) kept += resp[i] >= thr ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d, 64);
+    if ((tid & 63) == 0 && kept) atomicAdd(&s_kept, kept);
+    __syncthreads();
+    if (tid == 0) { thr_out[f * VO_MAX_LEVELS + l] = thr; kept_out[f * VO_MAX_LEVELS + l] = s_kept; }
+}
+
+__global__ __launch_bounds__(256) void k_harris_compact(PyrGeom g, FrameFeat ff, const float* thr_in, const int* kept_in)
+{
+    __shared__ int s_w[17];
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom lv = g.lv[l];
+    const int n = min(ff.cand_count[f * VO_MAX_LEVELS + l], lv.cand_cap);
+    const uint32_t* pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
+    const float* resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
+    const float thr = thr_in[f * VO_MAX_LEVELS + l];
     int out_base = 0;
-    bool overflow = false;
+    for (int k = 0; k < l; k++) out_base += kept_in[f * VO_MAX_LEVELS + k];
     uint32_t* kp_pos = ff.kp_pos + (size_t)f * g.kp_cap;
     int* kp_level = ff.kp_level + (size_t)f * g.kp_cap;
     float* kp_resp = ff.kp_resp + (size_t)f * g.kp_cap;
-    for (int l = 0; l < g.nlevels; l++) {
-        const LevelGeom lv = g.lv[l];
-        const int n = min(ff.cand_count[f * VO_MAX_LEVELS + l], lv.cand_cap);
-        const uint32_t* pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
-        const float* resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
-        float thr = -FLT_MAX;
-        if (n > lv.quota && lv.quota > 0 && g.score_type == 0) {
-            // 32-bit radix select of the quota-th largest response, 8 bits per pass
-            if (tid == 0) { s_prefix = 0; s_remaining = lv.quota; }
-            uint32_t maskbits = 0;
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                s_hist[tid] = 0;
-                __syncthreads();
-                const uint32_t prefix = s_prefix;
-                for (int i = tid; i < n; i += 256) {
-                    const uint32_t k = f2key(resp[i]);
-                    if ((k & maskbits) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    int rem = s_remaining, d = 255;
-                    for (; d > 0; d--) { if (s_hist[d] >= rem) break; rem -= s_hist[d]; }
-                    s_remaining = rem;
-                    s_prefix = prefix | ((uint32_t)d << shift);
-                }
-                maskbits |= 255u << shift;
-                __syncthreads();
-            }
-            thr = key2f(s_prefix);
+    bool overflow = false;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        const bool keep = i < n && resp[i] >= thr;
+        int tot;
+        const int p = out_base + block_excl_scan(keep ? 1 : 0, s_w, &tot);
+        if (keep) {
+            if (p < g.kp_cap) { kp_pos[p] = pos[i]; kp_level[p] = l; kp_resp[p] = resp[i]; }
+            else overflow = true;
         }
-        const int keep_all = (lv.quota <= 0) ? 0 : 1;     // retainBest(n_points == 0) clears
-        for (int base = 0; base < n; base += 256) {
-            const int i = base + tid;
-            const bool keep = keep_all && i < n && resp[i] >= thr;
-            int tot;
-            const int p = out_base + block_excl_scan(keep ? 1 : 0, s_w, &tot);
-            if (keep) {
-                if (p < g.kp_cap) { kp_pos[p] = pos[i]; kp_level[p] = l; kp_resp[p] = resp[i]; }
-                else overflow = true;
-            }
-            out_base += tot;
-        }
-        __syncthreads();
+        out_base += tot;
     }
     if (overflow) atomicOr(&ff.flags[f], 1);
-    if (tid == 0) ff.kp_count[f] = min(out_base, g.kp_cap);
+    if (l == g.nlevels - 1 && tid == 0) ff.kp_count[f] = min(out_base, g.kp_cap);
 }
 
-void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F)
+void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, float* thr, int* kept)
 {
-    hipLaunchKernelGGL(k_select_harris, dim3(F), dim3(256), 0, s, g, ff);
+    hipLaunchKernelGGL(k_harris_threshold, dim3(g.nlevels, F), dim3(256), 0, s, g, ff, thr, kept);
+    hipLaunchKernelGGL(k_harris_compact, dim3(g.nlevels, F), dim3(256), 0, s, g, ff, thr, kept);
 }
 
 // ------------------------------------------------------------------ orientation (orb.cpp ICAngles + fastAtan2)

@@ -21,7 +21,8 @@ struct vo_ctx {
     ResizeTab tabs[VO_MAX_LEVELS]{};
     void* tab_mem = nullptr;
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
-    int *sel_thr = nullptr, *sel_chunk_count = nullptr;
+    int *sel_thr = nullptr, *sel_chunk_count = nullptr, *har_kept = nullptr;
+    float* har_thr = nullptr;
     size_t staging_bytes = 0;
     FrameFeat ff{};
     PairBuf pb{};
@@ -211,9 +212,9 @@ static void free_config(vo_ctx* c)
 {
     void* ptrs[] = {c->tab_mem, c->pyr, c->blur, c->score, c->ff.cand_pos, c->ff.cand_resp, c->ff.cand_count,
                     c->ff.kp_pos, c->ff.kp_level, c->ff.kp_resp, c->ff.kp_angle, c->ff.kp_xy, c->ff.kp_size,
-                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->sel_thr, c->sel_chunk_count};
+                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->sel_thr, c->sel_chunk_count, c->har_kept, c->har_thr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr; c->sel_thr = c->sel_chunk_count = nullptr;
+    c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr; c->sel_thr = c->sel_chunk_count = c->har_kept = nullptr; c->har_thr = nullptr;
     memset(&c->ff, 0, sizeof(c->ff));
     free_pairbuf(c->pb);
     c->pb_pairs = c->pb_cap = 0;
@@ -322,6 +323,8 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     HIPCHK(dmalloc(&ff.kp_count, F)); HIPCHK(dmalloc(&ff.flags, F));
     HIPCHK(dmalloc(&ff.hist, F * VO_MAX_LEVELS * 256));
     HIPCHK(dmalloc(&ctx->sel_thr, F * VO_MAX_LEVELS));
+    HIPCHK(dmalloc(&ctx->har_kept, F * VO_MAX_LEVELS));
+    HIPCHK(dmalloc(&ctx->har_thr, F * VO_MAX_LEVELS));
     HIPCHK(dmalloc(&ctx->sel_chunk_count, F * (size_t)(g.sel_chunks_total + 1)));
     HIPCHK(hipMemset(ff.kp_count, 0, F * sizeof(int)));
     HIPCHK(hipMemset(ff.flags, 0, F * sizeof(int)));
@@ -379,7 +382,7 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     if (upto < 2) return VO_OK;
     { StageTimer t(ctx, ST_SELECT_FAST); launch_select_fast(s, score, g, ff, F, ctx->sel_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->sel_chunk_count + (size_t)first_slot * g.sel_chunks_total); }
     if (g.score_type == 0) { StageTimer t(ctx, ST_HARRIS); launch_harris(s, pyr, g, ff, F); }
-    { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F); }
+    { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F, ctx->har_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->har_kept + (size_t)first_slot * VO_MAX_LEVELS); }
     { StageTimer t(ctx, ST_ANGLE); launch_angle(s, pyr, g, ff, F); }
     { StageTimer t(ctx, ST_BLUR); launch_blur(s, pyr, blur, g, F); }
     { StageTimer t(ctx, ST_BRIEF); launch_brief(s, blur, g, ff, F); }

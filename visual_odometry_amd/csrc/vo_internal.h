@@ -105,7 +105,7 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F);
 void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count);
 void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
-void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F);
+void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, float* thr, int* kept);
 void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F);
 void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F);
