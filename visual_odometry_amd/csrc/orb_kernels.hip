@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
-    __shared__ uint16_t s_q[FT_QCAP];
+    __shared__ uint16_t s_q[FT_QCAP + 1];         // + one spare slot for the branch-free push
     __shared__ uint16_t s_q2[FT_Q2CAP];
     __shared__ int s_q2n;
     __shared__ uint32_t s_hist[256];
@@ -335,21 +335,18 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
         const uint32_t dk_e = (pk_sub16(r0_e, lo_e) | pk_sub16(r8_e, lo_e)) & (pk_sub16(r4_e, lo_e) | pk_sub16(r12_e, lo_e));
         const uint32_t dk_o = (pk_sub16(r0_o, lo_o) | pk_sub16(r8_o, lo_o)) & (pk_sub16(r4_o, lo_o) | pk_sub16(r12_o, lo_o));
         const uint32_t ce = (br_e | dk_e) & 0x80008000u, co = (br_o | dk_o) & 0x80008000u;
-        if ((ce | co) && gy >= 3 && gy < lv.h - 3) {
-            const int gx0 = x0 - 4 + 4 * gc;
-            uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
-            const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
-            bits &= hi_b >= lo_b ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
-            if (bits) {
-                int pos = atomicAdd(&s_qn, (int)__popc(bits));       // one LDS atomic per group
-                const int entry = gr * 256 + 4 * gc;                  // (score-tile row, column relative to x0-4)
+        // per-pixel candidate bits, clipped to the columns / rows where a corner is possible
+        const int gx0 = x0 - 4 + 4 * gc;
+        uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
+        const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
+        bits &= (hi_b >= lo_b && gy >= 3 && gy < lv.h - 3) ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
+        if (bits) {
+            const int pos = atomicAdd(&s_qn, (int)__popc(bits));       // one LDS atomic per group
+            const int entry = gr * 256 + 4 * gc;                        // (score-tile row, column relative to x0-4)
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if ((bits >> i) & 1u) {
-                        if (pos < FT_QCAP) s_q[pos] = (uint16_t)(entry + i);
-                        pos++;
-                    }
-                }
+            for (int i = 0; i < 4; i++) {                               // branch-free: losers write the spare slot
+                const int slot = pos + (int)__popc(bits & ((1u << i) - 1u));
+                s_q[((bits >> i) & 1u) && slot < FT_QCAP ? slot : FT_QCAP] = (uint16_t)(entry + i);
             }
         }
     }
