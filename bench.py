@@ -38,6 +38,25 @@ def ping_pong(n_distinct, n_total, start=0):
     return np.array(idx)
 
 
+STAGE_KERNELS = {"fast_score_nms": [("k_fast", 1)], "gaussian_blur": [("k_blur", 1)],
+                 "pyramid_resize": [("k_resize_tiled", 7)],
+                 "select_fast": [("k_sel_threshold", 1), ("k_sel_scan<false>", 1), ("k_sel_scan<true>", 1)],
+                 "match_nn": [("k_nn_pairs<false>", 1)], "essential_ransac": [("k_ransac", 1)]}
+
+
+def pmc_traffic(stage, nframes):
+    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB ->
+    bytes, tools/collect_traffic.py); None when no pass exists for this workload size."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+        if t.get("_meta", {}).get("frames_per_launch") != nframes:
+            return None
+        return float(sum(t[k]["hbm_bytes_per_launch"] * n for k, n in STAGE_KERNELS[stage]))
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(frames, K, nfeatures, nlevels, match_mode, ratio, budget_s=12.0):
     """The CPU oracle ("port") on the host cores over a bounded sample of the same pairs."""
     from concurrent.futures import ThreadPoolExecutor
@@ -174,7 +193,8 @@ def main():
             b = fe.stage_bytes(dom, nframes)
             ach = b / (ms / n * 1e-3) / 1e9 if b > 0 and ms > 0 else 0.0
             line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                                "traffic": pmc_traffic(dom, nframes),
                                 "algorithmic_bytes_per_launch": b, "avg_launch_ms": round(ms / n, 4)}
             hbm_stages = {}
             for k in ("pyramid_resize", "fast_score_nms", "select_fast", "gaussian_blur"):

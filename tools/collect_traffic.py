@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc runs of bench.py (one with FETCH_SIZE, one with WRITE_SIZE, as
+MI355X_MICROARCH.md prescribes: separate passes, --kernel-trace only) into profiles/<tag>_pmc_traffic.json.
+
+Units and gfx950 corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; WRITE_SIZE reads
+16-byte-per-lane streaming stores exactly; FETCH_SIZE reports half of the bytes of a wide coalesced streaming
+read, so it is doubled.  Calibration on this code base: k_sel_scan<false> streams the score map inside the
+31-px border with aligned 16-byte loads (about 0.82 x the pyramid bytes); its raw FETCH_SIZE is 0.545 of that
+byte count, i.e. the factor 2 applies to our access pattern.
+
+usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> [frames_per_launch]
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d, counter):
+    acc = collections.defaultdict(list)
+    for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        out[k] = {"fetch_size_kib_raw": round(f, 1), "write_size_kib_raw": round(w, 1),
+                  "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0)}
+    out["_meta"] = {"frames_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 257,
+                    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile"}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
