@@ -197,77 +197,26 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 }
 
 // ------------------------------------------------------------------ FAST-9/16 + cornerScore + 3x3 NMS
-// fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  One workgroup = a FAST_TW x FAST_TH output tile.
-//  A. the tile + halo is staged in LDS with 16-byte global loads (rows are 64-byte aligned in HBM);
+// fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  One WAVEFRONT = one FAST_TW x FAST_TH output tile;
+// a workgroup is a single wave, so the kernel has no cross-wave barrier and every wave runs at its own pace.
+//  A. the tile + halo 4 is staged in LDS with 16-byte global loads (rows are 64-byte aligned in HBM);
 //  B. high-speed pre-test, one lane = 4 horizontally adjacent pixels read as dwords from LDS and compared
 //     two at a time with packed 16-bit subtractions (v_perm_b32 + v_pk_sub_i16): a 9-arc of the 16-ring
-//     always contains two adjacent compass pixels (ring 0, 4, 8, 12), so a pixel can only be a corner if
-//     two adjacent compass pixels are both brighter than v+t or both darker than v-t (the same early-out
-//     OpenCV's FAST applies).  Survivors (a few % of pixels) are appended to an LDS queue;
-//  C. only queued pixels run the exact test (two 16-bit ring masks, 9 contiguous bits) and, if they are
-//     corners, cornerScore: max(A, B) - 1 with A/B the best 9-arc minimum of (v - ring) / (ring - v);
-//  D. 3x3 non-max suppression from the LDS score tile, dense dword stores of the score map, and the
-//     per-level score histogram that retainBest needs (LDS atomics, one global atomic per non-empty bin).
-#define FT_PXW 160                       // LDS pixel tile: columns x0-16 .. x0+143
+//     always contains two adjacent compass pixels (ring 0, 4, 8, 12), so a pixel can only be a corner if two
+//     adjacent compass pixels are both brighter than v+t or both darker than v-t (OpenCV's own early-out).
+//     Survivors (a few % of the pixels) are appended to a wave-private LDS queue: wavefront ballot of the
+//     candidate bit + v_mbcnt prefix, no atomics;
+//  C. queued pixels get cornerScore directly, two ring differences per packed 16-bit min/max:
+//     A / B = best 9-arc minimum of (v - ring) / (ring - v); corner <=> max(A, B) > t, score = max(A, B) - 1;
+//  D. 3x3 non-max suppression on the queue (decide, then clear the losers in the LDS score tile), survivors
+//     inside the border feed the per-level score histogram retainBest needs (global atomics, ~3 per tile);
+//  E. dense 16-byte stores of the score tile.
+#define FT_PXW (FAST_TW + 32)            // LDS pixel tile: columns x0-16 .. x0+TW+15
 #define FT_PXH (FAST_TH + 8)             // rows y0-4 .. y0+TH+3
-#define FT_SCW 144                       // LDS score tile: columns x0-4 .. x0+139 (dword aligned with the output)
+#define FT_SCW (FAST_TW + 16)            // LDS score tile: columns x0-4 .. x0+TW+11 (dword aligned with the output)
 #define FT_SCH (FAST_TH + 2)             // rows y0-1 .. y0+TH
-#define FT_GROUPS_X 34                   // dword groups covering x0-4 .. x0+131
-#define FT_QCAP 1024                     // candidate queue (compass survivors); a tile that overflows it takes the dense path
-#define FT_Q2CAP 512                     // corner queue
-
-__device__ __forceinline__ bool has_arc9(uint32_t m)     // 16-bit ring mask: 9 cyclically contiguous bits set?
-{
-    m |= m << 16;
-    uint32_t x = m & (m >> 1);
-    x &= x >> 2;
-    x &= x >> 4;
-    x &= m >> 8;
-    return x != 0;
-}
-
-// ring differences v - ring[k] of the pixel at c (centre in the LDS pixel tile)
-__device__ __forceinline__ void fast_ring_diffs(const uint8_t* c, int* d)
-{
-    const int v = c[0];
-    d[0]  = v - c[3 * FT_PXW];      d[1]  = v - c[3 * FT_PXW + 1];  d[2]  = v - c[2 * FT_PXW + 2];  d[3]  = v - c[FT_PXW + 3];
-    d[4]  = v - c[3];               d[5]  = v - c[-FT_PXW + 3];     d[6]  = v - c[-2 * FT_PXW + 2]; d[7]  = v - c[-3 * FT_PXW + 1];
-    d[8]  = v - c[-3 * FT_PXW];     d[9]  = v - c[-3 * FT_PXW - 1]; d[10] = v - c[-2 * FT_PXW - 2]; d[11] = v - c[-FT_PXW - 3];
-    d[12] = v - c[-3];              d[13] = v - c[FT_PXW - 3];      d[14] = v - c[2 * FT_PXW - 2];  d[15] = v - c[3 * FT_PXW - 1];
-}
-
-// exact FAST-9/16 test: 9 contiguous ring pixels all darker than v - t or all brighter than v + t
-__device__ __forceinline__ bool fast_is_corner(const uint8_t* c, int t)
-{
-    int d[16];
-    fast_ring_diffs(c, d);
-    uint32_t dark = 0, bright = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) { dark |= (uint32_t)(d[k] > t) << k; bright |= (uint32_t)(d[k] < -t) << k; }
-    return has_arc9(dark) || has_arc9(bright);
-}
-
-// cornerScore<16> of a corner: max(A, B) - 1
-__device__ __forceinline__ int fast_corner_score(const uint8_t* c)
-{
-    int d[16];
-    fast_ring_diffs(c, d);
-    int mn[16], mx[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn[k] = min(d[k], d[(k + 1) & 15]); mx[k] = max(d[k], d[(k + 1) & 15]); }
-    int mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { mn4[k] = min(mn[k], mn[(k + 2) & 15]); mx4[k] = max(mx[k], mx[(k + 2) & 15]); }
-    int A = -256, B = -256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int a = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int b = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        A = max(A, a);
-        B = max(B, -b);
-    }
-    return max(A, B) - 1;
-}
+#define FT_GROUPS_X (FAST_TW / 4 + 2)    // dword groups covering x0-4 .. x0+TW+3
+#define FT_QCAP 448                      // candidate queue; a tile that overflows it takes the dense path
 
 typedef short vo_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
@@ -278,17 +227,58 @@ __device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) + __builtin_bit_cast(vo_s16x2, b));
 }
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(vo_s16x2, a), __builtin_bit_cast(vo_s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vo_s16x2, a), __builtin_bit_cast(vo_s16x2, b)));
+}
+__device__ __forceinline__ uint32_t swap16(uint32_t a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 
-__global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g)
+// cornerScore<16> with the corner decision folded in: 0 if the pixel at c (centre in the LDS pixel tile) is
+// no FAST-9 corner, else max(A, B) - 1.  Q[k] holds the ring differences (d[k], d[k+8]) as two int16.
+__device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)
+{
+    const uint32_t v = c[0], vv = v | (v << 16);
+    uint32_t Q[8];
+#define RD(k, o0, o8) Q[k] = pk_sub16(vv, (uint32_t)c[o0] | ((uint32_t)c[o8] << 16))
+    RD(0, 3 * FT_PXW, -3 * FT_PXW);         RD(1, 3 * FT_PXW + 1, -3 * FT_PXW - 1);
+    RD(2, 2 * FT_PXW + 2, -2 * FT_PXW - 2); RD(3, FT_PXW + 3, -FT_PXW - 3);
+    RD(4, 3, -3);                           RD(5, -FT_PXW + 3, FT_PXW - 3);
+    RD(6, -2 * FT_PXW + 2, 2 * FT_PXW - 2); RD(7, -3 * FT_PXW + 1, 3 * FT_PXW - 1);
+#undef RD
+    // windows of 2, 4, 8 and 9 consecutive differences; index k+8 is the same register with halves swapped
+    uint32_t mn2[8], mx2[8], mn4[8], mx4[8];
+    const uint32_t q8 = swap16(Q[0]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t nx = k < 7 ? Q[k + 1] : q8; mn2[k] = pk_min16(Q[k], nx); mx2[k] = pk_max16(Q[k], nx); }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t n2 = k < 6 ? mn2[k + 2] : swap16(mn2[k - 6]), x2 = k < 6 ? mx2[k + 2] : swap16(mx2[k - 6]);
+        mn4[k] = pk_min16(mn2[k], n2); mx4[k] = pk_max16(mx2[k], x2);
+    }
+    uint32_t A2 = 0x80008000u, B2 = 0x7fff7fffu;       // running max of arc minima / min of arc maxima
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t n4 = k < 4 ? mn4[k + 4] : swap16(mn4[k - 4]), x4 = k < 4 ? mx4[k + 4] : swap16(mx4[k - 4]);
+        const uint32_t far = swap16(Q[k]);              // (d[k+8], d[k])
+        A2 = pk_max16(A2, pk_min16(pk_min16(mn4[k], n4), far));
+        B2 = pk_min16(B2, pk_max16(pk_max16(mx4[k], x4), far));
+    }
+    const int A = max((int)(short)(A2 & 0xffffu), (int)(short)(A2 >> 16));
+    const int B = -min((int)(short)(B2 & 0xffffu), (int)(short)(B2 >> 16));
+    const int m = max(A, B);
+    return m > t ? m - 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
-    __shared__ uint16_t s_q[FT_QCAP + 1];         // + one spare slot for the branch-free push
-    __shared__ uint16_t s_q2[FT_Q2CAP];
-    __shared__ int s_q2n;
-    __shared__ uint32_t s_hist[256];
-    __shared__ int s_qn;
-    const int f = blockIdx.y, tid = threadIdx.x;
+    __shared__ uint16_t s_q[FT_QCAP + 1];            // + one spare slot for the branch-free push
+    const int f = blockIdx.y, lane = threadIdx.x;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].ftile_base) l++;
     const LevelGeom lv = g.lv[l];
@@ -297,11 +287,11 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     const int t = g.fast_thr;
 
-    // A. stage pixels (16-byte loads), clear the score tile, histogram and queue
-    s_hist[tid] = 0;
-    if (tid == 0) { s_qn = 0; s_q2n = 0; }
-    for (int i = tid; i < FT_SCH * FT_SCW / 16; i += 256) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < FT_PXH * (FT_PXW / 16); i += 256) {
+    // A. stage pixels (16-byte loads), clear the score tile
+#pragma unroll
+    for (int i = lane; i < FT_SCH * FT_SCW / 16; i += 64) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = lane; i < FT_PXH * (FT_PXW / 16); i += 64) {
         const int ry = i / (FT_PXW / 16), rx = (i % (FT_PXW / 16)) * 16;
         const int gy = y0 - 4 + ry, gx = x0 - 16 + rx;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -313,9 +303,12 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
     // B. compass pre-test on the tile + 1 ring, 4 pixels per lane, two pixels per packed 16-bit operation
     const uint32_t T2 = (uint32_t)t * 0x00010001u;
     const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
+    int qn = 0;                                       // wave-uniform queue length
 #pragma unroll
-    for (int gi = tid; gi < FT_GROUPS_X * FT_SCH; gi += 256) {
-        const int gr = gi / FT_GROUPS_X, gc = gi - gr * FT_GROUPS_X;
+    for (int it = 0; it < (FT_GROUPS_X * FT_SCH + 63) / 64; it++) {
+        const int gi = it * 64 + lane;
+        const bool in_range = gi < FT_GROUPS_X * FT_SCH;
+        const int gr = in_range ? gi / FT_GROUPS_X : 0, gc = in_range ? gi - gr * FT_GROUPS_X : 0;
         const int gy = y0 - 1 + gr;
         const uint32_t* rowp = (const uint32_t*)(s_px + (gr + 3) * FT_PXW) + 3 + gc;     // dword of the group itself
         const uint32_t c = rowp[0], wl = rowp[-1], wr = rowp[1];
@@ -339,123 +332,87 @@ __global__ __launch_bounds__(256, 8) void k_fast(const uint8_t* pyr, uint8_t* sc
         const int gx0 = x0 - 4 + 4 * gc;
         uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
         const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
-        bits &= (hi_b >= lo_b && gy >= 3 && gy < lv.h - 3) ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
-        if (bits) {
-            const int pos = atomicAdd(&s_qn, (int)__popc(bits));       // one LDS atomic per group
-            const int entry = gr * 256 + 4 * gc;                        // (score-tile row, column relative to x0-4)
+        bits &= (in_range && hi_b >= lo_b && gy >= 3 && gy < lv.h - 3) ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
+        if (__ballot(bits != 0)) {                                   // wave-uniform
+            const int entry = gr * 256 + 4 * gc;                     // (score-tile row, column relative to x0-4)
 #pragma unroll
-            for (int i = 0; i < 4; i++) {                               // branch-free: losers write the spare slot
-                const int slot = pos + (int)__popc(bits & ((1u << i) - 1u));
-                s_q[((bits >> i) & 1u) && slot < FT_QCAP ? slot : FT_QCAP] = (uint16_t)(entry + i);
+            for (int i = 0; i < 4; i++) {
+                const bool set = (bits >> i) & 1u;
+                const unsigned long long m = __ballot(set);
+                const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                s_q[set && slot < FT_QCAP ? slot : FT_QCAP] = (uint16_t)(entry + i);
+                qn += (int)__popcll(m);
             }
         }
     }
     __syncthreads();
 
-    // C. exact test for the queued candidates; the corners among them are compacted into a second queue
-    //    so that cornerScore runs on full wavefronts of corners only
-    const int nq = s_qn;
-    if (nq <= FT_QCAP) {
-        for (int e = tid; e - (tid & 63) < nq; e += 256) {
-            bool corner = false;
-            int q = 0;
-            if (e < nq) {
-                q = s_q[e];
-                corner = fast_is_corner(s_px + ((q >> 8) + 3) * FT_PXW + 12 + (q & 255), t);
-            }
-            if (corner) {
-                const int pos = atomicAdd(&s_q2n, 1);
-                if (pos < FT_Q2CAP) s_q2[pos] = (uint16_t)q;
-            }
+    if (qn <= FT_QCAP) {
+        // C. cornerScore (0 = no corner) for the queued candidates
+        for (int e = lane; e < qn; e += 64) {
+            const int q = s_q[e], gr = q >> 8, cx = q & 255;             // cx: column relative to x0-4
+            s_sc[gr * FT_SCW + cx] = (uint8_t)fast_score_or_zero(s_px + (gr + 3) * FT_PXW + 12 + cx, t);
         }
         __syncthreads();
-    }
-    const int nc = s_q2n;
-    const bool queued = nq <= FT_QCAP && nc <= FT_Q2CAP;
-    if (queued) {
-        for (int e = tid; e < nc; e += 256) {
-            const int q = s_q2[e], gr = q >> 8, cx = q & 255;                  // cx: column relative to x0-4
-            s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(s_px + (gr + 3) * FT_PXW + 12 + cx);
-        }
-        __syncthreads();
-        // D. 3x3 non-max suppression, corners only (at most FT_Q2CAP = 2 per thread): decide, then clear losers
-        bool lose[2] = {false, false};
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int e = tid + k * 256;
-            if (e < nc) {
-                const int q = s_q2[e], gr = q >> 8, cx = q & 255;
-                const uint8_t* c = s_sc + gr * FT_SCW + cx;
-                const int sv = c[0];
+        // D. 3x3 non-max suppression on the queue: decide (bit k of `lose` = k-th entry of this lane), then clear
+        uint32_t lose = 0;
+        for (int e = lane, k = 0; e < qn; e += 64, k++) {
+            const int q = s_q[e], gr = q >> 8, cx = q & 255;
+            const uint8_t* c = s_sc + gr * FT_SCW + cx;
+            const int sv = c[0];
+            if (sv) {
                 const int gx = x0 - 4 + cx, gy = y0 - 1 + gr;
                 const bool inside = gr >= 1 && gr <= FAST_TH && cx >= 4 && cx < 4 + FAST_TW;      // the tile proper, not its ring
                 const bool win = inside && sv > c[-1] && sv > c[1] && sv > c[-FT_SCW - 1] && sv > c[-FT_SCW] && sv > c[-FT_SCW + 1] &&
                                  sv > c[FT_SCW - 1] && sv > c[FT_SCW] && sv > c[FT_SCW + 1];
-                lose[k] = !win;
-                if (win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[sv], 1u);
+                if (!win) lose |= 1u << k;
+                else if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge)
+                    atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int e = tid + k * 256;
-            if (e < nc && lose[k]) { const int q = s_q2[e]; s_sc[(q >> 8) * FT_SCW + (q & 255)] = 0; }
-        }
+        for (int e = lane, k = 0; e < qn; e += 64, k++)
+            if ((lose >> k) & 1u) { const int q = s_q[e]; s_sc[(q >> 8) * FT_SCW + (q & 255)] = 0; }
         __syncthreads();
-        // dense store of the tile rows: 8 pixels per thread, 16 threads per row
-        const int tx = tid & 15;
-#pragma unroll 1
-        for (int ty = tid >> 4; ty < FAST_TH; ty += 16) {
-            const int gy = y0 + ty;
-            const uint32_t* c = (const uint32_t*)(s_sc + (ty + 1) * FT_SCW + 4 + tx * 8);
-            if (gy < lv.h && x0 + tx * 8 < lv.stride)
-                *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(c[0], c[1]);
-        }
     } else {
-        // a queue overflowed (extremely corner-dense tile): test and score every pixel of the tile + ring,
-        // then the dense NMS + store
-        for (int i = tid; i < FT_SCH * 130; i += 256) {
-            const int gr = i / 130, cx = 3 + i % 130;
+        // the queue overflowed (extremely corner-dense tile): score every pixel of the tile + ring, dense NMS
+        for (int i = lane; i < FT_SCH * (FAST_TW + 2); i += 64) {
+            const int gr = i / (FAST_TW + 2), cx = 3 + i % (FAST_TW + 2);
             const int gx = x0 - 4 + cx, gy = y0 - 1 + gr;
             if (gx < xlo || gx > xhi || gy < 3 || gy >= lv.h - 3) continue;
-            const uint8_t* c = s_px + (gr + 3) * FT_PXW + 12 + cx;
-            if (fast_is_corner(c, t)) s_sc[gr * FT_SCW + cx] = (uint8_t)fast_corner_score(c);
+            s_sc[gr * FT_SCW + cx] = (uint8_t)fast_score_or_zero(s_px + (gr + 3) * FT_PXW + 12 + cx, t);
         }
         __syncthreads();
-        const int tx = tid & 15;
-#pragma unroll 1
-        for (int ty = tid >> 4; ty < FAST_TH; ty += 16) {
-            const int gy = y0 + ty;
-            uint32_t out[2] = {0, 0};
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int cx = 4 + tx * 8 + h * 4;                                // score-tile column of the dword
-                const uint8_t* c = s_sc + (ty + 1) * FT_SCW + cx;
-                if (*(const uint32_t*)c) {
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const int sv = c[b];
-                        if (sv && sv > c[b - 1] && sv > c[b + 1] && sv > c[b - FT_SCW - 1] && sv > c[b - FT_SCW] && sv > c[b - FT_SCW + 1] &&
-                            sv > c[b + FT_SCW - 1] && sv > c[b + FT_SCW] && sv > c[b + FT_SCW + 1]) {
-                            out[h] |= (uint32_t)sv << (8 * b);
-                            const int gx = x0 + tx * 8 + h * 4 + b;
-                            if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge) atomicAdd(&s_hist[sv], 1u);
-                        }
-                    }
-                }
-            }
-            if (gy < lv.h && x0 + tx * 8 < lv.stride)
-                *(uint2*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + x0 + tx * 8) = make_uint2(out[0], out[1]);
+        uint8_t* s_out = s_px;                            // pixels are no longer needed: NMS result goes here
+        for (int i = lane; i < FAST_TH * FAST_TW; i += 64) {
+            const int ty = i / FAST_TW, tx = i % FAST_TW;
+            const uint8_t* c = s_sc + (ty + 1) * FT_SCW + 4 + tx;
+            const int sv = c[0];
+            const bool win = sv && sv > c[-1] && sv > c[1] && sv > c[-FT_SCW - 1] && sv > c[-FT_SCW] && sv > c[-FT_SCW + 1] &&
+                             sv > c[FT_SCW - 1] && sv > c[FT_SCW] && sv > c[FT_SCW + 1];
+            s_out[i] = win ? (uint8_t)sv : 0;
+            const int gx = x0 + tx, gy = y0 + ty;
+            if (win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge)
+                atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
         }
+        __syncthreads();
+        for (int i = lane; i < FAST_TH * FAST_TW; i += 64) s_sc[(i / FAST_TW + 1) * FT_SCW + 4 + i % FAST_TW] = s_out[i];
+        __syncthreads();
     }
-    __syncthreads();
-    const uint32_t hv = s_hist[tid];
-    if (hv) atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + tid], hv);
+    // E. dense store of the tile rows, 16 bytes per lane
+#pragma unroll
+    for (int i = lane; i < FAST_TH * (FAST_TW / 16); i += 64) {
+        const int ty = i / (FAST_TW / 16), c16 = i % (FAST_TW / 16);
+        const int gy = y0 + ty, gx = x0 + 16 * c16;
+        const uint32_t* c = (const uint32_t*)(s_sc + (ty + 1) * FT_SCW + 4 + 16 * c16);
+        if (gy < lv.h && gx < lv.stride)
+            *(uint4*)(score + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + gx) = make_uint4(c[0], c[1], c[2], c[3]);
+    }
 }
 
 void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F)
 {
-    hipLaunchKernelGGL(k_fast, dim3(g.ftiles_total, F), dim3(256), 0, s, pyr, score, hist, g);
+    hipLaunchKernelGGL(k_fast, dim3(g.ftiles_total, F), dim3(64), 0, s, pyr, score, hist, g);
 }
 
 // ------------------------------------------------------------------ retainBest by FAST score
