@@ -304,6 +304,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     const uint32_t T2 = (uint32_t)t * 0x00010001u;
     const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
     int qn = 0;                                       // wave-uniform queue length
+    const bool edge_tile = x0 < 4 || x0 + FAST_TW + 4 > lv.w || y0 < 4 || y0 + FAST_TH + 4 > lv.h;
 #pragma unroll
     for (int it = 0; it < (FT_GROUPS_X * FT_SCH + 63) / 64; it++) {
         const int gi = it * 64 + lane;
@@ -329,10 +330,15 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         const uint32_t dk_o = (pk_sub16(r0_o, lo_o) | pk_sub16(r8_o, lo_o)) & (pk_sub16(r4_o, lo_o) | pk_sub16(r12_o, lo_o));
         const uint32_t ce = (br_e | dk_e) & 0x80008000u, co = (br_o | dk_o) & 0x80008000u;
         // per-pixel candidate bits, clipped to the columns / rows where a corner is possible
-        const int gx0 = x0 - 4 + 4 * gc;
         uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
-        const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
-        bits &= (in_range && hi_b >= lo_b && gy >= 3 && gy < lv.h - 3) ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
+        if (edge_tile) {                                             // wave-uniform: tiles touching the image border
+            const int gx0 = x0 - 4 + 4 * gc;
+            const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
+            bits &= (hi_b >= lo_b && gy >= 3 && gy < lv.h - 3) ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
+        } else {
+            bits &= gc == 0 ? 8u : gc == FT_GROUPS_X - 1 ? 1u : 15u;  // ring columns x0-1 and x0+TW only
+        }
+        if (!in_range) bits = 0;
         if (__ballot(bits != 0)) {                                   // wave-uniform
             const int entry = gr * 256 + 4 * gc;                     // (score-tile row, column relative to x0-4)
 #pragma unroll
