@@ -22,6 +22,17 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* hypot from IEEE operations only (OpenCV calls std::hypot; this agrees with it to ~1 ulp). Written out so
+ * that the HIP kernels, which use the same expression, reproduce the Jacobi rotations bit for bit. */
+static inline double vo_hypot(double a, double b)
+{
+    a = fabs(a); b = fabs(b);
+    if (a < b) { double t = a; a = b; b = t; }
+    if (a == 0) return 0;
+    double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
 /* ---------------------------------------------------------------- one-sided Jacobi SVD (lapack.cpp JacobiSVDImpl_)
  * At: n rows of length m (row i = column i of A, A is m x n, m >= n). On return row i of At is
  * sigma_i * u_i (NOT normalised), W sorted descending, Vt (n x n) rows = right singular vectors. */
@@ -45,7 +56,7 @@ static void jacobi_svd(double* At, int m, int n, double* W, double* Vt)
                 for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta), c, s;
+                double beta = a - b, gamma = vo_hypot(p, beta), c, s;
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);

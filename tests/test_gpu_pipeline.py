@@ -13,8 +13,17 @@ def _check_pair(res, X, ref):
     got_rt = np.hstack([res["R"].reshape(3, 3), res["t"].reshape(3, 1)])
     assert np.linalg.norm(got_rt - np.hstack([ref["R"], ref["t"]])) < 1e-4
     n = ref["n_inl"]
-    rel = np.linalg.norm(X[:3, :n] - ref["X"][:3, :n], axis=0) / np.linalg.norm(ref["X"][:3, :n], axis=0)
-    assert rel.max() < 1e-3
+    Xg, Xr = X[:, :n], ref["X"][:, :n]
+    norm_r = np.linalg.norm(Xr[:3], axis=0)
+    rel = np.linalg.norm(Xg[:3] - Xr[:3], axis=0) / norm_r
+    # DLT points with (almost) no parallax are arbitrarily ill conditioned: a 1e-12 change of [R|t] moves them by
+    # more than 1e-3 relative (the reference itself drops far points, visual_slam.py:177-178). The 1e-3 bound is
+    # asserted on the points within 10x the median distance, the homogeneous direction on all of them.
+    near = norm_r <= 10.0 * np.median(norm_r)
+    assert near.sum() > 0.9 * n
+    assert rel[near].max() < 1e-3, (rel.max(), norm_r[np.argmax(rel)])
+    hg, hr = Xg / np.linalg.norm(Xg, axis=0), Xr / np.linalg.norm(Xr, axis=0)
+    assert (1.0 - np.abs((hg * hr).sum(axis=0))).max() < 1e-9
     assert np.allclose(X[3, :n], 1.0)
 
 
@@ -99,3 +108,39 @@ def test_too_few_matches_raises(ctx):
     ip.match_features()
     with pytest.raises(ValueError):
         ip.determine_essential_matrix(ip.filtered_matches)
+
+
+def test_bgr_frames_and_config3_shape(oracle):
+    """BGR upload (gray conversion on the device) and the 4-level / 4000-feature configuration on a 1080p frame."""
+    from visual_odometry_amd import synth
+    from visual_odometry_amd.frontend import FrontEnd
+    seq = synth.sequence(2, 1920, 1080, cache_dir="/tmp")
+    gray, K = seq["frames"], seq["K"]
+    rng = np.random.default_rng(5)
+    bgr = np.clip(gray[..., None].astype(np.int16) + rng.integers(-6, 7, gray.shape + (3,)), 0, 255).astype(np.uint8)
+    fe = FrontEnd(1080, 1920, max_frames=2, max_pairs=1, nfeatures=4000, nlevels=4)
+    fe.upload(bgr)
+    fe.detect(0, 2)
+    p = oracle.orb_params(nfeatures=4000, nlevels=4)
+    for s in range(2):
+        ref = oracle.orb_detect_and_compute(bgr[s], p)
+        got = fe.features(s)
+        assert len(ref["xy"]) > 3500 and not got["truncated"]
+        assert np.array_equal(got["xy"], ref["xy"]) and np.array_equal(got["desc"], ref["desc"])
+        assert np.array_equal(got["angle"], ref["angle"]) and np.array_equal(got["response"], ref["response"])
+    res, X = fe.run_pairs([[0, 1]], K, want_points=True)
+    ref = oracle.pair(oracle.gray(bgr[0]), oracle.gray(bgr[1]), p, K)
+    _check_pair(res[0], X[0], ref)
+
+
+def test_kitti_like_shape(oracle):
+    """1241 x 376 (KITTI gray): widths that are not multiples of the tile sizes."""
+    from visual_odometry_amd import synth
+    from visual_odometry_amd.frontend import FrontEnd
+    seq = synth.sequence(3, 1241, 376, cache_dir="/tmp")
+    fe = FrontEnd(376, 1241, max_frames=3, max_pairs=2, nfeatures=2000)
+    fe.upload(seq["frames"]); fe.detect(0, 3)
+    res, X = fe.run_pairs([[0, 1], [1, 2]], seq["K"], want_points=True)
+    p = oracle.orb_params(nfeatures=2000)
+    for i in range(2):
+        _check_pair(res[i], X[i], oracle.pair(seq["frames"][i], seq["frames"][i + 1], p, seq["K"]))

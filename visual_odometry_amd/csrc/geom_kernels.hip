@@ -19,6 +19,16 @@
 #define VO_DK_ITERS 300
 #endif
 
+// hypot from IEEE operations only (same expression as the CPU oracle, so the rotations agree bit for bit)
+__device__ __forceinline__ double vo_hypot(double a, double b)
+{
+    a = fabs(a); b = fabs(b);
+    if (a < b) { double t = a; a = b; b = t; }
+    if (a == 0) return 0;
+    double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
 // ------------------------------------------------------------------ one-sided Jacobi SVD
 // At: N rows of length M (row i = column i of the M x N matrix). Returns At rows = sigma_i u_i,
 // W descending, Vt rows = right singular vectors (Hestenes rotations, as OpenCV's JacobiSVDImpl_).
@@ -46,7 +56,7 @@ __device__ __forceinline__ void jacobi_svd(double* At, double* W, double* Vt)
                 for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
                 if (fabs(p) > eps * sqrt(a * b)) {
                     p *= 2;
-                    double beta = a - b, gamma = hypot(p, beta), c, s;
+                    double beta = a - b, gamma = vo_hypot(p, beta), c, s;
                     if (beta < 0) {
                         double delta = (gamma - beta) * 0.5;
                         s = sqrt(delta / gamma);

@@ -351,6 +351,37 @@ extern "C" int vo_frames_upload(vo_ctx* ctx, const uint8_t* frames, int F, int r
     return VO_OK;
 }
 
+extern "C" int vo_frames_upload_color(vo_ctx* ctx, const uint8_t* frames, int F, int channels, int row_stride,
+                                      int64_t frame_stride, int first_slot)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (channels == 1) return vo_frames_upload(ctx, frames, F, row_stride, frame_stride, first_slot);
+    if (channels != 3 && channels != 4) FAIL(VO_ERR_INVALID, "channels must be 1, 3 or 4");
+    if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (row_stride < ctx->w * channels || frame_stride < (int64_t)row_stride * ctx->h) FAIL(VO_ERR_INVALID, "strides too small");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t per = (size_t)frame_stride;
+    // stage in chunks of at most 64 frames
+    const int chunk = F < 64 ? F : 64;
+    if (per * chunk > ctx->staging_bytes) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->staging) (void)hipFree(ctx->staging);
+        ctx->staging = nullptr; ctx->staging_bytes = 0;
+        HIPCHK(hipMalloc((void**)&ctx->staging, per * chunk));
+        ctx->staging_bytes = per * chunk;
+    }
+    for (int f0 = 0; f0 < F; f0 += chunk) {
+        const int n = F - f0 < chunk ? F - f0 : chunk;
+        HIPCHK(hipMemcpyAsync(ctx->staging, frames + (size_t)f0 * per, per * n, hipMemcpyHostToDevice, ctx->stream));
+        StageTimer t(ctx, ST_GRAY);
+        launch_gray(ctx->stream, ctx->staging, channels, row_stride, frame_stride,
+                    ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes, ctx->g, n);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}
+
 // stages up to `upto` (0 = pyramid only, 1 = + FAST score map, 2 = everything)
 static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
 {

@@ -28,13 +28,18 @@ class FrontEnd:
         self._X = None                                                                # reused by every run_pairs call
 
     def upload(self, frames, first_slot=0):
+        """frames: [F, H, W] gray or [F, H, W, 3|4] BGR(A) uint8 (BGR is converted on the device, as ORB does)."""
         f = np.ascontiguousarray(frames, dtype=np.uint8)
-        if f.ndim == 2:
+        if f.ndim == 2 or (f.ndim == 3 and f.shape[-1] in (3, 4) and f.shape[:2] == (self.h, self.w)):
             f = f[None]
-        if f.ndim != 3 or f.shape[1:] != (self.h, self.w):
-            raise ValueError(f"frames must be [F, {self.h}, {self.w}] uint8 (gray)")
+        if f.ndim not in (3, 4) or f.shape[1:3] != (self.h, self.w):
+            raise ValueError(f"frames must be [F, {self.h}, {self.w}] or [F, {self.h}, {self.w}, 3|4] uint8")
         c = self.ctx
-        c.check(c.lib.vo_frames_upload(c.handle, f.ctypes.data, f.shape[0], f.strides[1], f.strides[0], int(first_slot)))
+        if f.ndim == 3:
+            c.check(c.lib.vo_frames_upload(c.handle, f.ctypes.data, f.shape[0], f.strides[1], f.strides[0], int(first_slot)))
+        else:
+            c.check(c.lib.vo_frames_upload_color(c.handle, f.ctypes.data, f.shape[0], f.shape[3], f.strides[1], f.strides[0],
+                                                 int(first_slot)))
 
     def detect(self, first_slot, count, wait=True):
         """ORB detect + describe of `count` resident slots. wait=False only enqueues the work on the ctx stream;
