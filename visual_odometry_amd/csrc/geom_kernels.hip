@@ -260,7 +260,8 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
 // (consecutive lanes hold consecutive doubles: conflict-free ds_read/write_b64).
 #define FP_LANES 64
 #define CM(r, k) cm[((r) * 20 + (k)) * FP_LANES]
-__device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout, double* cm)
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout, lds_double* cm)
 {
     double basis[36];
     {
@@ -551,7 +552,7 @@ struct RansacShared {
     int used;
 };
 
-__global__ __launch_bounds__(256) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp, const uint32_t* rng_tab, int rng_n)
+__global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp, const uint32_t* rng_tab, int rng_n)
 {
     __shared__ RansacShared sh;
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256) void k_ransac(PairBuf pb, int kp_cap, RansacPa
     if (M == 5) {       // ptsetreg.cpp: count == modelPoints -> all solutions, every point an inlier
         if (tid == 0) {
             double* models = pb.models + (size_t)p * 64 * 90;
-            int nm = five_point_solve(x1, x2, models, sh.cm);
+            int nm = five_point_solve(x1, x2, models, (lds_double*)sh.cm);
             for (int k = 0; k < 9; k++) res->E[k] = nm > 0 ? models[k] : 0.0;
             res->status = nm > 0 ? VO_OK : VO_ERR_NO_MODEL;
             res->n_inl = nm > 0 ? 5 : 0;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256) void k_ransac(PairBuf pb, int kp_cap, RansacPa
                     s1[2 * i] = x1[2 * v]; s1[2 * i + 1] = x1[2 * v + 1];
                     s2[2 * i] = x2[2 * v]; s2[2 * i + 1] = x2[2 * v + 1];
                 }
-                nm = five_point_solve(s1, s2, sh.models + lane * 90, sh.cm + lane);
+                nm = five_point_solve(s1, s2, sh.models + lane * 90, (lds_double*)sh.cm + lane);
             }
             sh.nm[lane] = nm;
             // exclusive prefix of the model counts + flattened (sample, model) list
@@ -957,7 +958,7 @@ void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
 __global__ __launch_bounds__(64) void k_five_point_raw(const double* x1, const double* x2, double* E, int* nm)
 {
     __shared__ double s_cm[200 * FP_LANES];
-    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E, s_cm);
+    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E, (lds_double*)s_cm);
 }
 
 void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm)
