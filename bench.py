@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearse the multi-process path on a box with fewer GPUs than ranks (all ranks share GPU 0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,11 +109,17 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     dist = torch = None
+    device = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            device = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    on_gpu = world > 1 and args.dist_backend == "nccl"
 
     from visual_odometry_amd import synth
     from visual_odometry_amd.frontend import FrontEnd, MATCH_CROSSCHECK, MATCH_RATIO, chain_poses
@@ -125,7 +133,7 @@ def main():
     match_mode = MATCH_CROSSCHECK if args.matcher == "crosscheck" else MATCH_RATIO
 
     fe = FrontEnd(args.height, args.width, max_frames=C + 1, max_pairs=C, nfeatures=args.nfeatures,
-                  nlevels=args.nlevels, device=local_rank)
+                  nlevels=args.nlevels, device=device)
     fe.upload(frames)                                     # inputs resident in HBM before the timed region
     opts = fe.make_opts(match_mode=match_mode, ratio=args.ratio, want_points=True)
 
@@ -139,8 +147,8 @@ def main():
         if world > 1:                                     # trajectory gather over RCCL / xGMI: 128 B per pair
             rec[:, :9] = res["R"]; rec[:, 9:12] = res["t"]
             rec[:, 12] = res["n_kp1"]; rec[:, 13] = res["n_match"]; rec[:, 14] = res["n_inl"]; rec[:, 15] = res["n_good"]
-            mine = torch.from_numpy(rec).cuda()
-            out = torch.empty((world * C, 16), dtype=torch.float64, device="cuda")
+            mine = torch.from_numpy(rec).cuda() if on_gpu else torch.from_numpy(rec)
+            out = torch.empty((world * C, 16), dtype=torch.float64, device=mine.device)
             dist.all_gather_into_tensor(out, mine)
             gathered = out
         return res
@@ -148,7 +156,8 @@ def main():
     def sync():
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         res = step()
@@ -161,7 +170,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     prof = {} if args.no_profile else fe.profile_read()

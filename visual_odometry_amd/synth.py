@@ -147,13 +147,18 @@ def sequence(n_frames: int, w: int, h: int, step: float = 1.0, yaw_deg: float = 
     tag = hashlib.sha1(f"{n_frames}-{w}-{h}-{step}-{yaw_deg}-{seed}-v1".encode()).hexdigest()[:16]
     path = os.path.join(cache_dir, f"vo_synth_{tag}.npy") if cache_dir else None
     if path and os.path.exists(path):
-        frames = np.load(path)
-        if frames.shape == (n_frames, h, w):
-            return dict(frames=frames, K=k, R=rs, C=cs)
+        try:
+            frames = np.load(path)
+            if frames.shape == (n_frames, h, w):
+                return dict(frames=frames, K=k, R=rs, C=cs)
+        except (OSError, ValueError):
+            pass
     frames = np.stack([render_frame(w, h, k, rs[i], cs[i], seed, i) for i in range(n_frames)])
     if path:
-        try:
-            np.save(path, frames)
+        try:                                   # atomic publish: several ranks may render the same sequence at once
+            tmp = f"{path}.{os.getpid()}.tmp.npy"
+            np.save(tmp, frames)
+            os.replace(tmp, path)
         except OSError:
             pass
     return dict(frames=frames, K=k, R=rs, C=cs)
