@@ -144,3 +144,24 @@ def test_kitti_like_shape(oracle):
     p = oracle.orb_params(nfeatures=2000)
     for i in range(2):
         _check_pair(res[i], X[i], oracle.pair(seq["frames"][i], seq["frames"][i + 1], p, seq["K"]))
+
+
+def test_two_image_driver_and_image_and_keypoints(oracle, seq_small, tmp_path):
+    """ImageAndKeypoints + TriangulatePointsFromTwoImages (the reference's main_triangulate.py flow), from files."""
+    from PIL import Image
+    from visual_odometry_amd import ImageAndKeypoints, TriangulatePointsFromTwoImages
+    frames, K = seq_small["frames"], seq_small["K"]
+    names = []
+    for i in range(2):
+        names.append(str(tmp_path / f"f{i}.png"))
+        Image.fromarray(np.stack([frames[i]] * 3, axis=2)).save(names[-1])
+    iak = ImageAndKeypoints("ORB")
+    iak.set_image(np.stack([frames[0]] * 3, axis=2))
+    iak.detect_keypoints()
+    assert len(iak.keypoints) == len(iak.kp_colors) == len(iak.descriptors) > 100
+    assert iak.kp_colors[0].shape == (3,)
+    pair = TriangulatePointsFromTwoImages(camera_matrix=K).run(names[0], names[1])
+    ref = oracle.pair(frames[0], frames[1], oracle.orb_params(nfeatures=500), K)       # gray of an r=g=b image is itself
+    assert len(pair.raw_matches) == ref["n_match"]
+    assert np.linalg.norm(np.hstack([pair.R, pair.t]) - np.hstack([ref["R"], ref["t"]])) < 1e-4
+    assert pair.points3d_reconstr.shape == (4, ref["n_inl"])

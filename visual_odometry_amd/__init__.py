@@ -12,7 +12,8 @@ from .frame import Frame  # noqa: F401
 from .frame_generator import FrameGenerator  # noqa: F401
 
 __all__ = ["KeyPoint", "DMatch", "Feature", "Match", "Match3D", "MatchWithMap", "Frame", "FrameGenerator",
-           "OrbDetector", "ORB_create", "HammingMatcher", "BFMatcher", "ImagePair", "FrontEnd"]
+           "OrbDetector", "ORB_create", "HammingMatcher", "BFMatcher", "NORM_HAMMING", "ImagePair", "ImageAndKeypoints",
+           "TriangulatePointsFromTwoImages", "FrontEnd"]
 
 
 def __getattr__(name):
@@ -26,6 +27,12 @@ def __getattr__(name):
     if name == "ImagePair":
         from .image_pair import ImagePair
         return ImagePair
+    if name == "ImageAndKeypoints":
+        from .image_and_keypoints import ImageAndKeypoints
+        return ImageAndKeypoints
+    if name == "TriangulatePointsFromTwoImages":
+        from .triangulate_points_from_images import TriangulatePointsFromTwoImages
+        return TriangulatePointsFromTwoImages
     if name == "FrontEnd":
         from .frontend import FrontEnd
         return FrontEnd
