@@ -69,22 +69,6 @@ __device__ __forceinline__ void nn_body(const uint8_t* A, int na, const uint8_t*
     }
 }
 
-template <bool KNN2>
-__global__ __launch_bounds__(256) void k_nn_raw(const uint8_t* A, int na, const uint8_t* B, int nb,
-                                                int* idx, int* dist, int* idx2, int* dist2)
-{
-    nn_body<KNN2>(A, na, B, nb, idx, dist, idx2, dist2);
-}
-
-void launch_nn_raw(hipStream_t s, const uint8_t* a, int na, const uint8_t* b, int nb, int* idx, int* dist,
-                   int* idx2, int* dist2, int knn2)
-{
-    if (na <= 0) return;
-    dim3 grid((na + NN_ROWS_PER_BLOCK - 1) / NN_ROWS_PER_BLOCK), block(256);
-    if (knn2) hipLaunchKernelGGL(k_nn_raw<true>, grid, block, 0, s, a, na, b, nb, idx, dist, idx2, dist2);
-    else hipLaunchKernelGGL(k_nn_raw<false>, grid, block, 0, s, a, na, b, nb, idx, dist, idx2, dist2);
-}
-
 // batched: grid.y = pair, grid.z = direction slot (dir 0: frame1 rows vs frame2, dir 1: frame2 rows vs frame1)
 template <bool KNN2>
 __global__ __launch_bounds__(256) void k_nn_pairs(const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb,

@@ -186,7 +186,7 @@ static void build_lin_tab(int ssize, int dsize, int* ofs, uint16_t* c1, int* pmi
 static void free_pairbuf(PairBuf& pb)
 {
     void* ptrs[] = {pb.slots, pb.nn_idx, pb.nn_dist, pb.nn_idx2, pb.nn_dist2, pb.m_q, pb.m_t, pb.m_d, pb.m_count,
-                    pb.px1, pb.px2, pb.xn1, pb.xn2, pb.mask, pb.models, pb.nmodels, pb.in1, pb.in2, pb.ipx1, pb.ipx2,
+                    pb.px1, pb.px2, pb.xn1, pb.xn2, pb.mask, pb.models, pb.in1, pb.in2, pb.ipx1, pb.ipx2,
                     pb.res, pb.X, pb.pose_mask};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     memset(&pb, 0, sizeof(pb));
@@ -200,7 +200,7 @@ static hipError_t alloc_pairbuf(PairBuf& pb, int P, int cap, bool with_pose_mask
     A_(slots, (size_t)P * 2); A_(nn_idx, pc * 2); A_(nn_dist, pc * 2); A_(nn_idx2, pc); A_(nn_dist2, pc);
     A_(m_q, pc); A_(m_t, pc); A_(m_d, pc); A_(m_count, (size_t)P);
     A_(px1, pc * 2); A_(px2, pc * 2); A_(xn1, pc * 2); A_(xn2, pc * 2);
-    A_(mask, pc); A_(models, (size_t)P * 64 * 90); A_(nmodels, (size_t)P * 64);
+    A_(mask, pc); A_(models, (size_t)P * 64 * 90);
     A_(in1, pc * 2); A_(in2, pc * 2); A_(ipx1, pc * 2); A_(ipx2, pc * 2);
     A_(res, (size_t)P); A_(X, pc * 4);
     if (with_pose_mask) { A_(pose_mask, pc); }

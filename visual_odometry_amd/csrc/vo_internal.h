@@ -4,8 +4,6 @@
 #include <stdint.h>
 #include "../../include/vo_hip.h"
 
-#define VO_HALF_PATCH 15
-
 // ---- stage ids for vo_profile_* (index into ctx->prof) -------------------------------------
 enum {
     ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_SELECT_FAST, ST_HARRIS, ST_SELECT_HARRIS, ST_ANGLE,
@@ -80,7 +78,6 @@ struct PairBuf {
     double*   xn2;
     uint8_t*  mask;       // [P][kp_cap] E-RANSAC inlier mask
     double*   models;     // [P][64][90] workspace: five-point models of one RANSAC round
-    int*      nmodels;    // [P][64]
     double*   in1;        // [P][kp_cap][2] normalised inliers
     double*   in2;
     double*   ipx1;       // [P][kp_cap][2] pixel inliers
@@ -114,9 +111,6 @@ void launch_match_nn(hipStream_t s, const uint8_t* desc, const int* kp_count, in
                      int dirs_mask, int knn2);
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
                          int mode, double ratio, const double* K);
-// raw descriptor sets (single-call API): nearest neighbours of a in b
-void launch_nn_raw(hipStream_t s, const uint8_t* a, int na, const uint8_t* b, int nb, int* idx, int* dist,
-                   int* idx2, int* dist2, int knn2);
 
 void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp, const uint32_t* rng_tab, int rng_n);
 void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
