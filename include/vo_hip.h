@@ -148,6 +148,12 @@ int vo_frame_features(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float
  * doubles, w normalised to 1; the first n_inl columns of each are valid. */
 int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
                  vo_pair_result* results, double* X, int32_t x_cap);
+/* enqueue-only form: results / X must be page-locked (vo_host_alloc), X needs x_cap == vo_batch_kp_capacity();
+ * they are valid after vo_sync(ctx).  Two contexts on one GPU can overlap one's detection with the other's
+ * latency-bound RANSAC / pose kernels. */
+int vo_pairs_run_async(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
+                       vo_pair_result* results, double* X, int32_t x_cap);
+int vo_sync(vo_ctx* ctx);
 /* per-pair match list of the last vo_pairs_run (capacity cap each) */
 int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* dist, uint8_t* inlier_mask,
                     int cap, int32_t* n_out);

@@ -60,6 +60,8 @@ _SIGS = {
     "vo_host_free": (None, [_P]),
     "vo_frame_features": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "vo_pairs_run": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
+    "vo_pairs_run_async": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
+    "vo_sync": (C.c_int, [_P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_profile_enable": (C.c_int, [_P, C.c_int]),
     "vo_profile_reset": (C.c_int, [_P]),

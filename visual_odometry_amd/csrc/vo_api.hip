@@ -620,16 +620,16 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const float* 
     return VO_OK;
 }
 
-extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
-                            vo_pair_result* results, double* X, int32_t x_cap)
+static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
+                         vo_pair_result* results, double* X, int32_t x_cap, bool* whole_x_out)
 {
-    if (!ctx) return VO_ERR_INVALID;
     if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (!pair_slots || !K || !opts || !results || B < 0 || B > ctx->max_pairs) FAIL(VO_ERR_INVALID, "bad pair batch arguments");
     if (opts->match_mode != 0 && opts->match_mode != 1) FAIL(VO_ERR_INVALID, "match_mode must be 0 or 1");
     if (!(opts->ransac_prob > 0 && opts->ransac_prob < 1)) FAIL(VO_ERR_INVALID, "ransac_prob must be in (0, 1)");
     for (int i = 0; i < 2 * B; i++)
         if (pair_slots[i] < 0 || pair_slots[i] >= ctx->max_frames) FAIL(VO_ERR_INVALID, "pair slot %d out of range", pair_slots[i]);
+    *whole_x_out = false;
     if (B == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -649,10 +649,22 @@ extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const
     const bool whole_x = X && wp && x_cap == cap;       // caller's layout equals the device layout: one copy
     if (X && wp && x_cap < 1) FAIL(VO_ERR_INVALID, "x_cap must be positive");
     if (whole_x) HIPCHK(hipMemcpyAsync(X, ctx->pb.X, (size_t)B * 4 * cap * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (ctx->prof) prof_collect(ctx);
+    *whole_x_out = whole_x;
     ctx->last_pairs = B;
-    if (X && wp && !whole_x) {
+    return VO_OK;
+}
+
+extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
+                            vo_pair_result* results, double* X, int32_t x_cap)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    bool whole_x = false;
+    int rc = pairs_enqueue(ctx, pair_slots, B, K, opts, results, X, x_cap, &whole_x);
+    if (rc || B == 0) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_collect(ctx);
+    const int cap = ctx->g.kp_cap;
+    if (X && opts->want_points && !whole_x) {
         for (int p = 0; p < B; p++) {
             const int n = results[p].status == VO_OK ? (results[p].n_inl < x_cap ? results[p].n_inl : x_cap) : 0;
             if (n <= 0) continue;
@@ -661,6 +673,28 @@ extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const
                                (size_t)n * sizeof(double), 4, hipMemcpyDeviceToHost));
         }
     }
+    return VO_OK;
+}
+
+// Enqueue only: results (and X, which must use x_cap == vo_batch_kp_capacity) have to be page-locked
+// (vo_host_alloc) and are valid after the next vo_sync(ctx).  Lets a second ctx's detection overlap this
+// ctx's latency-bound RANSAC / pose kernels on the same GPU.
+extern "C" int vo_pairs_run_async(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
+                                  vo_pair_result* results, double* X, int32_t x_cap)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (X && opts && opts->want_points && ctx->configured && x_cap != ctx->g.kp_cap)
+        FAIL(VO_ERR_INVALID, "vo_pairs_run_async needs x_cap == vo_batch_kp_capacity()");
+    bool whole_x = false;
+    return pairs_enqueue(ctx, pair_slots, B, K, opts, results, X, x_cap, &whole_x);
+}
+
+extern "C" int vo_sync(vo_ctx* ctx)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_collect(ctx);
     return VO_OK;
 }
 

@@ -65,8 +65,10 @@ class FrontEnd:
         return _lib.PairOpts(int(match_mode), float(ratio), float(prob), float(thresh), int(max_iters), int(seed),
                              float(dist_thresh), int(bool(want_points)))
 
-    def run_pairs(self, pair_slots, K, opts=None, want_points=False):
-        """pair_slots: [B, 2] int32 of detected slots. Returns (results structured array [B], X or None)."""
+    def run_pairs(self, pair_slots, K, opts=None, want_points=False, wait=True):
+        """pair_slots: [B, 2] int32 of detected slots. Returns (results structured array [B], X or None) — views of
+        reused page-locked buffers (copy them if they must outlive the next call).  wait=False only enqueues the
+        work; the returned views are valid after self.wait()."""
         ps = np.ascontiguousarray(pair_slots, dtype=np.int32).reshape(-1, 2)
         B = len(ps)
         K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
@@ -80,9 +82,14 @@ class FrontEnd:
                 self._X = _lib.PinnedArray((self.max_pairs, 4, self.kp_cap), np.float64)
             X = self._X.array[:B]
         c = self.ctx
-        c.check(c.lib.vo_pairs_run(c.handle, ps.ctypes.data, B, K.ctypes.data, C.addressof(opts), res.ctypes.data,
-                                   _lib.ptr(X), self.kp_cap))
-        return res, X      # views of reused page-locked buffers: copy them if they must outlive the next call
+        fn = c.lib.vo_pairs_run if wait else c.lib.vo_pairs_run_async
+        self._keep = (ps, K, opts)                  # keep the argument buffers alive until the work has been consumed
+        c.check(fn(c.handle, ps.ctypes.data, B, K.ctypes.data, C.addressof(opts), res.ctypes.data, _lib.ptr(X), self.kp_cap))
+        return res, X
+
+    def wait(self):
+        c = self.ctx
+        c.check(c.lib.vo_sync(c.handle))
 
     def pair_matches(self, pair):
         cap = self.kp_cap
