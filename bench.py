@@ -57,6 +57,18 @@ def pmc_traffic(stage, nframes):
         return None
 
 
+VALU_PEAK_TLANEOPS = 35.0   # measured on MI355X by tools/ubench/valu_rates.hip (profiles/r01_valu_issue_rates.txt)
+
+
+def pmc_valu(stage):
+    """VALU lane-operations per launch of `stage` (SQ_INSTS_VALU x 64) from the committed PMC pass, or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return float(sum(t[k]["valu_wave_insts_per_launch"] * n for k, n in STAGE_KERNELS[stage])) * 64.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(frames, K, nfeatures, nlevels, match_mode, ratio, budget_s=12.0):
     """The CPU oracle ("port") on the host cores over a bounded sample of the same pairs."""
     from concurrent.futures import ThreadPoolExecutor
@@ -254,6 +266,13 @@ def main():
                 if k in prof:
                     bb = fe.stage_bytes(k, nframes)
                     hbm_stages[k] = round(bb / (prof[k][0] / prof[k][1] * 1e-3) / 1e9, 1)
+            lane_ops = pmc_valu(dom) if pmc_traffic(dom, nframes) is not None else None
+            if lane_ops:
+                rate = lane_ops / (ms / n * 1e-3) / 1e12
+                line["roofline"]["valu"] = {"lane_ops_per_launch": lane_ops, "achieved_Tlaneops": round(rate, 2),
+                                            "peak_Tlaneops_measured": VALU_PEAK_TLANEOPS,
+                                            "frac": round(rate / VALU_PEAK_TLANEOPS, 3),
+                                            "note": "integer wave64 VALU issue rate measured by tools/ubench/valu_rates.hip"}
             line["stages"] = stages
             line["streaming_kernels_GBps"] = hbm_stages
         if not args.no_cpu_baseline and world == 1:

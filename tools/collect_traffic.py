@@ -8,7 +8,7 @@ read, so it is doubled.  Calibration on this code base: k_sel_scan<false> stream
 31-px border with aligned 16-byte loads (about 0.82 x the pyramid bytes); its raw FETCH_SIZE is 0.545 of that
 byte count, i.e. the factor 2 applies to our access pattern.
 
-usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> [frames_per_launch]
+usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> [frames_per_launch] [valu_dir]
 """
 import collections
 import csv
@@ -28,11 +28,16 @@ def load(d, counter):
 
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    valu = load(sys.argv[5], "SQ_INSTS_VALU") if len(sys.argv) > 5 else {}
+    salu = load(sys.argv[5], "SQ_INSTS_SALU") if len(sys.argv) > 5 else {}
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         out[k] = {"fetch_size_kib_raw": round(f, 1), "write_size_kib_raw": round(w, 1),
                   "hbm_bytes_per_launch": round((2.0 * f + w) * 1024.0)}
+        if k in valu:
+            out[k]["valu_wave_insts_per_launch"] = round(valu[k])
+            out[k]["salu_wave_insts_per_launch"] = round(salu.get(k, 0.0))
     out["_meta"] = {"frames_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 257,
                     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)

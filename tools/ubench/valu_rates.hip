@@ -19,7 +19,7 @@ __global__ void k(uint32_t* out, uint32_t seed, long long* cyc)
     for (int it = 0; it < N_ITERS; it++) {
 #pragma unroll
         for (int i = 0; i < UNROLL; i++) {
-            if (OP == 0) r[i] = r[i] ^ a;                                        // v_xor_b32
+            if (OP == 0) r[i] = r[i] ^ r[(i + 5) & 15];                          // v_xor_b32 (register operands)
             if (OP == 1) r[i] = __popc(r[i]) + b;                                // v_bcnt_u32_b32 (accumulate form)
             if (OP == 2) r[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, r[i]) - __builtin_bit_cast(s16x2, a));  // v_pk_sub_i16
             if (OP == 3) r[i] = __builtin_amdgcn_perm(r[i], a, 0x0c050c03u);     // v_perm_b32
@@ -28,7 +28,13 @@ __global__ void k(uint32_t* out, uint32_t seed, long long* cyc)
             if (OP == 6) r[i] = min(r[i], a) + 1;                                // v_min_u32 + v_add (2 instrs)
             if (OP == 7) r[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, r[i]), __builtin_bit_cast(s16x2, a)));  // v_pk_min_i16
             if (OP == 8) r[i] = r[i] * 18u + b;                                  // v_mad_u32_u24 / mul_lo
-            if (OP == 9) r[i] = (r[i] >> 8) & 0x00ff00ffu;                       // shift + and (2 instrs, or 1 bfe/and_or)
+            if (OP == 9) r[i] = (r[i] >> 3) + r[(i + 3) & 15];                   // v_lshrrev + v_add (or v_lshl_add)
+            if (OP == 10) r[i] = (r[i] & a) | r[(i + 7) & 15];                   // v_and_or_b32 (1 instr)
+            if (OP == 11) r[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, r[i]), __builtin_bit_cast(s16x2, r[(i + 1) & 15])));  // v_pk_max_i16
+            if (OP == 12) { typedef unsigned short u16x2 __attribute__((ext_vector_type(2))); r[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, r[i]) >> (unsigned short)3) + 1u; }  // v_pk_lshrrev_b16 + add
+            if (OP == 13) r[i] = r[i] > a ? r[(i + 1) & 15] : b;                  // v_cmp + v_cndmask
+            if (OP == 14) r[i] = __builtin_amdgcn_sad_u8(r[i], a, b);            // v_sad_u8
+            if (OP == 15) r[i] = __builtin_amdgcn_ubfe(r[i], 8, 8) + b;          // v_bfe_u32 + add
         }
     }
     long long t1 = clock64();
@@ -44,7 +50,7 @@ void run(const char* name, int instrs_per_op)
 {
     uint32_t* out; long long* cyc;
     hipMalloc(&out, 256 * 2048 * 4 * sizeof(uint32_t)); hipMalloc(&cyc, 8);
-    for (int waves_per_simd : {1, 4, 8}) {
+    for (int waves_per_simd : {1, 8}) {
         // 256 CUs x 4 SIMDs: blocks of 256 threads (1 wave per SIMD each); `waves_per_simd` blocks per CU
         int blocks = 256 * waves_per_simd;
         hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 12345u, cyc);
@@ -65,6 +71,8 @@ int main()
 {
     run<0>("v_xor_b32", 1); run<1>("v_bcnt_u32_b32 (+acc)", 1); run<2>("v_pk_sub_i16", 1); run<3>("v_perm_b32", 1);
     run<4>("v_dot4_u32_u8", 1); run<5>("v_alignbyte_b32", 1); run<6>("v_min_u32 + v_add", 2); run<7>("v_pk_min_i16", 1);
-    run<8>("v_mad_u32_u24 / mul+add", 1); run<9>("lshr + and", 2);
+    run<8>("v_mad_u32_u24 / mul+add", 1); run<9>("v_lshrrev + v_add", 2); run<10>("v_and_or_b32", 1);
+    run<11>("v_pk_max_i16", 1); run<12>("v_pk_lshrrev_b16 + v_add", 2); run<13>("v_cmp + v_cndmask", 2);
+    run<14>("v_sad_u8", 1); run<15>("v_bfe_u32 + v_add", 2);
     return 0;
 }

@@ -18,6 +18,16 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // sepFilter2D integer taps of GaussianBlur(7x7, sigma 2): cvRound(256 * g)
 __constant__ int c_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
 
+// ------------------------------------------------------------------ XCD-aware tile order
+// Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2).  Neighbouring
+// image tiles share halo rows/columns and 128-byte lines, so tile indices are remapped to give every XCD one
+// contiguous run of tiles (bijective for any n; placement is a speed matter only, never correctness).
+__device__ __forceinline__ int xcd_tile(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 // ------------------------------------------------------------------ block-wide exclusive scan (<= 1024 threads)
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
@@ -134,7 +144,9 @@ __global__ __launch_bounds__(256) void k_resize_tiled(uint8_t* pyr, int frame_by
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_LH * RS_LW];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[RS_LH * RS_TW];
     const int f = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * RS_TW, y0 = blockIdx.y * RS_TH;
+    const int tiles_x = (dst.w + RS_TW - 1) / RS_TW;
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int x0 = (bid % tiles_x) * RS_TW, y0 = (bid / tiles_x) * RS_TH;
     const int x_last = min(x0 + RS_TW, dst.w) - 1, y_last = min(y0 + RS_TH, dst.h) - 1;
     const int sx0 = tab.xofs[x0] & ~15, sy0 = tab.yofs[y0];
     const int nrows = min(tab.yofs[y_last] + 2 - sy0, RS_LH);
@@ -188,7 +200,7 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 {
     const LevelGeom& d = g.lv[level];
     if (tab.tiled) {
-        dim3 grid((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, F);
+        dim3 grid(((d.w + RS_TW - 1) / RS_TW) * ((d.h + RS_TH - 1) / RS_TH), 1, F);
         hipLaunchKernelGGL(k_resize_tiled, grid, dim3(256), 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
         return;
     }
@@ -279,10 +291,11 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
     __shared__ uint16_t s_q[FT_QCAP + 1];            // + one spare slot for the branch-free push
     const int f = blockIdx.y, lane = threadIdx.x;
+    const int bid = xcd_tile(blockIdx.x, g.ftiles_total);
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].ftile_base) l++;
+    while (l + 1 < g.nlevels && bid >= g.lv[l + 1].ftile_base) l++;
     const LevelGeom lv = g.lv[l];
-    const int tile = blockIdx.x - lv.ftile_base;
+    const int tile = bid - lv.ftile_base;
     const int x0 = (tile % lv.ftiles_x) * FAST_TW, y0 = (tile / lv.ftiles_x) * FAST_TH;
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     const int t = g.fast_thr;
@@ -817,10 +830,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
     __shared__ __attribute__((aligned(16))) uint8_t s_in[BL_INH * BL_INW];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[BL_INH * BLUR_TW];
     const int f = blockIdx.y, tid = threadIdx.x;
+    const int bid = xcd_tile(blockIdx.x, g.btiles_total);
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].btile_base) l++;
+    while (l + 1 < g.nlevels && bid >= g.lv[l + 1].btile_base) l++;
     const LevelGeom lv = g.lv[l];
-    const int tile = blockIdx.x - lv.btile_base;
+    const int tile = bid - lv.btile_base;
     const int x0 = (tile % lv.btiles_x) * BLUR_TW, y0 = (tile / lv.btiles_x) * BLUR_TH;
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     if (lv.w >= 16 && lv.h >= 4) {
