@@ -31,13 +31,16 @@ __device__ __forceinline__ void nn_body(const uint8_t* A, int na, const uint8_t*
     __shared__ uint4 s_b[NN_TILE * 2];
     const int tid = threadIdx.x;
     Desc me[NN_Q];
-    int row[NN_Q], d0[NN_Q], i0[NN_Q], d1[NN_Q], i1[NN_Q];
+    int row[NN_Q];
+    // best / second best as one key (distance << 16 | train row): an unsigned min is the ascending scan with
+    // strict `<` (lowest row wins ties); rows < 65536 is guaranteed by the keypoint capacity check
+    uint32_t k0[NN_Q], k1[NN_Q];
 #pragma unroll
     for (int q = 0; q < NN_Q; q++) {
         row[q] = blockIdx.x * NN_ROWS_PER_BLOCK + q * 256 + tid;
         me[q].a = make_uint4(0, 0, 0, 0); me[q].b = me[q].a;
         if (row[q] < na) { me[q].a = *(const uint4*)(A + (size_t)row[q] * 32); me[q].b = *(const uint4*)(A + (size_t)row[q] * 32 + 16); }
-        d0[q] = INT_MAX; i0[q] = -1; d1[q] = INT_MAX; i1[q] = -1;
+        k0[q] = 0xffffffffu; k1[q] = 0xffffffffu;
     }
     for (int base = 0; base < nb; base += NN_TILE) {
         const int j = base + tid;
@@ -50,26 +53,22 @@ __device__ __forceinline__ void nn_body(const uint8_t* A, int na, const uint8_t*
             const uint4 ba = s_b[2 * k], bb = s_b[2 * k + 1];
 #pragma unroll
             for (int q = 0; q < NN_Q; q++) {
-                const int d = hamming(me[q], ba, bb);
-                if (KNN2) {
-                    if (d < d1[q]) {
-                        if (d0[q] > d) { d1[q] = d0[q]; i1[q] = i0[q]; d0[q] = d; i0[q] = base + k; }
-                        else { d1[q] = d; i1[q] = base + k; }
-                    }
-                } else if (d < d0[q]) { d0[q] = d; i0[q] = base + k; }
+                const uint32_t key = ((uint32_t)hamming(me[q], ba, bb) << 16) | (uint32_t)(base + k);
+                if (KNN2) k1[q] = min(k1[q], max(k0[q], key));
+                k0[q] = min(k0[q], key);
             }
         }
     }
 #pragma unroll
     for (int q = 0; q < NN_Q; q++) {
         if (row[q] < na) {
-            idx[row[q]] = i0[q]; dist[row[q]] = d0[q];
-            if (KNN2) { idx2[row[q]] = i1[q]; dist2[row[q]] = d1[q]; }
+            const bool has0 = k0[q] != 0xffffffffu, has1 = k1[q] != 0xffffffffu;
+            idx[row[q]] = has0 ? (int)(k0[q] & 0xffffu) : -1; dist[row[q]] = has0 ? (int)(k0[q] >> 16) : INT_MAX;
+            if (KNN2) { idx2[row[q]] = has1 ? (int)(k1[q] & 0xffffu) : -1; dist2[row[q]] = has1 ? (int)(k1[q] >> 16) : INT_MAX; }
         }
     }
 }
 
-// batched: grid.y = pair, grid.z = direction slot (dir 0: frame1 rows vs frame2, dir 1: frame2 rows vs frame1)
 template <bool KNN2>
 __global__ __launch_bounds__(256) void k_nn_pairs(const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb,
                                                   int dir_first)

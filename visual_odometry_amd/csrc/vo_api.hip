@@ -108,7 +108,7 @@ static int check_params(vo_ctx* ctx, const vo_orb_params* p)
     if (p->edge_threshold < 19 || p->edge_threshold > 255) FAIL(VO_ERR_INVALID, "edgeThreshold must be in [19, 255]");
     if (p->fast_threshold < 1 || p->fast_threshold > 254) FAIL(VO_ERR_INVALID, "fastThreshold must be in [1, 254]");
     if (p->score_type != 0 && p->score_type != 1) FAIL(VO_ERR_INVALID, "scoreType must be 0 (HARRIS) or 1 (FAST)");
-    if (p->nfeatures < 0 || p->nfeatures > 100000) FAIL(VO_ERR_INVALID, "nfeatures out of range");
+    if (p->nfeatures < 0 || p->nfeatures > 50000) FAIL(VO_ERR_INVALID, "nfeatures out of range (0..50000)");
     if (!(p->scale_factor > 1.0f)) FAIL(VO_ERR_INVALID, "scaleFactor must be > 1");
     return VO_OK;
 }
@@ -745,6 +745,7 @@ static int match_raw(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, in
     if (!n_out || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t)) FAIL(VO_ERR_INVALID, "bad matcher arguments");
     *n_out = 0;
     if (nq == 0 || nt == 0) return VO_OK;
+    if (nq > 65535 || nt > 65535) FAIL(VO_ERR_INVALID, "at most 65535 descriptors per set");
     HIPCHK(hipSetDevice(ctx->device));
     int rc = ensure_raw(ctx, nq > nt ? nq : nt);
     if (rc) return rc;
