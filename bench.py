@@ -152,7 +152,9 @@ def main():
     for c in range(n_ctx):
         fe_c = FrontEnd(args.height, args.width, max_frames=C + 1, max_pairs=C, nfeatures=args.nfeatures,
                         nlevels=args.nlevels, device=device)
+        t_up = time.perf_counter()
         fe_c.upload(frames)                               # inputs resident in HBM before the timed region
+        upload_s = time.perf_counter() - t_up
         fes.append(fe_c)
     fe = fes[0]
     opts = fe.make_opts(match_mode=match_mode, ratio=args.ratio, want_points=True)
@@ -244,6 +246,8 @@ def main():
                        "contexts_per_gpu": n_ctx,
                        "matcher": args.matcher, "ransac": "5-point, conf 0.99, 1 px, seed 2^64-1, <=1000 iters",
                        "parallelism": f"pair-sharded x{world}, RCCL all_gather of 128 B/pair per step" if world > 1 else "single GPU",
+                       "pcie_inclusive_pairs_per_s_per_gpu": round(C / (dt / args.steps + upload_s), 1),
+                       "h2d_upload_ms_per_chunk": round(1000 * upload_s, 2),
                        "pairs_ok_last_step": ok,
                        "mean_inliers_last_step": round(float(res["n_inl"].mean()), 1)},
         }
