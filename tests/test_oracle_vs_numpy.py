@@ -1,0 +1,249 @@
+"""CPU: the C oracle against independent numpy restatements of the same published definitions.
+
+These do not pin the oracle to cv2 (parity stays unpinned, see oracle/voo.h); they catch slips of the C code by
+computing every stage a second, structurally different way (brute force / textbook formulas / numpy SVD)."""
+import os
+
+import numpy as np
+
+from conftest import random_image
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+        (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _pattern():
+    src = open(os.path.join(os.path.dirname(__file__), "..", "oracle", "orb_pattern.inc")).read()
+    body = src[src.index("*/") + 2:]
+    return np.array([int(v) for v in body.replace("\n", " ").split(",") if v.strip()], np.int32).reshape(256, 4)
+
+
+def test_gaussian_taps_from_the_formula(oracle):
+    """getGaussianKernel(7, 2): exp(-x^2 / 8) normalised, scaled by 256 and rounded -> the integer taps."""
+    g = np.exp(-np.arange(-3, 4) ** 2 / 8.0)
+    taps = np.rint(256 * g / g.sum()).astype(int)
+    assert taps.tolist() == [18, 34, 49, 55, 49, 34, 18]
+    img = random_image(1, 40, 52).astype(np.int64)
+    pad = np.pad(img, 3, mode="reflect")                       # numpy 'reflect' == BORDER_REFLECT_101
+    h = sum(taps[k] * pad[3:-3, k:k + 52] for k in range(7))
+    hp = np.pad(h, ((3, 3), (0, 0)), mode="reflect")
+    v = sum(taps[k] * hp[k:k + 40, :] for k in range(7))
+    ref = np.minimum((v + (1 << 15)) >> 16, 255).astype(np.uint8)
+    assert np.array_equal(oracle.gaussian_blur7(img.astype(np.uint8)), ref)
+
+
+def test_fast_score_brute_force(oracle):
+    """cornerScore = the largest threshold t' for which the pixel is still a FAST-9 corner (checked arc by arc)."""
+    img = random_image(2, 36, 44)
+    f = img.astype(int)
+
+    def is_corner(y, x, t):
+        v = f[y, x]
+        ring = [f[y + dy, x + dx] for dx, dy in RING]
+        for s in range(16):
+            arc = [ring[(s + j) % 16] for j in range(9)]
+            if all(p > v + t for p in arc) or all(p < v - t for p in arc):
+                return True
+        return False
+
+    raw = np.zeros_like(f)
+    for y in range(3, 33):
+        for x in range(3, 41):
+            if is_corner(y, x, 20):
+                t = 20
+                while t < 255 and is_corner(y, x, t + 1):
+                    t += 1
+                raw[y, x] = t
+    ref = np.zeros_like(f)
+    for y in range(3, 33):
+        for x in range(3, 41):
+            s = raw[y, x]
+            nb = raw[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = 0
+            if s and s > nb.max():
+                ref[y, x] = s
+    assert np.array_equal(oracle.fast_score_nms(img, 20).astype(int), ref) and ref.max() > 0
+
+
+def test_harris_angle_and_brief_by_the_textbook(oracle):
+    img = random_image(3, 200, 240)
+    p = oracle.orb_params(nfeatures=120, nlevels=1)
+    d = oracle.orb_detect_and_compute(img, p)
+    f = img.astype(np.int64)
+    blur = oracle.gaussian_blur7(img).astype(np.int64)
+    pat = _pattern()
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert len(d["xy"]) > 60
+    for i in range(0, len(d["xy"]), 3):
+        x, y = int(d["xy"][i, 0]), int(d["xy"][i, 1])
+        # Harris: 7x7 block of 3x3 Sobel sums, float32 formula in OpenCV's order
+        a = b = c = 0
+        for yy in range(y - 3, y + 4):
+            for xx in range(x - 3, x + 4):
+                w = f[yy - 1:yy + 2, xx - 1:xx + 2]
+                ix = int((w[:, 2] * [1, 2, 1]).sum() - (w[:, 0] * [1, 2, 1]).sum())
+                iy = int((w[2, :] * [1, 2, 1]).sum() - (w[0, :] * [1, 2, 1]).sum())
+                a += ix * ix; b += iy * iy; c += ix * iy
+        f32 = np.float32
+        scale = f32(1) / f32(4 * 7 * 255.0)
+        s4 = scale * scale * scale * scale
+        resp = (f32(a) * f32(b) - f32(c) * f32(c) - f32(0.04) * (f32(a) + f32(b)) * (f32(a) + f32(b))) * s4
+        assert resp == d["response"][i]
+        # intensity centroid over the radius-15 disc; fastAtan2 is within 0.3 degrees of atan2
+        m10 = m01 = 0
+        for v in range(-15, 16):
+            for u in range(-umax[abs(v)], umax[abs(v)] + 1):
+                m10 += u * f[y + v, x + u]; m01 += v * f[y + v, x + u]
+        ang = np.degrees(np.arctan2(float(m01), float(m10))) % 360
+        assert min(abs(ang - d["angle"][i]), 360 - abs(ang - d["angle"][i])) < 0.3
+        # steered BRIEF with the oracle's own angle, float32 rotation, round half to even
+        th = f32(d["angle"][i]) * f32(np.pi / 180.0)
+        ca, sa = f32(np.cos(np.float64(th))), f32(np.sin(np.float64(th)))
+        bits = []
+        for (x1, y1, x2, y2) in pat:
+            ax = int(np.rint(f32(x1) * ca - f32(y1) * sa)); ay = int(np.rint(f32(x1) * sa + f32(y1) * ca))
+            bx = int(np.rint(f32(x2) * ca - f32(y2) * sa)); by = int(np.rint(f32(x2) * sa + f32(y2) * ca))
+            bits.append(1 if blur[y + ay, x + ax] < blur[y + by, x + bx] else 0)
+        ref = np.packbits(np.array(bits, np.uint8), bitorder="little")
+        assert np.array_equal(ref, d["desc"][i])
+
+
+def test_retain_best_set_semantics(oracle):
+    """Per level the kept set is exactly {response >= quota-th largest} of the FAST-ranked candidates."""
+    img = random_image(4, 260, 300)
+    p = oracle.orb_params(nfeatures=80, nlevels=2)
+    lw, lh, ls, quota = oracle.level_geometry(260, 300, p)
+    d = oracle.orb_detect_and_compute(img, p)
+    lv = oracle.pyramid(img, p)
+    for l in range(2):
+        score = oracle.fast_score_nms(lv[l], 20)[31:lh[l] - 31, 31:lw[l] - 31].astype(int)
+        vals = np.sort(score[score > 0])[::-1]
+        n_fast = 2 * quota[l]
+        kept_fast = int((score >= vals[n_fast - 1]).sum()) if len(vals) > n_fast else len(vals)
+        got = d["response"][d["octave"] == l]
+        assert quota[l] <= len(got) <= kept_fast
+        assert len(np.unique(d["xy"][d["octave"] == l], axis=0)) == len(got)
+
+
+def test_matcher_against_numpy_popcount(oracle):
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 256, (70, 32), dtype=np.uint8); t = rng.integers(0, 256, (90, 32), dtype=np.uint8)
+    t[:20] = q[rng.permutation(70)[:20]]
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
+    qi, ti, d = oracle.match_hamming(q, t, 0)
+    assert np.array_equal(ti, D.argmin(axis=1)) and np.array_equal(d, D.min(axis=1))
+    # cv2 crossCheck: every train row votes for its nearest query; a query keeps the closest voter (lowest index)
+    best = {}
+    for j in range(90):
+        qq = int(D[:, j].argmin()); dd = int(D[qq, j])
+        if qq not in best or dd < best[qq][0]:
+            best[qq] = (dd, j)
+    qi, ti, d = oracle.match_hamming(q, t, 1)
+    assert qi.tolist() == sorted(best) and ti.tolist() == [best[k][1] for k in sorted(best)]
+    # ratio rule
+    order = np.argsort(D, axis=1, kind="stable")
+    keep = [i for i in range(70) if float(D[i, order[i, 0]]) < 0.8 * float(D[i, order[i, 1]])]
+    qi, ti, d = oracle.knn2_ratio_hamming(q, t, 0.8)
+    assert qi.tolist() == keep and np.array_equal(ti, order[keep, 0])
+
+
+def _rot(ax, ang):
+    ax = np.asarray(ax, float) / np.linalg.norm(ax)
+    k = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(ang) * k + (1 - np.cos(ang)) * k @ k
+
+
+def _scene(seed, n):
+    rng = np.random.default_rng(seed)
+    K = np.array([[800, 0, 320], [0, 800, 240], [0, 0, 1.0]])
+    R = _rot(rng.normal(size=3), 0.06); t = rng.normal(size=3); t /= np.linalg.norm(t)
+    X = rng.uniform(-4, 4, (n, 3)) + np.array([0, 0, 10])
+    p1 = ((X / X[:, 2:]) @ K.T)[:, :2] + rng.normal(0, 0.3, (n, 2))
+    X2 = X @ R.T + t
+    p2 = ((X2 / X2[:, 2:]) @ K.T)[:, :2] + rng.normal(0, 0.3, (n, 2))
+    out = rng.random(n) < 0.3
+    p2[out] += rng.uniform(-40, 40, (int(out.sum()), 2))
+    return K, R, t, p1, p2
+
+
+def test_ransac_control_flow_in_python(oracle):
+    """RANSACPointSetRegistrator::run re-stated in Python around the oracle's five-point solver: OpenCV's MWC RNG,
+    repeat rejection, float32 Sampson test, strict `>` and RANSACUpdateNumIters must give the very same mask."""
+    K, R, t, p1, p2 = _scene(6, 300)
+    n = len(p1)
+    ifx, ify = 1 / K[0, 0], 1 / K[1, 1]
+    x1 = np.stack([p1[:, 0] * ifx + (-K[0, 2] * ifx), p1[:, 1] * ify + (-K[1, 2] * ify)], 1)
+    x2 = np.stack([p2[:, 0] * ifx + (-K[0, 2] * ifx), p2[:, 1] * ify + (-K[1, 2] * ify)], 1)
+    thr = np.float32((1.0 / ((K[0, 0] + K[1, 1]) / 2)) ** 2)
+    state = 0xFFFFFFFFFFFFFFFF
+
+    def nxt():
+        nonlocal state
+        state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        return state & 0xFFFFFFFF
+
+    def sampson_mask(E):
+        h1 = np.c_[x1, np.ones(n)]; h2 = np.c_[x2, np.ones(n)]
+        Ex1 = h1 @ E.T; Etx2 = h2 @ E
+        num = (h2 * Ex1).sum(1) ** 2
+        err = (num / (Ex1[:, 0] ** 2 + Ex1[:, 1] ** 2 + Etx2[:, 0] ** 2 + Etx2[:, 1] ** 2)).astype(np.float32)
+        return err <= thr
+
+    niters, best, best_mask, it = 1000, 0, None, 0
+    while it < niters:
+        idx = []
+        while len(idx) < 5:
+            v = nxt() % n
+            if v not in idx:
+                idx.append(v)
+        for E in oracle.five_point(x1[idx], x2[idx]):
+            m = sampson_mask(E); good = int(m.sum())
+            if good > max(best, 4):
+                best, best_mask = good, m
+                ep = (n - good) / n
+                denom = 1 - (1 - ep) ** 5
+                if denom < np.finfo(float).tiny:
+                    niters = 0
+                else:
+                    num, den = np.log(0.01), np.log(denom)
+                    niters = niters if (den >= 0 or -num >= niters * -den) else int(np.rint(num / den))
+        it += 1
+    rc, E, mask, ninl = oracle.find_essential_ransac(p1, p2, K)
+    assert rc == 0 and ninl == best and np.array_equal(mask.astype(bool), best_mask)
+
+
+def test_recover_pose_and_triangulate_with_numpy_svd(oracle):
+    K, R, t, p1, p2 = _scene(7, 250)
+    rc, E, mask, _ = oracle.find_essential_ransac(p1, p2, K)
+    q1, q2 = p1[mask > 0], p2[mask > 0]
+    ng, Ro, to, pm = oracle.recover_pose(E[0], q1, q2, K)
+    U, _, Vt = np.linalg.svd(E[0])
+    if np.linalg.det(U) < 0: U = -U
+    if np.linalg.det(Vt) < 0: Vt = -Vt
+    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    cands = [(U @ W @ Vt, U[:, 2]), (U @ W.T @ Vt, U[:, 2]), (U @ W @ Vt, -U[:, 2]), (U @ W.T @ Vt, -U[:, 2])]
+    n1 = (np.c_[q1, np.ones(len(q1))] @ np.linalg.inv(K).T)[:, :2]
+    n2 = (np.c_[q2, np.ones(len(q2))] @ np.linalg.inv(K).T)[:, :2]
+
+    def tri(P1, P2, a, b):
+        A = np.stack([a[0] * P1[2] - P1[0], a[1] * P1[2] - P1[1], b[0] * P2[2] - P2[0], b[1] * P2[2] - P2[1]])
+        return np.linalg.svd(A)[2][3]
+
+    counts = []
+    for Rc, tc in cands:
+        P = np.c_[Rc, tc]; good = 0
+        for a, b in zip(n1, n2):
+            Q = tri(np.eye(3, 4), P, a, b)
+            ok = Q[2] * Q[3] > 0
+            Q = Q / Q[3]
+            z2 = (P @ Q)[2]
+            good += bool(ok and Q[2] < 50 and 0 < z2 < 50)
+        counts.append(good)
+    k = int(np.argmax(counts))
+    assert ng == max(counts)
+    assert np.linalg.norm(Ro - cands[k][0]) < 1e-9 and np.linalg.norm(to.ravel() - cands[k][1]) < 1e-9
+    P1 = K @ np.c_[Ro.T, -Ro.T @ to]; P0 = K @ np.eye(3, 4)
+    Xo = oracle.triangulate(P1, P0, q1.T, q2.T)
+    for i in range(0, len(q1), 7):
+        ref = tri(P1, P0, q1[i], q2[i])
+        a, b = Xo[:, i] / np.linalg.norm(Xo[:, i]), ref / np.linalg.norm(ref)
+        assert 1 - abs(a @ b) < 1e-10
