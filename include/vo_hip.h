@@ -158,6 +158,15 @@ int vo_sync(vo_ctx* ctx);
 int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* dist, uint8_t* inlier_mask,
                     int cap, int32_t* n_out);
 
+/* ------------------------------------------------------------------ "next" row
+ * Map.remove_observations_with_reprojection_errors_above_threshold / calculate_reprojection_error —
+ * src/map.py:46-94.  poses: ncam x 16 (row-major 4x4, TrackedCamera.pose()), points: npt x 3, observation i =
+ * (obs_cam[i], obs_pt[i], obs_xy[2i..]) as INDICES into those arrays.  sqerr[i] = squared pixel error,
+ * keep[i] = sqerr < threshold (the reference's default threshold is 100). */
+int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam, const double* points, int npt,
+                           const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
+                           const double* K, double threshold, double* sqerr, uint8_t* keep);
+
 /* ------------------------------------------------------------------ measurement
  * With profiling on, every kernel family of the batched path is bracketed by hipEvents on the
  * ctx stream; vo_profile_read returns accumulated milliseconds and launch counts per stage since

@@ -229,3 +229,19 @@ def pair(img1, img2, params, K, match_mode=0, ratio=0.75, want_points=True):
     if want_points:
         out["X"] = X[:, :res.n_inl_E].copy()
     return out
+
+
+def reprojection_sqerr(poses, points, obs_cam, obs_pt, obs_xy, K, threshold=100.0):
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 16); points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2); K = np.ascontiguousarray(K, np.float64)
+    n = len(oc)
+    err = np.zeros(n); keep = np.zeros(n, np.uint8)
+    f = lib().voo_reprojection_sqerr
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                  C.c_double, C.c_void_p, C.c_void_p]
+    rc = f(poses.ctypes.data, len(poses), points.ctypes.data, len(points), oc.ctypes.data, op.ctypes.data,
+           xy.ctypes.data, n, K.ctypes.data, float(threshold), err.ctypes.data, keep.ctypes.data)
+    if rc:
+        raise IndexError("observation refers to a missing camera or point")
+    return err, keep.astype(bool)

@@ -81,6 +81,11 @@ int voo_pair(const uint8_t* img1, const uint8_t* img2, int h, int w, const voo_o
              const double* K, int match_mode, double ratio, voo_pair_result* out,
              double* X /*4 x cap, w=1*/, int32_t x_cap);
 
+/* --- "next" row: reprojection-error filter, map.py:46-94 -------------- */
+int voo_reprojection_sqerr(const double* poses, int ncam, const double* points, int npt,
+                           const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
+                           const double* K, double threshold, double* sqerr, uint8_t* keep);
+
 #ifdef __cplusplus
 }
 #endif

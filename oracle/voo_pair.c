@@ -79,3 +79,27 @@ int voo_pair(const uint8_t* img1, const uint8_t* img2, int h, int w, const voo_o
     free(mask); free(pts); free(md); free(qi); free(d1); free(oct); free(kf);
     return rc;
 }
+
+/* ---------------------------------------------------------------- "next" row: reprojection-error filter
+ * /root/reference/src/map.py:46-68 (remove_observations_with_reprojection_errors_above_threshold) and :70-94
+ * (calculate_reprojection_error): for every observation project its map point with its camera's 4x4 pose and K,
+ * divide by z, squared pixel distance to the observed coordinate; keep iff sqerr < threshold.  Sums run left to
+ * right (numpy's BLAS may order them differently: compare with a tolerance). */
+int voo_reprojection_sqerr(const double* poses /*ncam x 16*/, int ncam, const double* points /*npt x 3*/, int npt,
+                           const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
+                           const double* K, double threshold, double* sqerr, uint8_t* keep)
+{
+    for (int i = 0; i < nobs; i++) {
+        if (obs_cam[i] < 0 || obs_cam[i] >= ncam || obs_pt[i] < 0 || obs_pt[i] >= npt) return -1;
+        const double* T = poses + 16 * (size_t)obs_cam[i];
+        const double* X = points + 3 * (size_t)obs_pt[i];
+        double c[3], t[3];
+        for (int r = 0; r < 3; r++) c[r] = T[4 * r] * X[0] + T[4 * r + 1] * X[1] + T[4 * r + 2] * X[2] + T[4 * r + 3] * 1.0;
+        for (int r = 0; r < 3; r++) t[r] = K[3 * r] * c[0] + K[3 * r + 1] * c[1] + K[3 * r + 2] * c[2];
+        double dx = t[0] / t[2] - obs_xy[2 * i], dy = t[1] / t[2] - obs_xy[2 * i + 1];
+        double e = dx * dx + dy * dy;
+        sqerr[i] = e;
+        keep[i] = e < threshold ? 1 : 0;
+    }
+    return 0;
+}

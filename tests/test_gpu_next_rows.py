@@ -1,0 +1,65 @@
+"""GPU parity of the first widened row: the map's reprojection-error filter."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Cam:
+    def __init__(self, cid, R, t): self.camera_id, self.R, self.t = cid, R, t
+    def pose(self):
+        T = np.eye(4); T[:3, :3] = self.R; T[:3, 3] = np.asarray(self.t).ravel(); return T
+
+
+class Pt:
+    def __init__(self, pid, p): self.point_id, self.point = pid, tuple(p)
+
+
+class Obs:
+    def __init__(self, pid, cid, xy): self.point_id, self.camera_id, self.image_coordinates = pid, cid, xy
+
+
+def _map(seed, ncam, npt, nobs):
+    rng = np.random.default_rng(seed)
+    K = np.array([[802.8, 0, 565.4], [0, 802.8, 240.1], [0, 0, 1.0]])
+    cams = []
+    for i in range(ncam):
+        a = rng.normal(0, 0.05, 3); th = np.linalg.norm(a); k = a / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        cams.append(Cam(100 + 7 * i, np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx, rng.normal(0, 0.5, 3)))
+    pts = [Pt(5000 + 3 * j, rng.uniform(-5, 5, 3) + [0, 0, 20]) for j in range(npt)]
+    obs = []
+    for _ in range(nobs):
+        c, p = cams[rng.integers(ncam)], pts[rng.integers(npt)]
+        x = K @ (c.pose() @ np.r_[p.point, 1.0])[:3]
+        obs.append(Obs(p.point_id, c.camera_id, tuple(x[:2] / x[2] + rng.normal(0, rng.choice([0.5, 3, 12]), 2))))
+    return K, cams, pts, obs
+
+
+def test_reprojection_filter_matches_oracle_and_numpy(oracle, ctx):
+    from visual_odometry_amd import map_filters as mf
+    K, cams, pts, obs = _map(1, 18, 3000, 20000)
+    arrays = mf._arrays(cams, pts, obs)
+    err, keep = mf.reprojection_sqerr(*arrays, K, 100)
+    eo, ko = oracle.reprojection_sqerr(*arrays, K, 100)
+    assert np.array_equal(err, eo) and np.array_equal(keep, ko)          # same left-to-right float64 arithmetic
+    # numpy, as the reference writes it (map.py:57-64)
+    for i in range(0, 20000, 997):
+        o = obs[i]
+        cam = next(c for c in cams if c.camera_id == o.camera_id); p = next(p for p in pts if p.point_id == o.point_id)
+        t = K @ (cam.pose() @ np.array([np.hstack((np.array(p.point), 1))]).T)[0:3, :]
+        t = t / t[2, 0]
+        sq = float(np.abs((t[0, 0] - o.image_coordinates[0]) ** 2) + np.abs((t[1, 0] - o.image_coordinates[1]) ** 2))
+        assert abs(sq - err[i]) <= 1e-9 * max(1.0, sq)
+    kept = mf.remove_observations_with_reprojection_errors_above_threshold(cams, pts, obs, K, 100)
+    assert len(kept) == int(keep.sum()) and 0.4 * len(obs) < len(kept) < len(obs)
+    total = mf.calculate_reprojection_error(cams, pts, obs, K)
+    assert abs(total - float(np.sum(eo))) <= 1e-9 * total
+
+
+def test_reprojection_filter_edge_cases(ctx):
+    from visual_odometry_amd import map_filters as mf, _lib
+    K = np.eye(3)
+    assert mf.remove_observations_with_reprojection_errors_above_threshold([], [], [], K) == []
+    with pytest.raises(_lib.VoError):
+        mf.reprojection_sqerr(np.eye(4)[None], np.zeros((1, 3)), [0], [5], [[0, 0]], K)     # missing point

@@ -63,6 +63,7 @@ _SIGS = {
     "vo_pairs_run_async": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
     "vo_sync": (C.c_int, [_P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
+    "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
     "vo_profile_enable": (C.c_int, [_P, C.c_int]),
     "vo_profile_reset": (C.c_int, [_P]),
     "vo_profile_read": (C.c_int, [_P, _P, _P]),

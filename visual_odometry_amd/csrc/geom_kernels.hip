@@ -965,3 +965,36 @@ void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, do
 {
     hipLaunchKernelGGL(k_five_point_raw, dim3(1), dim3(64), 0, s, x1, x2, E, nm);
 }
+
+// ------------------------------------------------------------------ reprojection-error filter
+// src/map.py:46-94: project every observation's map point with its camera pose and K, squared pixel error,
+// keep iff below the threshold.  One lane per observation; poses / points are gathered through L2.
+__global__ void k_reprojection(const double* poses, int ncam, const double* points, int npt, const int* obs_cam,
+                               const int* obs_pt, const double* obs_xy, int nobs, const double* Kd, double threshold,
+                               double* sqerr, uint8_t* keep, int* bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nobs) return;
+    const int ci = obs_cam[i], pi = obs_pt[i];
+    if (ci < 0 || ci >= ncam || pi < 0 || pi >= npt) { atomicOr(bad, 1); sqerr[i] = 0; keep[i] = 0; return; }
+    const double* T = poses + 16 * (size_t)ci;
+    const double* X = points + 3 * (size_t)pi;
+    double c[3], t[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) c[r] = T[4 * r] * X[0] + T[4 * r + 1] * X[1] + T[4 * r + 2] * X[2] + T[4 * r + 3] * 1.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) t[r] = Kd[3 * r] * c[0] + Kd[3 * r + 1] * c[1] + Kd[3 * r + 2] * c[2];
+    const double dx = t[0] / t[2] - obs_xy[2 * i], dy = t[1] / t[2] - obs_xy[2 * i + 1];
+    const double e = dx * dx + dy * dy;
+    sqerr[i] = e;
+    keep[i] = e < threshold ? 1 : 0;
+}
+
+void launch_reprojection(hipStream_t s, const double* poses, int ncam, const double* points, int npt, const int* obs_cam,
+                         const int* obs_pt, const double* obs_xy, int nobs, const double* Kd, double threshold,
+                         double* sqerr, uint8_t* keep, int* bad)
+{
+    if (nobs <= 0) return;
+    hipLaunchKernelGGL(k_reprojection, dim3((nobs + 255) / 256), dim3(256), 0, s, poses, ncam, points, npt, obs_cam, obs_pt,
+                       obs_xy, nobs, Kd, threshold, sqerr, keep, bad);
+}

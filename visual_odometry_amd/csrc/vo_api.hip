@@ -936,6 +936,45 @@ extern "C" int vo_stage_five_point(vo_ctx* ctx, const double* x1, const double* 
     return VO_OK;
 }
 
+// ------------------------------------------------------------------ "next" row: reprojection-error filter
+extern "C" int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam, const double* points, int npt,
+                                      const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
+                                      const double* K, double threshold, double* sqerr, uint8_t* keep)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (ncam < 0 || npt < 0 || nobs < 0 || !K || (nobs > 0 && (!poses || !points || !obs_cam || !obs_pt || !obs_xy || !sqerr || !keep)))
+        FAIL(VO_ERR_INVALID, "bad arguments");
+    if (nobs == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nd = (size_t)16 * ncam + (size_t)3 * npt + (size_t)2 * nobs + 9 + (size_t)nobs + 64;
+    const size_t ni = (size_t)2 * nobs + 16;                       // ints, stored in the double scratch as well
+    int rc = ensure_raw_d(ctx, nd + ni / 2 + nobs / 8 + 64);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    double* d = ctx->raw_d;
+    double *dposes = d, *dpoints = dposes + (size_t)16 * ncam, *dxy = dpoints + (size_t)3 * npt, *dK = dxy + (size_t)2 * nobs;
+    double* derr = dK + 16;
+    int* dcam = (int*)(derr + nobs + 8); int* dpt = dcam + nobs; int* dbad = dpt + nobs;
+    uint8_t* dkeep = (uint8_t*)(dbad + 8);
+    HIPCHK(hipMemcpyAsync(dposes, poses, (size_t)16 * ncam * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dpoints, points, (size_t)3 * npt * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dxy, obs_xy, (size_t)2 * nobs * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dcam, obs_cam, (size_t)nobs * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dpt, obs_pt, (size_t)nobs * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(dbad, 0, sizeof(int), s));
+    { StageTimer t(ctx, ST_MISC); launch_reprojection(s, dposes, ncam, dpoints, npt, dcam, dpt, dxy, nobs, dK, threshold, derr, dkeep, dbad); }
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(sqerr, derr, (size_t)nobs * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(keep, dkeep, (size_t)nobs, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    if (bad) FAIL(VO_ERR_INVALID, "an observation refers to a missing camera or point");
+    return VO_OK;
+}
+
 // ------------------------------------------------------------------ measurement
 extern "C" int vo_profile_enable(vo_ctx* ctx, int on)
 {

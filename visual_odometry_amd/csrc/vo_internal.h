@@ -118,3 +118,6 @@ void launch_triangulate_pairs(hipStream_t s, PairBuf pb, int kp_cap, int P, Rans
 void launch_triangulate_raw(hipStream_t s, const double* P1, const double* P2, const double* x1, const double* x2,
                             int M, double* X);
 void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm);
+void launch_reprojection(hipStream_t s, const double* poses, int ncam, const double* points, int npt, const int* obs_cam,
+                         const int* obs_pt, const double* obs_xy, int nobs, const double* Kd, double threshold,
+                         double* sqerr, uint8_t* keep, int* bad);

@@ -1,0 +1,60 @@
+"""Reprojection-error filter over all map observations (reference: src/map.py:46-94).
+
+The reference walks Python lists of Observation / TrackedCamera / TrackedPoint objects and multiplies 4x4
+matrices per observation; here the same quantities go to the GPU as arrays (one lane per observation).  The
+object-level helpers accept the reference's record types unchanged (duck typed: .camera_id/.pose(),
+.point_id/.point, .camera_id/.point_id/.image_coordinates)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def reprojection_sqerr(poses, points, obs_cam, obs_pt, obs_xy, camera_matrix, threshold=100.0, ctx=None):
+    """Arrays in, (sqerr [N] float64, keep [N] bool) out. obs_cam / obs_pt index rows of poses / points."""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    oc = np.ascontiguousarray(obs_cam, np.int32); op = np.ascontiguousarray(obs_pt, np.int32)
+    xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(camera_matrix, np.float64).reshape(3, 3)
+    n = len(oc)
+    if not (len(op) == n == len(xy)):
+        raise ValueError("observation arrays differ in length")
+    err = np.zeros(n); keep = np.zeros(n, np.uint8)
+    ctx = ctx or _lib.default_context()
+    ctx.check(ctx.lib.vo_reprojection_filter(ctx.handle, poses.ctypes.data, len(poses), points.ctypes.data, len(points),
+                                             oc.ctypes.data, op.ctypes.data, xy.ctypes.data, n, K.ctypes.data,
+                                             float(threshold), err.ctypes.data, keep.ctypes.data))
+    return err, keep.astype(bool)
+
+
+def _arrays(cameras, points, observations):
+    cam_row = {c.camera_id: i for i, c in enumerate(cameras)}
+    pt_row = {p.point_id: i for i, p in enumerate(points)}
+    poses = np.stack([c.pose() for c in cameras]) if cameras else np.zeros((0, 4, 4))
+    pts = np.array([p.point for p in points], dtype=np.float64).reshape(-1, 3)
+    oc = np.array([cam_row[o.camera_id] for o in observations], np.int32)
+    op = np.array([pt_row[o.point_id] for o in observations], np.int32)
+    xy = np.array([o.image_coordinates for o in observations], dtype=np.float64).reshape(-1, 2)
+    return poses, pts, oc, op, xy
+
+
+def remove_observations_with_reprojection_errors_above_threshold(cameras, points, observations, camera_matrix,
+                                                                 threshold=100, ctx=None):
+    """map.py:46-68 — returns the observations whose squared reprojection error is below the threshold."""
+    if not observations:
+        return []
+    _, keep = reprojection_sqerr(*_arrays(cameras, points, observations), camera_matrix, threshold, ctx)
+    return [o for o, k in zip(observations, keep) if k]
+
+
+def calculate_reprojection_error(cameras, points, observations, camera_matrix, ctx=None):
+    """map.py:70-94 — total squared reprojection error, summed in observation order."""
+    if not observations:
+        return 0.0
+    err, _ = reprojection_sqerr(*_arrays(cameras, points, observations), camera_matrix, np.inf, ctx)
+    total = 0.0
+    for e in err.tolist():
+        total += e
+    return total
