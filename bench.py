@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--workload", choices=["sequence", "independent"], default="sequence",
+                    help="sequence: C+1 consecutive frames -> C pairs, each frame detected once (BASELINE config 2); "
+                         "independent: C pairs with their own two frames each, 2C detections (BASELINE config 4 accounting)")
     ap.add_argument("--contexts", type=int, default=2, help="contexts (streams) per GPU alternating over the chunks")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the multi-process path on a box with fewer GPUs than ranks (all ranks share GPU 0)")
@@ -140,9 +143,16 @@ def main():
     C = args.pairs_per_step
     seq = synth.sequence(args.distinct_frames, args.width, args.height, cache_dir="/tmp")
     K = seq["K"]
-    order = ping_pong(args.distinct_frames, C + 1, start=rank * 3)
-    frames = seq["frames"][order]                         # chunk of C+1 consecutive views -> C pairs
-    pairs = np.stack([np.arange(C), np.arange(C) + 1], axis=1).astype(np.int32)
+    if args.workload == "sequence":
+        order = ping_pong(args.distinct_frames, C + 1, start=rank * 3)
+        frames = seq["frames"][order]                     # chunk of C+1 consecutive views -> C pairs
+        pairs = np.stack([np.arange(C), np.arange(C) + 1], axis=1).astype(np.int32)
+    else:
+        a = ping_pong(args.distinct_frames, C, start=rank * 3)
+        b = ping_pong(args.distinct_frames, C, start=rank * 3 + 1)
+        frames = seq["frames"][np.stack([a, b], axis=1).ravel()]      # 2C frames, pair k = slots (2k, 2k+1)
+        pairs = np.stack([2 * np.arange(C), 2 * np.arange(C) + 1], axis=1).astype(np.int32)
+    NF = len(frames)
     match_mode = MATCH_CROSSCHECK if args.matcher == "crosscheck" else MATCH_RATIO
 
     # Two contexts (two HIP streams, two sets of resident buffers) on the GPU: while one chunk is in its
@@ -150,7 +160,7 @@ def main():
     n_ctx = max(1, args.contexts)
     fes = []
     for c in range(n_ctx):
-        fe_c = FrontEnd(args.height, args.width, max_frames=C + 1, max_pairs=C, nfeatures=args.nfeatures,
+        fe_c = FrontEnd(args.height, args.width, max_frames=NF, max_pairs=C, nfeatures=args.nfeatures,
                         nlevels=args.nlevels, device=device)
         t_up = time.perf_counter()
         fe_c.upload(frames)                               # inputs resident in HBM before the timed region
@@ -182,7 +192,7 @@ def main():
         if in_flight[k] is not None:
             f.wait()
             consume(in_flight[k])
-        f.detect(0, C + 1, wait=False)                    # each frame detected once (sequence mode)
+        f.detect(0, NF, wait=False)                       # sequence mode: each frame detected once
         in_flight[k], _ = f.run_pairs(pairs, K, opts, wait=False)
 
     def drain():
@@ -226,7 +236,7 @@ def main():
     if not args.no_profile:
         fe.profile(True)
         for _ in range(prof_steps):
-            fe.detect(0, C + 1, wait=False)
+            fe.detect(0, NF, wait=False)
             fe.run_pairs(pairs, K, opts)
         prof = fe.profile_read()
         fe.profile(False)
@@ -240,8 +250,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f32+f64",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: seeded synthetic {args.width}x{args.height} drone sequence, "
-                                   f"{args.nfeatures} ORB features/frame, {args.nlevels} levels; chunk of {C + 1} "
-                                   f"consecutive frames -> {C} pairs per GPU per step, each frame detected once",
+                                   f"{args.nfeatures} ORB features/frame, {args.nlevels} levels; " +
+                                   (f"chunk of {C + 1} consecutive frames -> {C} pairs per GPU per step, each frame detected once"
+                                    if args.workload == "sequence" else
+                                    f"{C} independent pairs per GPU per step, both frames of every pair detected ({NF} detections)"),
                        "pairs_per_step_per_gpu": C, "distinct_rendered_frames": args.distinct_frames,
                        "contexts_per_gpu": n_ctx,
                        "matcher": args.matcher, "ransac": "5-point, conf 0.99, 1 px, seed 2^64-1, <=1000 iters",
@@ -256,7 +268,7 @@ def main():
             stages = {k: {"ms_per_launch": round(ms / n, 4), "launches": n, "ms_total": round(ms, 3)} for k, (ms, n) in prof.items()}
             dom = max((k for k in prof if k != "misc"), key=lambda k: prof[k][0])
             ms, n = prof[dom]
-            nframes = C + 1
+            nframes = NF
             b = fe.stage_bytes(dom, nframes)
             ach = b / (ms / n * 1e-3) / 1e9 if b > 0 and ms > 0 else 0.0
             line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,

@@ -109,62 +109,66 @@ static void solve_z(const double* A, int n, double* x)
 }
 
 /* ---------------------------------------------------------------- polynomials in (x, y, z), degree <= 3
- * monomial order of Nister's 10x20 elimination template (the one five-point.cpp's getCoeffMat uses):
- *   x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1 */
-static const int k_exp[20][3] = {
+ * degree-1 polynomials: coefficients of (x, y, z, 1); degree-2: (x^2, xy, xz, x, y^2, yz, y, z^2, z, 1);
+ * degree-3 in the monomial order of Nister's 10x20 elimination template (the one five-point.cpp's
+ * getCoeffMat uses):  x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1.
+ * The products accumulate in exactly this loop order (the HIP kernel uses the same tables and loops, so the
+ * two agree bit for bit even on badly conditioned samples). */
+static const int k_e1[4][3] = {{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+static const int k_e2[10][3] = {{2,0,0},{1,1,0},{1,0,1},{1,0,0},{0,2,0},{0,1,1},{0,1,0},{0,0,2},{0,0,1},{0,0,0}};
+static const int k_e3[20][3] = {
     {3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
     {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0}};
+static int k_t11[4][4], k_t21[10][4], k_tab_ready = 0;
 
-static int mono_index(int a, int b, int c)
+static void make_poly_tab(void)
 {
-    for (int i = 0; i < 20; i++) if (k_exp[i][0] == a && k_exp[i][1] == b && k_exp[i][2] == c) return i;
-    return -1;
+    if (k_tab_ready) return;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++)
+        for (int m = 0; m < 10; m++)
+            if (k_e2[m][0] == k_e1[i][0] + k_e1[j][0] && k_e2[m][1] == k_e1[i][1] + k_e1[j][1] && k_e2[m][2] == k_e1[i][2] + k_e1[j][2]) k_t11[i][j] = m;
+    for (int i = 0; i < 10; i++) for (int j = 0; j < 4; j++)
+        for (int m = 0; m < 20; m++)
+            if (k_e3[m][0] == k_e2[i][0] + k_e1[j][0] && k_e3[m][1] == k_e2[i][1] + k_e1[j][1] && k_e3[m][2] == k_e2[i][2] + k_e1[j][2]) k_t21[i][j] = m;
+    k_tab_ready = 1;
 }
 
-static void pmul_acc(const double* p, const double* q, double scale, double* r)
+static void mul11_acc(const double* p, const double* q, double s, double* r)      /* deg 1 x deg 1 -> deg 2 */
 {
-    for (int i = 0; i < 20; i++) {
-        if (p[i] == 0) continue;
-        for (int j = 0; j < 20; j++) {
-            if (q[j] == 0) continue;
-            int idx = mono_index(k_exp[i][0] + k_exp[j][0], k_exp[i][1] + k_exp[j][1], k_exp[i][2] + k_exp[j][2]);
-            if (idx >= 0) r[idx] += scale * p[i] * q[j];
-        }
-    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r[k_t11[i][j]] += s * p[i] * q[j];
 }
 
-/* basis: 4 row-major 3x3 matrices (coefficients of x, y, z, 1).  A: 10 x 20. */
+static void mul21_acc(const double* p, const double* q, double s, double* r)      /* deg 2 x deg 1 -> deg 3 */
+{
+    for (int i = 0; i < 10; i++) for (int j = 0; j < 4; j++) r[k_t21[i][j]] += s * p[i] * q[j];
+}
+
+/* basis: 4 row-major 3x3 matrices (coefficients of x, y, z, 1).  A: 10 x 20:
+ * row 0 = det(E), rows 1..9 = (E E^T - 0.5 tr(E E^T) I) E. */
 static void build_constraints(const double* basis, double* A)
 {
-    double E[3][3][20];
-    memset(E, 0, sizeof(E));
-    static const int lin[4] = {12, 15, 18, 19};      /* x, y, z, 1 */
+    double E[3][3][4];
+    make_poly_tab();
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
-        for (int k = 0; k < 4; k++) E[r][c][lin[k]] = basis[k * 9 + r * 3 + c];
+        for (int k = 0; k < 4; k++) E[r][c][k] = basis[k * 9 + r * 3 + c];
     memset(A, 0, sizeof(double) * 200);
-    /* row 0: det(E) */
-    {
-        double m[20];
-        static const int co[3][2][2] = {{{1, 2}, {1, 2}}, {{0, 2}, {0, 2}}, {{0, 1}, {0, 1}}};
-        (void)co;
-        for (int c = 0; c < 3; c++) {
-            int c1 = (c + 1) % 3, c2 = (c + 2) % 3;     /* cyclic cofactor expansion along row 0 */
-            memset(m, 0, sizeof(m));
-            pmul_acc(E[1][c1], E[2][c2], 1.0, m);
-            pmul_acc(E[1][c2], E[2][c1], -1.0, m);
-            pmul_acc(E[0][c], m, 1.0, A);
-        }
+    for (int c = 0; c < 3; c++) {
+        int c1 = (c + 1) % 3, c2 = (c + 2) % 3;     /* cyclic cofactor expansion along row 0 */
+        double m[10];
+        memset(m, 0, sizeof(m));
+        mul11_acc(E[1][c1], E[2][c2], 1.0, m);
+        mul11_acc(E[1][c2], E[2][c1], -1.0, m);
+        mul21_acc(m, E[0][c], 1.0, A);
     }
-    /* rows 1..9: (E E^T - 0.5 tr(E E^T) I) E = 0 */
-    double EEt[3][3][20], tr[20];
-    memset(EEt, 0, sizeof(EEt)); memset(tr, 0, sizeof(tr));
+    double L[3][3][10], tr[10];
+    memset(L, 0, sizeof(L));
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
-        for (int k = 0; k < 3; k++) pmul_acc(E[r][k], E[c][k], 1.0, EEt[r][c]);
-    for (int i = 0; i < 20; i++) tr[i] = EEt[0][0][i] + EEt[1][1][i] + EEt[2][2][i];
-    for (int r = 0; r < 3; r++) for (int i = 0; i < 20; i++) EEt[r][r][i] -= 0.5 * tr[i];
+        for (int k = 0; k < 3; k++) mul11_acc(E[r][k], E[c][k], 1.0, L[r][c]);
+    for (int i = 0; i < 10; i++) tr[i] = L[0][0][i] + L[1][1][i] + L[2][2][i];
+    for (int r = 0; r < 3; r++) for (int i = 0; i < 10; i++) L[r][r][i] -= 0.5 * tr[i];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
         double* row = A + (1 + r * 3 + c) * 20;
-        for (int k = 0; k < 3; k++) pmul_acc(EEt[r][k], E[k][c], 1.0, row);
+        for (int k = 0; k < 3; k++) mul21_acc(L[r][k], E[k][c], 1.0, row);
     }
 }
 
@@ -173,16 +177,21 @@ static int reduce_10x20(double* A, double* X)
 {
     for (int col = 0; col < 10; col++) {
         int piv = col; double best = fabs(A[col * 20 + col]);
-        for (int r = col + 1; r < 10; r++) if (fabs(A[r * 20 + col]) > best) { best = fabs(A[r * 20 + col]); piv = r; }
+        for (int r = col + 1; r < 10; r++) { double v = fabs(A[r * 20 + col]); if (v > best) { best = v; piv = r; } }
         if (best < 1e-300) return -1;
-        if (piv != col) for (int k = 0; k < 20; k++) { double t = A[col * 20 + k]; A[col * 20 + k] = A[piv * 20 + k]; A[piv * 20 + k] = t; }
-        double inv = 1.0 / A[col * 20 + col];
-        for (int k = 0; k < 20; k++) A[col * 20 + k] *= inv;
+        double prow[20];
+        const double inv = 1.0 / A[piv * 20 + col];
+        for (int k = 0; k < 20; k++) {
+            const double a = A[piv * 20 + k], b = A[col * 20 + k];
+            prow[k] = a * inv;
+            A[piv * 20 + k] = b;                      /* row swap (no-op when piv == col) */
+            A[col * 20 + k] = prow[k];
+        }
         for (int r = 0; r < 10; r++) {
             if (r == col) continue;
-            double f = A[r * 20 + col];
+            const double f = A[r * 20 + col];
             if (f == 0) continue;
-            for (int k = 0; k < 20; k++) A[r * 20 + k] -= f * A[col * 20 + k];
+            for (int k = 0; k < 20; k++) A[r * 20 + k] -= f * prow[k];
         }
     }
     for (int r = 0; r < 10; r++) for (int k = 0; k < 10; k++) X[r * 10 + k] = A[r * 20 + 10 + k];
@@ -207,34 +216,54 @@ static inline cplx cdiv(cplx a, cplx b)
     return r;
 }
 
+/* OpenCV runs a fixed 300 sweeps (its exit test is maxDiff <= 0).  Compiled with -DVOO_DK_FULL_300 this does the
+ * same.  By default a sample stops as soon as further sweeps can only move rounding noise: every correction below
+ * 4 ulp of its root, or the largest correction has been small (< 1e-7 relative) and has stopped shrinking for two
+ * sweeps (the noise floor of an ill-conditioned / multiple root).  The roots agree with the 300-sweep result to
+ * that noise floor, and the HIP kernel applies the identical rule, operation for operation. */
 static int solve_poly(const double* c, int n0, cplx* roots, int max_iters)
 {
     int n = n0;
-    cplx coeffs[16];
-    for (int i = 0; i <= n0; i++) { coeffs[i].re = c[i]; coeffs[i].im = 0; }
-    for (; n > 1; n--) if (fabs(coeffs[n].re) + fabs(coeffs[n].im) > DBL_EPSILON) break;
+    for (; n > 1; n--) if (fabs(c[n]) > DBL_EPSILON) break;
     cplx p = {1, 0}, r = {1, 1};
-    for (int i = 0; i < n; i++) { roots[i] = p; p = cmul(p, r); }
+    for (int i = 0; i < n0; i++) { roots[i] = p; p = cmul(p, r); }
+    double prev = 1e300;
+    int stall = 0;
     for (int iter = 0; iter < max_iters; iter++) {
-        double max_diff = 0;
+        double max_diff = 0, max_mag = 0;
+        int conv_all = 1;
         for (int i = 0; i < n; i++) {
             p = roots[i];
-            cplx num = coeffs[n], denom = coeffs[n];
+            cplx num = {c[n], 0}, denom = {c[n], 0};
             for (int j = 0; j < n; j++) {
-                num = cadd(cmul(num, p), coeffs[n - j - 1]);
+                cplx np = cmul(num, p);
+                num.re = np.re + c[n - j - 1]; num.im = np.im;
                 if (j != i) {
                     cplx d = csub(p, roots[j]);
                     if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
-                    /* coincident estimates (OpenCV's num_same_root branch) never occur for the
-                     * distinct starting points (1+i)^k in practice; treated as a unit factor */
+                    /* coincident estimates (OpenCV's num_same_root branch) never occur for the distinct
+                     * starting points (1+i)^k in practice; treated as a unit factor */
                 }
             }
             num = cdiv(num, denom);
             roots[i] = csub(p, num);
             double ab = sqrt(num.re * num.re + num.im * num.im);
             if (ab > max_diff) max_diff = ab;
+            double mag = fabs(roots[i].re) + fabs(roots[i].im);
+            if (mag > max_mag) max_mag = mag;
+            conv_all &= ab <= 4 * DBL_EPSILON * mag;
         }
         if (max_diff <= 0) break;
+#ifndef VOO_DK_FULL_300
+        if (conv_all) break;
+        if (max_diff < 1e-7 * (1.0 + max_mag)) {
+            if (max_diff > 0.5 * prev) { if (++stall >= 2) break; }
+            else stall = 0;
+        }
+        prev = max_diff;
+#else
+        (void)conv_all; (void)prev; (void)stall;
+#endif
     }
     for (int i = 0; i < n; i++) if (fabs(roots[i].im) < 1e-100) roots[i].im = 0;
     return n;

@@ -165,3 +165,23 @@ def test_two_image_driver_and_image_and_keypoints(oracle, seq_small, tmp_path):
     assert len(pair.raw_matches) == ref["n_match"]
     assert np.linalg.norm(np.hstack([pair.R, pair.t]) - np.hstack([ref["R"], ref["t"]])) < 1e-4
     assert pair.points3d_reconstr.shape == (4, ref["n_inl"])
+
+
+def test_long_sequence_every_pair_identical_to_oracle(oracle):
+    """23 consecutive pairs of a KITTI-shaped sequence (wide, short frames: many badly conditioned samples, weak
+    cheirality).  The five-point solver runs the same IEEE operations in the same order on both sides, so the
+    RANSAC decisions, inlier sets and [R|t] must agree exactly — this caught a premature RANSAC exit once."""
+    from visual_odometry_amd import synth
+    from visual_odometry_amd.frontend import FrontEnd
+    n = 24
+    seq = synth.sequence(n, 1241, 376, cache_dir="/tmp")
+    fe = FrontEnd(376, 1241, n, n - 1, nfeatures=2000)
+    fe.upload(seq["frames"]); fe.detect(0, n)
+    res, _ = fe.run_pairs([[i, i + 1] for i in range(n - 1)], seq["K"])
+    p = oracle.orb_params(nfeatures=2000)
+    for k in range(n - 1):
+        ref = oracle.pair(seq["frames"][k], seq["frames"][k + 1], p, seq["K"], want_points=False)
+        g = res[k]
+        assert (g["n_match"], g["n_inl"], g["n_good"]) == (ref["n_match"], ref["n_inl"], ref["n_good"]), k
+        d = np.linalg.norm(np.hstack([g["R"].reshape(3, 3), g["t"].reshape(3, 1)]) - np.hstack([ref["R"], ref["t"]]))
+        assert d < 1e-9, (k, d)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Trajectory check for BASELINE config 5 (KITTI-00 shape; the dataset is not in this image, so a seeded synthetic
+1241x376 sequence stands in): run the HIP front end over N frames, chain the relative poses, and report the ATE
+(RMSE of camera centres after a similarity alignment) against (a) the CPU oracle's chained poses on the same
+frames and (b) the generating trajectory.  Needs an MI355X."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+from visual_odometry_amd import synth  # noqa: E402
+from visual_odometry_amd.frontend import FrontEnd, chain_poses  # noqa: E402
+
+
+def align_sim3(a, b):
+    """Umeyama: s, R, t minimising |b - (s R a + t)|; a, b are [n, 3]."""
+    ma, mb = a.mean(0), b.mean(0)
+    A, B = a - ma, b - mb
+    U, D, Vt = np.linalg.svd(B.T @ A / len(a))
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    s = np.trace(np.diag(D) @ S) / (A ** 2).sum() * len(a)
+    return s, R, mb - s * R @ ma
+
+
+def ate(est, ref):
+    s, R, t = align_sim3(est, ref)
+    return float(np.sqrt((((s * (R @ est.T)).T + t - ref) ** 2).sum(1).mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--width", type=int, default=1241)
+    ap.add_argument("--height", type=int, default=376)
+    ap.add_argument("--nfeatures", type=int, default=2000)
+    a = ap.parse_args()
+    seq = synth.sequence(a.frames, a.width, a.height, cache_dir="/tmp")
+    fe = FrontEnd(a.height, a.width, a.frames, a.frames - 1, nfeatures=a.nfeatures)
+    fe.upload(seq["frames"]); fe.detect(0, a.frames)
+    pairs = [[i, i + 1] for i in range(a.frames - 1)]
+    res, _ = fe.run_pairs(pairs, seq["K"])
+    gpu = chain_poses(res["R"].reshape(-1, 3, 3), res["t"])[:, :3, 3]
+    p = O.orb_params(nfeatures=a.nfeatures)
+    Rs, ts = [], []
+    for i, j in pairs:
+        r = O.pair(seq["frames"][i], seq["frames"][j], p, seq["K"], want_points=False)
+        Rs.append(r["R"]); ts.append(r["t"].ravel())
+    cpu = chain_poses(np.stack(Rs), np.stack(ts))[:, :3, 3]
+    # ground truth camera centres expressed in the first camera's frame
+    R0, C0 = seq["R"][0], seq["C"][0]
+    gt = (seq["C"] - C0) @ R0.T
+    out = {"frames": a.frames, "ate_gpu_vs_cpu_oracle": ate(gpu, cpu), "max_abs_centre_diff_gpu_vs_cpu": float(np.abs(gpu - cpu).max()),
+           "ate_gpu_vs_ground_truth": ate(gpu, gt), "ate_cpu_vs_ground_truth": ate(cpu, gt),
+           "note": "unit-norm steps (monocular scale is unobservable); ground-truth ATE after Sim(3) alignment"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

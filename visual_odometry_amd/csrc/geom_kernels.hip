@@ -658,6 +658,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
         // (3) score four models at a time, consume in order
         const int T = sh.off[64];
         bool done = false;
+        int last_h = -1;
         for (int b = 0; b * 4 < T && !done; b++) {
             const int e = b * 4 + wave;
             if (e < T) {
@@ -673,8 +674,11 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                 const int e2 = b * 4 + w;
                 if (e2 >= T) break;
                 const int h = sh.eh[e2];
-                if (r0 + h >= niters) { done = true; break; }
-                iters_done = r0 + h + 1;
+                if (h != last_h) {               // `iter < niters` is tested once per sample; all models of a sample
+                    if (r0 + h >= niters) { done = true; break; }   // that has started are scored (ptsetreg.cpp)
+                    last_h = h;
+                    iters_done = r0 + h + 1;
+                }
                 const int good = sh.cnt[b & 1][w];
                 if (good > max(max_good, 4)) {
                     const int m = e2 - sh.off[h];
