@@ -29,6 +29,8 @@ extern "C" {
 #define VO_ERR_TOO_FEW       -3   /* fewer than 5 correspondences (cv2.findEssentialMat returns None) */
 #define VO_ERR_NO_MODEL      -4   /* RANSAC found no model with > 4 inliers */
 #define VO_ERR_NOT_CONFIGURED -5
+#define VO_ERR_AMBIGUOUS      -6   /* exactly 5 correspondences: findEssentialMat stacks up to 10 solutions, which
+                                     cv2.recoverPose (and the reference) cannot consume */
 
 typedef struct vo_ctx vo_ctx;
 

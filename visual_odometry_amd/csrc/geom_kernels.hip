@@ -871,6 +871,11 @@ __global__ __launch_bounds__(256) void k_pose(PairBuf pb, int kp_cap, RansacPara
         if (tid == 0) res->n_good = 0;
         return;
     }
+    if (res->reserved != 1) {           // M == 5: stacked solutions; decomposeEssentialMat needs a single 3x3 matrix
+        __syncthreads();
+        if (tid == 0) { res->status = VO_ERR_AMBIGUOUS; res->n_good = 0; }
+        return;
+    }
     const int M = pb.m_count[p];
     const size_t base2 = (size_t)p * kp_cap * 2;
     const uint8_t* mask = pb.mask + (size_t)p * kp_cap;

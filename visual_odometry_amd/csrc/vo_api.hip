@@ -863,7 +863,7 @@ extern "C" int vo_recover_pose(vo_ctx* ctx, const double* E, const double* p1, c
     if (rc) return rc;
     vo_pair_result res{};
     memcpy(res.E, E, sizeof(res.E));
-    res.status = VO_OK; res.n_match = M;
+    res.status = VO_OK; res.n_match = M; res.reserved = 1;
     HIPCHK(hipMemcpyAsync(ctx->raw_pb.res, &res, sizeof(res), hipMemcpyHostToDevice, ctx->stream));
     RansacParams rp{};
     rp.dist_thresh = dist_thresh; rp.prob = 0.99; rp.thresh_px = 1; rp.max_iters = 1;
