@@ -169,6 +169,14 @@ int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam, const dou
                            const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
                            const double* K, double threshold, double* sqerr, uint8_t* keep);
 
+/* VisualSlam.update_feature_mapper + track_feature_back_in_time — src/visual_slam.py:183-188, :94-99, for ALL
+ * features at once.  A feature id is (frame, index) with frame < F, index < cap.  Pair p maps
+ * every matched feature (pair_frames[2p+1], mt[k]) to (pair_frames[2p], mq[k]), k in [match_off[p], match_off[p+1]);
+ * pairs are applied in order (a later pair overwrites an earlier entry, as the dict does).  Outputs are F x cap:
+ * the first feature of every feature's chain and the number of links followed. */
+int vo_feature_tracks(vo_ctx* ctx, int F, int cap, const int32_t* pair_frames, const int32_t* match_off,
+                      const int32_t* mq, const int32_t* mt, int P, int32_t* root_frame, int32_t* root_idx, int32_t* hops);
+
 /* ------------------------------------------------------------------ measurement
  * With profiling on, every kernel family of the batched path is bracketed by hipEvents on the
  * ctx stream; vo_profile_read returns accumulated milliseconds and launch counts per stage since

@@ -63,3 +63,36 @@ def test_reprojection_filter_edge_cases(ctx):
     assert mf.remove_observations_with_reprojection_errors_above_threshold([], [], [], K) == []
     with pytest.raises(_lib.VoError):
         mf.reprojection_sqerr(np.eye(4)[None], np.zeros((1, 3)), [0], [5], [[0, 0]], K)     # missing point
+
+
+def test_feature_tracks_match_the_reference_dict_walk(ctx, seq_small):
+    """feature_mapper as the reference builds it (a dict keyed by (frame, idx)) against the array version, on real
+    inlier matches of consecutive pairs plus a skip pair that overwrites entries (last assignment wins)."""
+    from visual_odometry_amd import map_filters as mf
+    from visual_odometry_amd.frontend import FrontEnd
+    frames, K = seq_small["frames"], seq_small["K"]
+    fe = FrontEnd(480, 640, max_frames=4, max_pairs=4, nfeatures=500)
+    fe.upload(frames); fe.detect(0, 4)
+    pairs = [[0, 1], [1, 2], [0, 2], [2, 3]]
+    fe.run_pairs(pairs, K)
+    matches = []
+    for p in range(len(pairs)):
+        qi, ti, _, mask = fe.pair_matches(p)
+        matches.append((qi[mask > 0], ti[mask > 0]))
+    cap = fe.kp_cap
+    rf, ri, hops = mf.feature_tracks(4, cap, pairs, matches)
+    mapper = {}
+    for (f1, f2), (q, t) in zip(pairs, matches):          # update_feature_mapper, pair after pair
+        for a, b in zip(q.tolist(), t.tolist()):
+            mapper[(f2, b)] = (f1, a)
+    longest = 0
+    for f in range(4):
+        for i in range(0, cap, 3):
+            fid, n = (f, i), 0
+            while fid in mapper:                          # track_feature_back_in_time
+                fid = mapper[fid]; n += 1
+            assert (rf[f, i], ri[f, i], hops[f, i]) == (fid[0], fid[1], n)
+            longest = max(longest, n)
+    assert longest >= 2
+    with pytest.raises(Exception):
+        mf.feature_tracks(2, 8, [[0, 1], [1, 0]], [(np.array([0]), np.array([0])), (np.array([0]), np.array([0]))])   # a cycle

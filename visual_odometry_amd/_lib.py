@@ -64,6 +64,7 @@ _SIGS = {
     "vo_sync": (C.c_int, [_P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
+    "vo_feature_tracks": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "vo_profile_enable": (C.c_int, [_P, C.c_int]),
     "vo_profile_reset": (C.c_int, [_P]),
     "vo_profile_read": (C.c_int, [_P, _P, _P]),

@@ -1007,3 +1007,43 @@ void launch_reprojection(hipStream_t s, const double* poses, int ncam, const dou
     hipLaunchKernelGGL(k_reprojection, dim3((nobs + 255) / 256), dim3(256), 0, s, poses, ncam, points, npt, obs_cam, obs_pt,
                        obs_xy, nobs, Kd, threshold, sqerr, keep, bad);
 }
+
+// ------------------------------------------------------------------ feature-track bookkeeping
+// src/visual_slam.py:183-188 (update_feature_mapper: feature_mapper[featureid2] = featureid1 for every match of the
+// current pair, later pairs overwrite earlier ones) and :94-99 (track_feature_back_in_time: follow the chain to its
+// first feature).  Feature ids are (frame, index); the dict becomes a [F][cap] table of packed parents.
+__global__ void k_track_link(const int* pair_frames, const int* match_off, const int* mq, const int* mt, int P, int cap,
+                             unsigned long long* parent)
+{
+    const int p = blockIdx.y;
+    const int n = match_off[p + 1] - match_off[p];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f1 = pair_frames[2 * p], f2 = pair_frames[2 * p + 1];
+    const int q = mq[match_off[p] + i], t = mt[match_off[p] + i];
+    // key (pair + 1) in the high bits: an atomic max keeps the LAST pair's entry, as the dict assignment order does
+    const unsigned long long v = ((unsigned long long)(p + 1) << 40) | ((unsigned long long)(unsigned)f1 << 20) | (unsigned)q;
+    atomicMax(&parent[(size_t)f2 * cap + t], v);
+}
+
+__global__ void k_track_roots(const unsigned long long* parent, int F, int cap, int* root_frame, int* root_idx, int* hops, int* bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (i >= cap) return;
+    int cf = f, ci = i, n = 0;
+    for (;;) {
+        const unsigned long long v = parent[(size_t)cf * cap + ci];
+        if (v == 0) break;
+        cf = (int)((v >> 20) & 0xfffffu); ci = (int)(v & 0xfffffu);
+        if (++n > F) { atomicOr(bad, 1); break; }       // a cycle: the reference's while-loop would never end
+    }
+    root_frame[(size_t)f * cap + i] = cf; root_idx[(size_t)f * cap + i] = ci; hops[(size_t)f * cap + i] = n;
+}
+
+void launch_tracks(hipStream_t s, const int* pair_frames, const int* match_off, const int* mq, const int* mt, int P, int max_m,
+                   int F, int cap, unsigned long long* parent, int* root_frame, int* root_idx, int* hops, int* bad)
+{
+    if (P > 0 && max_m > 0)
+        hipLaunchKernelGGL(k_track_link, dim3((max_m + 255) / 256, P), dim3(256), 0, s, pair_frames, match_off, mq, mt, P, cap, parent);
+    hipLaunchKernelGGL(k_track_roots, dim3((cap + 255) / 256, F), dim3(256), 0, s, parent, F, cap, root_frame, root_idx, hops, bad);
+}

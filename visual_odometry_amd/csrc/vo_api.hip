@@ -975,6 +975,59 @@ extern "C" int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam
     return VO_OK;
 }
 
+// ------------------------------------------------------------------ "next" row: feature-track bookkeeping
+extern "C" int vo_feature_tracks(vo_ctx* ctx, int F, int cap, const int32_t* pair_frames, const int32_t* match_off,
+                                 const int32_t* mq, const int32_t* mt, int P, int32_t* root_frame, int32_t* root_idx, int32_t* hops)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (F < 1 || cap < 1 || P < 0 || F >= (1 << 20) || cap >= (1 << 20) || !root_frame || !root_idx || !hops ||
+        (P > 0 && (!pair_frames || !match_off || !mq || !mt))) FAIL(VO_ERR_INVALID, "bad arguments");
+    int total = 0, max_m = 0;
+    for (int p = 0; p < P; p++) {
+        const int n = match_off[p + 1] - match_off[p];
+        if (n < 0 || pair_frames[2 * p] < 0 || pair_frames[2 * p] >= F || pair_frames[2 * p + 1] < 0 || pair_frames[2 * p + 1] >= F)
+            FAIL(VO_ERR_INVALID, "pair %d refers to a missing frame", p);
+        if (n > max_m) max_m = n;
+    }
+    if (P > 0) total = match_off[P] - match_off[0];
+    for (int i = 0; i < total; i++)
+        if (mq[match_off[0] + i] < 0 || mq[match_off[0] + i] >= cap || mt[match_off[0] + i] < 0 || mt[match_off[0] + i] >= cap)
+            FAIL(VO_ERR_INVALID, "match %d refers to a missing feature", i);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t fc = (size_t)F * cap;
+    const size_t n_int = (size_t)2 * P + (P + 1) + (size_t)2 * total + 3 * fc + 16;
+    int rc = ensure_raw_d(ctx, fc + n_int / 2 + 64);                 // parents (u64) + the int arrays
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    unsigned long long* dparent = (unsigned long long*)ctx->raw_d;
+    int* di = (int*)(dparent + fc);
+    int *dpf = di, *doff = dpf + 2 * P, *dq = doff + P + 1, *dt = dq + total, *drf = dt + total, *dri = drf + fc, *dh = dri + fc, *dbad = dh + fc;
+    HIPCHK(hipMemsetAsync(dparent, 0, fc * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(dbad, 0, sizeof(int), s));
+    if (P > 0) {
+        std::vector<int> off(P + 1);
+        for (int p = 0; p <= P; p++) off[p] = match_off[p] - match_off[0];
+        HIPCHK(hipMemcpyAsync(dpf, pair_frames, (size_t)2 * P * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(doff, off.data(), (size_t)(P + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        if (total > 0) {
+            HIPCHK(hipMemcpyAsync(dq, mq + match_off[0], (size_t)total * sizeof(int), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(dt, mt + match_off[0], (size_t)total * sizeof(int), hipMemcpyHostToDevice, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));                              // `off` is a stack vector
+    }
+    { StageTimer t(ctx, ST_MISC); launch_tracks(s, dpf, doff, dq, dt, P, max_m, F, cap, dparent, drf, dri, dh, dbad); }
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(root_frame, drf, fc * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(root_idx, dri, fc * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hops, dh, fc * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    if (bad) FAIL(VO_ERR_INVALID, "the feature map contains a cycle");
+    return VO_OK;
+}
+
 // ------------------------------------------------------------------ measurement
 extern "C" int vo_profile_enable(vo_ctx* ctx, int on)
 {

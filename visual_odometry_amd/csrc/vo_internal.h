@@ -121,3 +121,5 @@ void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, do
 void launch_reprojection(hipStream_t s, const double* poses, int ncam, const double* points, int npt, const int* obs_cam,
                          const int* obs_pt, const double* obs_xy, int nobs, const double* Kd, double threshold,
                          double* sqerr, uint8_t* keep, int* bad);
+void launch_tracks(hipStream_t s, const int* pair_frames, const int* match_off, const int* mq, const int* mt, int P, int max_m,
+                   int F, int cap, unsigned long long* parent, int* root_frame, int* root_idx, int* hops, int* bad);

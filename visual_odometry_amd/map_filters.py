@@ -58,3 +58,25 @@ def calculate_reprojection_error(cameras, points, observations, camera_matrix, c
     for e in err.tolist():
         total += e
     return total
+
+
+def feature_tracks(n_frames, cap, pair_frames, matches, ctx=None):
+    """update_feature_mapper + track_feature_back_in_time (visual_slam.py:183-188, :94-99) for every feature at once.
+
+    pair_frames: [P, 2] frame ids (f1, f2); matches: list of P (q_idx, t_idx) int arrays — the matches with 3-D
+    information of each pair, in the order the reference would process the pairs.  Returns (root_frame, root_idx,
+    hops), each [n_frames, cap]: feature (f, i) traces back to (root_frame[f, i], root_idx[f, i])."""
+    pf = np.ascontiguousarray(pair_frames, np.int32).reshape(-1, 2)
+    P = len(pf)
+    off = np.zeros(P + 1, np.int32)
+    for p, (q, t) in enumerate(matches):
+        if len(q) != len(t):
+            raise ValueError("q and t differ in length")
+        off[p + 1] = off[p] + len(q)
+    mq = np.ascontiguousarray(np.concatenate([np.asarray(q, np.int32) for q, _ in matches]) if P else np.zeros(0, np.int32))
+    mt = np.ascontiguousarray(np.concatenate([np.asarray(t, np.int32) for _, t in matches]) if P else np.zeros(0, np.int32))
+    rf = np.zeros((n_frames, cap), np.int32); ri = np.zeros((n_frames, cap), np.int32); hops = np.zeros((n_frames, cap), np.int32)
+    ctx = ctx or _lib.default_context()
+    ctx.check(ctx.lib.vo_feature_tracks(ctx.handle, int(n_frames), int(cap), pf.ctypes.data, off.ctypes.data, mq.ctypes.data,
+                                        mt.ctypes.data, P, rf.ctypes.data, ri.ctypes.data, hops.ctypes.data))
+    return rf, ri, hops
