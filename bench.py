@@ -113,6 +113,8 @@ def main():
                     help="sequence: C+1 consecutive frames -> C pairs, each frame detected once (BASELINE config 2); "
                          "independent: C pairs with their own two frames each, 2C detections (BASELINE config 4 accounting)")
     ap.add_argument("--contexts", type=int, default=2, help="contexts (streams) per GPU alternating over the chunks")
+    ap.add_argument("--chain-detect", type=int, default=1,
+                    help="1: a context's detection starts after the previous context's detection (software pipeline)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the multi-process path on a box with fewer GPUs than ranks (all ranks share GPU 0)")
     args = ap.parse_args()
@@ -192,7 +194,7 @@ def main():
         if in_flight[k] is not None:
             f.wait()
             consume(in_flight[k])
-        f.detect(0, NF, wait=False)                       # sequence mode: each frame detected once
+        f.detect(0, NF, wait=False, after=fes[(k - 1) % n_ctx] if args.chain_detect else None)
         in_flight[k], _ = f.run_pairs(pairs, K, opts, wait=False)
 
     def drain():

@@ -156,6 +156,9 @@ int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K,
 int vo_pairs_run_async(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
                        vo_pair_result* results, double* X, int32_t x_cap);
 int vo_sync(vo_ctx* ctx);
+/* Orders ctx's next enqueued work after `other`'s most recent vo_frames_detect_async (same device).  Chaining the
+ * detections of two contexts keeps them out of phase: one's RANSAC / pose always runs beside the other's ORB. */
+int vo_detect_after(vo_ctx* ctx, vo_ctx* other);
 /* per-pair match list of the last vo_pairs_run (capacity cap each) */
 int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* dist, uint8_t* inlier_mask,
                     int cap, int32_t* n_out);

@@ -62,6 +62,7 @@ _SIGS = {
     "vo_pairs_run": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
     "vo_pairs_run_async": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
     "vo_sync": (C.c_int, [_P]),
+    "vo_detect_after": (C.c_int, [_P, _P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
     "vo_feature_tracks": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),

@@ -258,7 +258,7 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
 // (x2^T E x1 = 0, unit Frobenius norm) to Eout and returns their number.
 // cm: this lane's slice of the 10x20 elimination matrix in LDS, element (r, k) at cm[(r*20 + k) * FP_LANES]
 // (consecutive lanes hold consecutive doubles: conflict-free ds_read/write_b64).
-#define FP_LANES 64
+#define FP_LANES 32
 #define CM(r, k) cm[((r) * 20 + (k)) * FP_LANES]
 typedef __attribute__((address_space(3))) double lds_double;
 __device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout, lds_double* cm)
@@ -533,16 +533,18 @@ __device__ __forceinline__ int count_inliers(const double* E, const double* x1, 
 }
 
 // ------------------------------------------------------------------ RANSACPointSetRegistrator::run, one workgroup (4 waves) per pair
-// Round = 64 minimal samples.  (1) sample indices: the RNG stream (OpenCV's MWC, data independent) is read
+// Round = RS_ROUND (32) minimal samples — the adaptive count ends at 9..30 on textured pairs, so one round is the
+// common case; the elimination matrices (51 KB) are the only large LDS user and the models live in global memory
+// (L2), so the other context's streaming kernels keep most of the CU's LDS while this latency-bound kernel runs.  (1) sample indices: the RNG stream (OpenCV's MWC, data independent) is read
 // from a table, `% M` is taken by all threads in parallel, thread 0 only applies the repeat rejection;
-// (2) wave 0 solves the 64 samples, one per lane, elimination matrices and models in LDS; (3) the models
+// (2) wave 0 solves the samples, one per lane, elimination matrices in LDS; (3) the models
 // are scored four at a time (one per wave, ballot + popcount over the correspondences) and consumed strictly
 // in OpenCV's order, so the adaptive iteration count and the strict `>` rule behave as in the serial loop.
-#define RS_STREAM 448
+#define RS_STREAM 256
+#define RS_ROUND FP_LANES
 
 struct RansacShared {
-    double cm[200 * FP_LANES];          // 102400 B
-    double models[64 * 90];             //  46080 B
+    double cm[200 * FP_LANES];          // 51200 B
     uint32_t stream[RS_STREAM];
     int sub[64][5];
     int nm[64];
@@ -594,8 +596,9 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
 #ifdef VO_EXP_TIMING
     long long tA = clock64(), tB = 0, tC = 0, tD = 0, tE = 0;
 #endif
-    for (int r0 = 0; r0 < niters; r0 += 64) {
-        const int nh = min(64, niters - r0);
+    double* gmodels = pb.models + (size_t)p * 64 * 90;
+    for (int r0 = 0; r0 < niters; r0 += RS_ROUND) {
+        const int nh = min(RS_ROUND, niters - r0);
         // (1) sample indices
         for (int i = tid; i < RS_STREAM; i += 256) sh.stream[i] = pos + i < rng_n ? rng_tab[pos + i] % (uint32_t)M : 0u;
         __syncthreads();
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                     s1[2 * i] = x1[2 * v]; s1[2 * i + 1] = x1[2 * v + 1];
                     s2[2 * i] = x2[2 * v]; s2[2 * i + 1] = x2[2 * v + 1];
                 }
-                nm = five_point_solve(s1, s2, sh.models + lane * 90, (lds_double*)sh.cm + lane);
+                nm = five_point_solve(s1, s2, gmodels + lane * 90, (lds_double*)sh.cm + lane);
             }
             sh.nm[lane] = nm;
             // exclusive prefix of the model counts + flattened (sample, model) list
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                 const int h = sh.eh[e], m = e - sh.off[h];
                 double E[9];
 #pragma unroll
-                for (int k = 0; k < 9; k++) E[k] = sh.models[h * 90 + m * 9 + k];
+                for (int k = 0; k < 9; k++) E[k] = gmodels[h * 90 + m * 9 + k];
                 const int good = count_inliers(E, x1, x2, M, t, lane, 64, 0, nullptr);
                 if (lane == 0) sh.cnt[b & 1][wave] = good;
             }
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                 if (good > max(max_good, 4)) {
                     const int m = e2 - sh.off[h];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) bestE[k] = sh.models[h * 90 + m * 9 + k];
+                    for (int k = 0; k < 9; k++) bestE[k] = gmodels[h * 90 + m * 9 + k];
                     max_good = good;
                     niters = ransac_update_num_iters(rp.prob, (double)(M - good) / M, 5, niters);
                 }

@@ -1,4 +1,4 @@
-// match_kernels.hip — brute-force Hamming matcher on gfx950 (XOR + popcount; no MFMA).
+// match_kernels.hip — brute-force Hamming matcher on gfx950 (int8 MFMA over +1/-1 expanded descriptors).
 //
 // Replaces `self.matcher.match(d1, d2)` for cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True)
 // (reference: src/image_pair.py:234-236, matcher built at src/visual_slam.py:18 and
@@ -8,94 +8,165 @@
 #include "vo_internal.h"
 #include <limits.h>
 
-#define NN_TILE 256
-
-struct Desc { uint4 a, b; };
-
-__device__ __forceinline__ int hamming(const Desc& x, const uint4& ya, const uint4& yb)
+// ------------------------------------------------------------------ Hamming matrix on the matrix cores
+// 256-bit Hamming distance is a dot product once the bits are written as +1 / -1 bytes:
+// sum_k a_k b_k = 256 - 2 * hamming, exact in int32.  The descriptor sets of a pair are a 2000 x 2000 x 256
+// contraction, the one GEMM-shaped piece of the path (compute bound: 2 GOP per pair and direction against
+// 128 KB of operands), so it runs on v_mfma_i32_16x16x64_i8 and the VALU only folds the 16x16 accumulator
+// blocks into the running (distance, index) keys: 2 instructions per distance instead of the 16 of XOR+popcount.
+//
+// Expanded layout (k_desc_expand, once per frame): [frame][group = row / 16][chunk 0..15][row % 16][16 B], i.e.
+// the 16 bytes lane l of an MFMA operand needs for k-step s (row l & 15, chunk 4 s + (l >> 4)) of 16 rows are one
+// contiguous KB -> fully coalesced 16-byte loads, conflict-free ds_read_b128, straight copies into LDS.
+__device__ __forceinline__ uint32_t expand4(uint32_t nib)
 {
-    return __popc(x.a.x ^ ya.x) + __popc(x.a.y ^ ya.y) + __popc(x.a.z ^ ya.z) + __popc(x.a.w ^ ya.w) +
-           __popc(x.b.x ^ yb.x) + __popc(x.b.y ^ yb.y) + __popc(x.b.z ^ yb.z) + __popc(x.b.w ^ yb.w);
+    const uint32_t m = (nib * 0x00204081u) & 0x01010101u;     // bit i -> byte i
+    return ~(m * 0xfeu);                                       // 1 -> 0x01 (+1), 0 -> 0xff (-1)
 }
 
-// nearest (and optionally second nearest) row of B for every row of A.  One lane holds NN_Q rows of A in
-// registers; B is streamed through LDS in tiles and read as wave-wide broadcasts (ds_read_b128, one read
-// serves NN_Q distances); 256-bit Hamming distance = 8 x (v_xor, v_bcnt accumulate).
-#define NN_Q 2
-#define NN_ROWS_PER_BLOCK (256 * NN_Q)
-
-template <bool KNN2>
-__device__ __forceinline__ void nn_body(const uint8_t* A, int na, const uint8_t* B, int nb,
-                                        int* idx, int* dist, int* idx2, int* dist2)
+__global__ __launch_bounds__(256) void k_desc_expand(const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x)
 {
-    __shared__ uint4 s_b[NN_TILE * 2];
-    const int tid = threadIdx.x;
-    Desc me[NN_Q];
-    int row[NN_Q];
-    // best / second best as one key (distance << 16 | train row): an unsigned min is the ascending scan with
-    // strict `<` (lowest row wins ties); rows < 65536 is guaranteed by the keypoint capacity check
-    uint32_t k0[NN_Q], k1[NN_Q];
-#pragma unroll
-    for (int q = 0; q < NN_Q; q++) {
-        row[q] = blockIdx.x * NN_ROWS_PER_BLOCK + q * 256 + tid;
-        me[q].a = make_uint4(0, 0, 0, 0); me[q].b = me[q].a;
-        if (row[q] < na) { me[q].a = *(const uint4*)(A + (size_t)row[q] * 32); me[q].b = *(const uint4*)(A + (size_t)row[q] * 32 + 16); }
-        k0[q] = 0xffffffffu; k1[q] = 0xffffffffu;
-    }
-    for (int base = 0; base < nb; base += NN_TILE) {
-        const int j = base + tid;
-        __syncthreads();
-        if (j < nb) { s_b[2 * tid] = *(const uint4*)(B + (size_t)j * 32); s_b[2 * tid + 1] = *(const uint4*)(B + (size_t)j * 32 + 16); }
-        __syncthreads();
-        const int lim = min(NN_TILE, nb - base);
-#pragma unroll 4
-        for (int k = 0; k < lim; k++) {
-            const uint4 ba = s_b[2 * k], bb = s_b[2 * k + 1];
-#pragma unroll
-            for (int q = 0; q < NN_Q; q++) {
-                const uint32_t key = ((uint32_t)hamming(me[q], ba, bb) << 16) | (uint32_t)(base + k);
-                if (KNN2) k1[q] = min(k1[q], max(k0[q], key));
-                k0[q] = min(k0[q], key);
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NN_Q; q++) {
-        if (row[q] < na) {
-            const bool has0 = k0[q] != 0xffffffffu, has1 = k1[q] != 0xffffffffu;
-            idx[row[q]] = has0 ? (int)(k0[q] & 0xffffu) : -1; dist[row[q]] = has0 ? (int)(k0[q] >> 16) : INT_MAX;
-            if (KNN2) { idx2[row[q]] = has1 ? (int)(k1[q] & 0xffffu) : -1; dist2[row[q]] = has1 ? (int)(k1[q] >> 16) : INT_MAX; }
-        }
-    }
+    const int f = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;              // t = (group * 16 + chunk) * 16 + row % 16
+    if (t >= cap_x * 16) return;
+    const int i = t & 15, c = (t >> 4) & 15, row = (t >> 8) * 16 + i;
+    uint32_t bits = 0;
+    if (row < min(kp_count[f], kp_cap)) bits = *(const uint16_t*)(desc + ((size_t)f * kp_cap + row) * 32 + 2 * c);
+    const uint4 o = make_uint4(expand4(bits & 15u), expand4((bits >> 4) & 15u), expand4((bits >> 8) & 15u), expand4(bits >> 12));
+    *(uint4*)(desc_x + ((size_t)f * cap_x * 16 + t) * 16) = o;
 }
 
-template <bool KNN2>
-__global__ __launch_bounds__(256) void k_nn_pairs(const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb,
-                                                  int dir_first)
+void launch_desc_expand(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int F)
 {
-    const int p = blockIdx.y, dir = dir_first + blockIdx.z;
+    if (F <= 0) return;
+    hipLaunchKernelGGL(k_desc_expand, dim3((cap_x * 16 + 255) / 256, F), dim3(256), 0, s, desc, kp_count, kp_cap, cap_x, desc_x);
+}
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+#define MM_STAGE_ROWS 64                  // rows of B per LDS stage (4 groups of 16, 16 KB), double buffered
+#ifndef MM_WAVES
+#define MM_WAVES 8
+#endif
+#ifndef MM_RB
+#define MM_RB 4                           // 16-row blocks of A per wave, held in registers as MFMA fragments
+#endif
+#define MM_THREADS (MM_WAVES * 64)
+#define MM_WAVE_ROWS (MM_RB * 16)
+#define MM_BLOCK_ROWS (MM_WAVES * MM_WAVE_ROWS)
+#define MM_LD (MM_STAGE_ROWS * 256 / 16 / MM_THREADS)   // 16-byte staging loads per thread and stage
+
+// Nearest (and second nearest) row of B for every row of A.  key = (dot + 256) << 16 | (65535 - j): a signed max
+// is OpenCV's ascending scan with strict `<` (smaller distance first, then the lower index); columns beyond nb
+// start from a large negative accumulator and can never win.
+template <bool KNN2>
+__global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x,
+                                                 PairBuf pb, int dir_first, int row_blocks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[2][MM_STAGE_ROWS * 256];
+    // all row blocks of a pair on one XCD: the other frame's expanded descriptors (0.5 MB) are then read from HBM /
+    // Infinity Cache once per pair and shared through that XCD's L2
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int p = bid / row_blocks, dir = dir_first + blockIdx.z;
     const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
     const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
-    if ((int)(blockIdx.x * NN_ROWS_PER_BLOCK) >= na) return;
-    const size_t o = ((size_t)p * 2 + dir) * kp_cap;
-    nn_body<KNN2>(desc + (size_t)fa * kp_cap * 32, na, desc + (size_t)fb * kp_cap * 32, nb,
-                  pb.nn_idx + o, pb.nn_dist + o, pb.nn_idx2 + (size_t)p * kp_cap, pb.nn_dist2 + (size_t)p * kp_cap);
+    const int row0 = (bid % row_blocks) * MM_BLOCK_ROWS;
+    if (row0 >= na) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const uint8_t* A = desc_x + (size_t)fa * cap_x * 256;
+    const uint8_t* B = desc_x + (size_t)fb * cap_x * 256;
+    const int wrow0 = row0 + wave * MM_WAVE_ROWS;
+
+    v4i a[MM_RB][4];
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            a[rb][s] = wrow0 < na ? *(const v4i*)(A + ((size_t)((wrow0 >> 4) + rb) * 16 + 4 * s + lg) * 256 + li * 16) : (v4i){0, 0, 0, 0};
+
+    const v4i c_ok = {256, 256, 256, 256}, c_bad = {-16384, -16384, -16384, -16384};
+    v4i best[MM_RB], best2[MM_RB];
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++) { best[rb] = (v4i){INT_MIN, INT_MIN, INT_MIN, INT_MIN}; best2[rb] = best[rb]; }
+
+    // B streams through two LDS buffers by LDS-DMA (global_load_lds_dwordx4: a wave-instruction copies one
+    // contiguous KB, no staging registers): stage sg + 1 is in flight while stage sg feeds the MFMAs
+    const int nstages = (nb + MM_STAGE_ROWS - 1) / MM_STAGE_ROWS;
+    const bool active = wrow0 < na;                             // wave-uniform; idle waves still take the barriers
+#define MM_GLDS(stage, buf)                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < MM_LD; q++)                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)(stage) * (MM_STAGE_ROWS * 256) + (size_t)(q * MM_THREADS + tid) * 16), \
+                                         (__attribute__((address_space(3))) void*)(s_b[buf] + (q * MM_THREADS + wave * 64) * 16), 16, 0, 0)
+    if (nstages > 0) { MM_GLDS(0, 0); }
+    for (int sg = 0; sg < nstages; sg++) {
+        __syncthreads();                                        // stage sg has landed; buffer (sg + 1) & 1 is free
+        if (sg + 1 < nstages) { MM_GLDS(sg + 1, (sg + 1) & 1); }
+        const uint8_t* sb = s_b[sg & 1];
+        const int ng = active ? min(4, (nb - sg * MM_STAGE_ROWS + 15) >> 4) : 0;
+        for (int g = 0; g < ng; g++) {
+            const int j0 = sg * MM_STAGE_ROWS + g * 16;
+            v4i cin = c_ok;
+            if (j0 + 16 > nb && j0 + li >= nb) cin = c_bad;
+            v4i b[4], acc[MM_RB];
+#pragma unroll
+            for (int s = 0; s < 4; s++) b[s] = *(const v4i*)(sb + g * 4096 + (4 * s + lg) * 256 + li * 16);
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][0], b[0], cin, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < 4; s++)
+#pragma unroll
+                for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][s], b[s], acc[rb], 0, 0, 0);
+            const uint32_t jr = 65535u - (uint32_t)(j0 + li);
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = (int)(((uint32_t)acc[rb][r] << 16) | jr);
+                    if (KNN2) best2[rb][r] = max(best2[rb][r], min(best[rb][r], key));
+                    best[rb][r] = max(best[rb][r], key);
+                }
+        }
+    }
+#undef MM_GLDS
+
+    const size_t o = ((size_t)p * 2 + dir) * kp_cap, o2 = (size_t)p * kp_cap;
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int k0 = best[rb][r], k1 = best2[rb][r];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int u0 = __shfl_xor(k0, d, 64), u1 = __shfl_xor(k1, d, 64);
+                if (KNN2) k1 = max(max(k1, u1), min(k0, u0));
+                k0 = max(k0, u0);
+            }
+            const int row = wrow0 + rb * 16 + lg * 4 + r;
+            if (li == 0 && row < na) {
+                pb.nn_idx[o + row] = k0 >= 0 ? 65535 - (k0 & 0xffff) : -1;
+                pb.nn_dist[o + row] = k0 >= 0 ? (512 - (k0 >> 16)) >> 1 : INT_MAX;
+                if (KNN2) {
+                    pb.nn_idx2[o2 + row] = k1 >= 0 ? 65535 - (k1 & 0xffff) : -1;
+                    pb.nn_dist2[o2 + row] = k1 >= 0 ? (512 - (k1 >> 16)) >> 1 : INT_MAX;
+                }
+            }
+        }
 }
 
 // dirs_mask: bit 0 = forward (frame1 -> frame2), bit 1 = reverse. knn2 applies to the forward direction.
-void launch_match_nn(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb, int P,
+void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,
                      int dirs_mask, int knn2)
 {
     if (P <= 0) return;
-    dim3 block(256);
-    const int gx = (kp_cap + NN_ROWS_PER_BLOCK - 1) / NN_ROWS_PER_BLOCK;
+    dim3 block(MM_THREADS);
+    const int gx = (kp_cap + MM_BLOCK_ROWS - 1) / MM_BLOCK_ROWS;
     if (knn2) {
-        hipLaunchKernelGGL(k_nn_pairs<true>, dim3(gx, P, 1), block, 0, s, desc, kp_count, kp_cap, pb, 0);
+        hipLaunchKernelGGL(k_nn_mfma<true>, dim3(gx * P, 1, 1), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 0, gx);
         return;
     }
-    if (dirs_mask == 3) hipLaunchKernelGGL(k_nn_pairs<false>, dim3(gx, P, 2), block, 0, s, desc, kp_count, kp_cap, pb, 0);
-    else if (dirs_mask == 1) hipLaunchKernelGGL(k_nn_pairs<false>, dim3(gx, P, 1), block, 0, s, desc, kp_count, kp_cap, pb, 0);
-    else if (dirs_mask == 2) hipLaunchKernelGGL(k_nn_pairs<false>, dim3(gx, P, 1), block, 0, s, desc, kp_count, kp_cap, pb, 1);
+    if (dirs_mask == 3) hipLaunchKernelGGL(k_nn_mfma<false>, dim3(gx * P, 1, 2), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 0, gx);
+    else if (dirs_mask == 1) hipLaunchKernelGGL(k_nn_mfma<false>, dim3(gx * P, 1, 1), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 0, gx);
+    else if (dirs_mask == 2) hipLaunchKernelGGL(k_nn_mfma<false>, dim3(gx * P, 1, 1), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 1, gx);
 }
 
 // ------------------------------------------------------------------ match selection + ordered compaction, one workgroup per pair

@@ -19,14 +19,6 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 __constant__ int c_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
 
 // ------------------------------------------------------------------ XCD-aware tile order
-// Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2).  Neighbouring
-// image tiles share halo rows/columns and 128-byte lines, so tile indices are remapped to give every XCD one
-// contiguous run of tiles (bijective for any n; placement is a speed matter only, never correctness).
-__device__ __forceinline__ int xcd_tile(int b, int n)
-{
-    const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
 
 // ------------------------------------------------------------------ block-wide exclusive scan (<= 1024 threads)
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
@@ -916,8 +908,15 @@ void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom
 
 // ------------------------------------------------------------------ steered BRIEF (orb.cpp computeOrbDescriptors, WTA_K = 2)
 // One wavefront per keypoint; lane j evaluates tests j, 64 + j, 128 + j, 192 + j; each ballot is 64
-// descriptor bits (8 bytes, LSB first).  Also writes the exported keypoint record.
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff)
+// descriptor bits (8 bytes, LSB first).  Also writes the exported keypoint record and the descriptor's +1 / -1
+// byte image for the MFMA matcher (layout: vo_internal.h desc_x_rows; lane c < 16 expands bits 16c .. 16c + 15).
+__device__ __forceinline__ uint32_t brief_expand4(uint32_t nib)
+{
+    const uint32_t m = (nib * 0x00204081u) & 0x01010101u;
+    return ~(m * 0xfeu);
+}
+
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff, uint8_t* desc_x, int cap_x)
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -951,13 +950,20 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
         uint64_t wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
         *(uint64_t*)(ff.desc + ki * 32 + lane * 8) = wv;
     }
+    if (lane < 16) {
+        const uint64_t wv = lane < 4 ? words[0] : lane < 8 ? words[1] : lane < 12 ? words[2] : words[3];
+        const uint32_t bits = (uint32_t)(wv >> (16 * (lane & 3))) & 0xffffu;
+        const uint4 o = make_uint4(brief_expand4(bits & 15u), brief_expand4((bits >> 4) & 15u), brief_expand4((bits >> 8) & 15u), brief_expand4(bits >> 12));
+        *(uint4*)(desc_x + (((size_t)f * cap_x + (k & ~15)) * 16 + (size_t)lane * 16 + (k & 15)) * 16) = o;
+    }
     if (lane == 0) {
         ff.kp_xy[ki * 2] = kx; ff.kp_xy[ki * 2 + 1] = ky;
         ff.kp_size[ki] = 31 * sf;
     }
 }
 
-void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F)
+// desc_x: this launch's first frame, cap_x rows of 256 B per frame
+void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x)
 {
-    hipLaunchKernelGGL(k_brief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, s, blur, g, ff);
+    hipLaunchKernelGGL(k_brief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x);
 }

@@ -21,6 +21,7 @@ struct vo_ctx {
     ResizeTab tabs[VO_MAX_LEVELS]{};
     void* tab_mem = nullptr;
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
+    uint8_t* desc_x = nullptr;            // descriptors expanded to +1 / -1 bytes for the MFMA matcher
     int *sel_thr = nullptr, *sel_chunk_count = nullptr, *har_kept = nullptr;
     float* har_thr = nullptr;
     size_t staging_bytes = 0;
@@ -32,7 +33,7 @@ struct vo_ctx {
 
     // scratch for the single-call operators
     int raw_cap = 0;
-    uint8_t* raw_desc = nullptr; float* raw_xy = nullptr; int* raw_count = nullptr;
+    uint8_t* raw_desc = nullptr; float* raw_xy = nullptr; int* raw_count = nullptr; uint8_t* raw_desc_x = nullptr;
     PairBuf raw_pb{};
     double* raw_d = nullptr; size_t raw_d_n = 0;     // generic double scratch
     uint32_t* rng_tab = nullptr; uint64_t rng_seed = 0; bool rng_valid = false;   // OpenCV RNG stream for the RANSAC seed
@@ -45,6 +46,8 @@ struct vo_ctx {
     int ev_stage[MAX_EVENTS];
     int n_ev = 0;
     bool ev_ready = false;
+    hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
+    bool ev_det_set = false;
 };
 
 static const char* k_stage_names[VO_STAGE_COUNT] = {
@@ -212,9 +215,9 @@ static void free_config(vo_ctx* c)
 {
     void* ptrs[] = {c->tab_mem, c->pyr, c->blur, c->score, c->ff.cand_pos, c->ff.cand_resp, c->ff.cand_count,
                     c->ff.kp_pos, c->ff.kp_level, c->ff.kp_resp, c->ff.kp_angle, c->ff.kp_xy, c->ff.kp_size,
-                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->sel_thr, c->sel_chunk_count, c->har_kept, c->har_thr};
+                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->sel_thr, c->sel_chunk_count, c->har_kept, c->har_thr, c->desc_x};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr; c->sel_thr = c->sel_chunk_count = c->har_kept = nullptr; c->har_thr = nullptr;
+    c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr; c->desc_x = nullptr; c->sel_thr = c->sel_chunk_count = c->har_kept = nullptr; c->har_thr = nullptr;
     memset(&c->ff, 0, sizeof(c->ff));
     free_pairbuf(c->pb);
     c->pb_pairs = c->pb_cap = 0;
@@ -238,6 +241,7 @@ extern "C" int vo_create(int device_id, vo_ctx** out)
     }
     for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventCreate(&ctx->ev[i][0]); (void)hipEventCreate(&ctx->ev[i][1]); }
     ctx->ev_ready = true;
+    (void)hipEventCreateWithFlags(&ctx->ev_det, hipEventDisableTiming);
     *out = ctx;
     return VO_OK;
 }
@@ -249,9 +253,10 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_config(ctx);
     free_pairbuf(ctx->raw_pb);
-    void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab};
+    void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab, ctx->raw_desc_x};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
+    if (ctx->ev_det) (void)hipEventDestroy(ctx->ev_det);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -320,6 +325,7 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     HIPCHK(dmalloc(&ff.kp_resp, F * g.kp_cap)); HIPCHK(dmalloc(&ff.kp_angle, F * g.kp_cap));
     HIPCHK(dmalloc(&ff.kp_xy, F * g.kp_cap * 2)); HIPCHK(dmalloc(&ff.kp_size, F * g.kp_cap));
     HIPCHK(dmalloc(&ff.desc, F * g.kp_cap * 32));
+    HIPCHK(dmalloc(&ctx->desc_x, F * (size_t)desc_x_rows(g.kp_cap) * 256));
     HIPCHK(dmalloc(&ff.kp_count, F)); HIPCHK(dmalloc(&ff.flags, F));
     HIPCHK(dmalloc(&ff.hist, F * VO_MAX_LEVELS * 256));
     HIPCHK(dmalloc(&ctx->sel_thr, F * VO_MAX_LEVELS));
@@ -416,7 +422,11 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F, ctx->har_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->har_kept + (size_t)first_slot * VO_MAX_LEVELS); }
     { StageTimer t(ctx, ST_ANGLE); launch_angle(s, pyr, g, ff, F); }
     { StageTimer t(ctx, ST_BLUR); launch_blur(s, pyr, blur, g, F); }
-    { StageTimer t(ctx, ST_BRIEF); launch_brief(s, blur, g, ff, F); }
+    {
+        StageTimer t(ctx, ST_BRIEF);
+        const int cx = desc_x_rows(g.kp_cap);
+        launch_brief(s, blur, g, ff, F, ctx->desc_x + (size_t)first_slot * cx * 256, cx);
+    }
     return VO_OK;
 }
 
@@ -447,6 +457,22 @@ extern "C" int vo_frames_detect_async(vo_ctx* ctx, int first_slot, int F)
     int rc = run_detect(ctx, first_slot, F, 2);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev_det, ctx->stream));
+    ctx->ev_det_set = true;
+    return VO_OK;
+}
+
+// Software pipelining over two contexts of one GPU: ctx's next work starts only after `other`'s most recent
+// vo_frames_detect_async has finished.  Chaining the detections (A.detect -> B.detect -> A.detect ...) keeps the
+// two contexts out of phase, so each one's latency-bound RANSAC / pose kernels always run beside the other's
+// issue-bound ORB kernels instead of beside its RANSAC.
+extern "C" int vo_detect_after(vo_ctx* ctx, vo_ctx* other)
+{
+    if (!ctx || !other) return VO_ERR_INVALID;
+    if (ctx->device != other->device) FAIL(VO_ERR_INVALID, "the two contexts are on different devices");
+    if (ctx == other || !other->ev_det_set) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, other->ev_det, 0));
     return VO_OK;
 }
 
@@ -601,15 +627,16 @@ static int ensure_rng(vo_ctx* ctx, uint64_t seed)
 
 static int map_select_mode(int match_mode) { return match_mode == 0 ? 1 : 3; }
 
-static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const float* kp_xy, const int* kp_count, int cap,
+static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc_x, const float* kp_xy, const int* kp_count, int cap,
                      int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points)
 {
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemsetAsync(pb.res, 0, (size_t)P * sizeof(vo_pair_result), s));
     {
         StageTimer t(ctx, ST_MATCH_NN);
-        if (select_mode == 3) launch_match_nn(s, desc, kp_count, cap, pb, P, 1, 1);
-        else launch_match_nn(s, desc, kp_count, cap, pb, P, select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3, 0);
+        const int cx = desc_x_rows(cap);
+        if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1);
+        else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3, 0);
     }
     { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
     if (!do_geometry) return VO_OK;
@@ -641,7 +668,7 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
     rp.seed = opts->ransac_seed; rp.dist_thresh = opts->pose_dist_thresh;
     memcpy(rp.K, K, sizeof(rp.K));
     const bool wp = opts->want_points != 0;
-    int rc = run_pairs(ctx, ctx->pb, ctx->ff.desc, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
+    int rc = run_pairs(ctx, ctx->pb, ctx->desc_x, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
                        map_select_mode(opts->match_mode), opts->ratio, rp, true, wp);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -726,10 +753,11 @@ static int ensure_raw(vo_ctx* ctx, int cap)
     cap = align_up(cap + cap / 4 + 64, 64);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     free_pairbuf(ctx->raw_pb);
-    void* ptrs[] = {ctx->raw_desc, ctx->raw_xy, ctx->raw_count};
+    void* ptrs[] = {ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_desc_x};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    ctx->raw_desc = nullptr; ctx->raw_xy = nullptr; ctx->raw_count = nullptr; ctx->raw_cap = 0;
+    ctx->raw_desc = nullptr; ctx->raw_xy = nullptr; ctx->raw_count = nullptr; ctx->raw_desc_x = nullptr; ctx->raw_cap = 0;
     HIPCHK(dmalloc(&ctx->raw_desc, (size_t)2 * cap * 32));
+    HIPCHK(dmalloc(&ctx->raw_desc_x, (size_t)2 * desc_x_rows(cap) * 256));
     HIPCHK(dmalloc(&ctx->raw_xy, (size_t)2 * cap * 2));
     HIPCHK(dmalloc(&ctx->raw_count, 2));
     HIPCHK(hipMemset(ctx->raw_xy, 0, (size_t)2 * cap * 2 * sizeof(float)));
@@ -759,7 +787,8 @@ static int match_raw(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, in
     HIPCHK(hipMemcpyAsync(ctx->raw_pb.slots, slots, sizeof(slots), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->dK, Kid, sizeof(Kid), hipMemcpyHostToDevice, s));
     RansacParams rp{};
-    rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false);
+    { StageTimer tm(ctx, ST_BRIEF); launch_desc_expand(s, ctx->raw_desc, ctx->raw_count, cap, desc_x_rows(cap), ctx->raw_desc_x, 2); }
+    rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc_x, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     int n = 0;

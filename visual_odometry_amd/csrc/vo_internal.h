@@ -105,9 +105,22 @@ void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFea
 void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, float* thr, int* kept);
 void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F);
-void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F);
+void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x);
 
-void launch_match_nn(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb, int P,
+// Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2).  Neighbouring
+// work items share data (image tiles: halo rows and 128-byte lines; the row blocks of a pair: the other frame's
+// descriptors), so indices are remapped to give every XCD one
+// contiguous run of tiles (bijective for any n; placement is a speed matter only, never correctness).
+__device__ __forceinline__ int xcd_tile(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// expanded descriptors: [frame][cap_x / 16][16 chunks][16 rows][16 B] of +1 / -1 bytes, cap_x = desc_x_rows(kp_cap)
+static inline int desc_x_rows(int kp_cap) { return (kp_cap + 255) & ~255; }
+void launch_desc_expand(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int F);
+void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,
                      int dirs_mask, int knn2);
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
                          int mode, double ratio, const double* K);

@@ -41,10 +41,13 @@ class FrontEnd:
             c.check(c.lib.vo_frames_upload_color(c.handle, f.ctypes.data, f.shape[0], f.shape[3], f.strides[1], f.strides[0],
                                                  int(first_slot)))
 
-    def detect(self, first_slot, count, wait=True):
+    def detect(self, first_slot, count, wait=True, after=None):
         """ORB detect + describe of `count` resident slots. wait=False only enqueues the work on the ctx stream;
-        the next run_pairs (same stream) is ordered after it."""
+        the next run_pairs (same stream) is ordered after it.  after=<another FrontEnd on this GPU>: start only when
+        that one's latest asynchronous detection has finished (keeps two alternating contexts out of phase)."""
         c = self.ctx
+        if after is not None and after is not self:
+            c.check(c.lib.vo_detect_after(c.handle, after.ctx.handle))
         fn = c.lib.vo_frames_detect if wait else c.lib.vo_frames_detect_async
         c.check(fn(c.handle, int(first_slot), int(count)))
 
