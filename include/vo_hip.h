@@ -130,6 +130,9 @@ typedef struct {
 int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params* params, int max_frames, int max_pairs);
 /* copy F gray frames (u8, row_stride/frame_stride in bytes) into slots [first_slot, first_slot+F) */
 int vo_frames_upload(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot);
+/* Same, enqueue only: `frames` should be page-locked (vo_host_alloc) and must stay unchanged until vo_sync(ctx).
+ * Streaming drivers alternate two contexts: one's upload (DMA) runs beside the other's kernels. */
+int vo_frames_upload_async(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot);
 /* same for BGR (channels 3) / BGRA (4) frames: converted to gray on the device (cv2's BGR2GRAY, as ORB does) */
 int vo_frames_upload_color(vo_ctx* ctx, const uint8_t* frames, int F, int channels, int row_stride,
                            int64_t frame_stride, int first_slot);

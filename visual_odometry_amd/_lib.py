@@ -52,6 +52,7 @@ _SIGS = {
     "vo_stage_five_point": (C.c_int, [_P, _P, _P, _P, _P]),
     "vo_batch_configure": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int]),
     "vo_frames_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int]),
+    "vo_frames_upload_async": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int]),
     "vo_frames_upload_color": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]),
     "vo_frames_detect": (C.c_int, [_P, C.c_int, C.c_int]),
     "vo_frames_detect_async": (C.c_int, [_P, C.c_int, C.c_int]),

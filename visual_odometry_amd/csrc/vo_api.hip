@@ -340,21 +340,43 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     return VO_OK;
 }
 
-extern "C" int vo_frames_upload(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
+static int frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
 {
-    if (!ctx) return VO_ERR_INVALID;
     if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
     if (row_stride < ctx->w) FAIL(VO_ERR_INVALID, "row_stride < width");
+    if (F == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     const LevelGeom& lv = ctx->g.lv[0];
-    for (int f = 0; f < F; f++) {
-        uint8_t* dst = ctx->pyr + (size_t)(first_slot + f) * ctx->g.frame_bytes + lv.off;
-        HIPCHK(hipMemcpy2DAsync(dst, lv.stride, frames + (size_t)f * frame_stride, row_stride, ctx->w, ctx->h,
+    uint8_t* dst0 = ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes + lv.off;
+    if (row_stride == ctx->w && lv.stride == ctx->w && frame_stride >= (int64_t)ctx->w * ctx->h) {
+        // dense frames and an unpadded level 0: the whole batch is ONE strided copy (a "row" = a frame)
+        HIPCHK(hipMemcpy2DAsync(dst0, ctx->g.frame_bytes, frames, (size_t)frame_stride, (size_t)ctx->w * ctx->h, F,
                                 hipMemcpyHostToDevice, ctx->stream));
+        return VO_OK;
     }
+    for (int f = 0; f < F; f++)
+        HIPCHK(hipMemcpy2DAsync(dst0 + (size_t)f * ctx->g.frame_bytes, lv.stride, frames + (size_t)f * frame_stride, row_stride,
+                                ctx->w, ctx->h, hipMemcpyHostToDevice, ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_frames_upload(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    int rc = frames_upload_enqueue(ctx, frames, F, row_stride, frame_stride, first_slot);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return VO_OK;
+}
+
+// Enqueue only (gray frames).  With page-locked source memory (vo_host_alloc) the copy runs on the DMA engines
+// behind the work already queued on this ctx and beside the other ctx's kernels; the source must stay untouched
+// until the next vo_sync(ctx).
+extern "C" int vo_frames_upload_async(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    return frames_upload_enqueue(ctx, frames, F, row_stride, frame_stride, first_slot);
 }
 
 extern "C" int vo_frames_upload_color(vo_ctx* ctx, const uint8_t* frames, int F, int channels, int row_stride,

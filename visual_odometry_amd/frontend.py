@@ -27,15 +27,24 @@ class FrontEnd:
         self._res = _lib.PinnedArray((self.max_pairs,), _lib.PAIR_RESULT_DTYPE)      # page-locked result buffers,
         self._X = None                                                                # reused by every run_pairs call
 
-    def upload(self, frames, first_slot=0):
-        """frames: [F, H, W] gray or [F, H, W, 3|4] BGR(A) uint8 (BGR is converted on the device, as ORB does)."""
+    def pinned_frames(self, count):
+        """Page-locked [count, H, W] uint8 staging array for upload(..., wait=False) (kept alive by the caller)."""
+        return _lib.PinnedArray((int(count), self.h, self.w), np.uint8)
+
+    def upload(self, frames, first_slot=0, wait=True):
+        """frames: [F, H, W] gray or [F, H, W, 3|4] BGR(A) uint8 (BGR is converted on the device, as ORB does).
+        wait=False (gray only): enqueue the copy; `frames` should come from pinned_frames() and must not change
+        before the next wait()."""
         f = np.ascontiguousarray(frames, dtype=np.uint8)
         if f.ndim == 2 or (f.ndim == 3 and f.shape[-1] in (3, 4) and f.shape[:2] == (self.h, self.w)):
             f = f[None]
         if f.ndim not in (3, 4) or f.shape[1:3] != (self.h, self.w):
             raise ValueError(f"frames must be [F, {self.h}, {self.w}] or [F, {self.h}, {self.w}, 3|4] uint8")
         c = self.ctx
-        if f.ndim == 3:
+        if f.ndim == 3 and not wait:
+            self._keep_frames = f
+            c.check(c.lib.vo_frames_upload_async(c.handle, f.ctypes.data, f.shape[0], f.strides[1], f.strides[0], int(first_slot)))
+        elif f.ndim == 3:
             c.check(c.lib.vo_frames_upload(c.handle, f.ctypes.data, f.shape[0], f.strides[1], f.strides[0], int(first_slot)))
         else:
             c.check(c.lib.vo_frames_upload_color(c.handle, f.ctypes.data, f.shape[0], f.shape[3], f.strides[1], f.strides[0],
