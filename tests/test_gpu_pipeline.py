@@ -185,3 +185,38 @@ def test_long_sequence_every_pair_identical_to_oracle(oracle):
         assert (g["n_match"], g["n_inl"], g["n_good"]) == (ref["n_match"], ref["n_inl"], ref["n_good"]), k
         d = np.linalg.norm(np.hstack([g["R"].reshape(3, 3), g["t"].reshape(3, 1)]) - np.hstack([ref["R"], ref["t"]]))
         assert d < 1e-9, (k, d)
+
+
+def test_overlapped_contexts_are_deterministic():
+    """Two contexts alternating chunks (asynchronous detect + pairs, chained detections) must reproduce the
+    synchronous single-context results bit for bit, chunk after chunk: catches kernels that lean on timing
+    (a missing wait on an LDS-DMA in the MFMA matcher once showed up exactly here)."""
+    from visual_odometry_amd import synth
+    from visual_odometry_amd.frontend import FrontEnd
+    C = 48
+    seq = synth.sequence(9, 1280, 720, cache_dir="/tmp")
+    order = [(i % 16 if i % 16 < 9 else 16 - i % 16) for i in range(C + 1)]
+    frames = seq["frames"][order]
+    pairs = np.stack([np.arange(C), np.arange(C) + 1], 1).astype(np.int32)
+    fes = [FrontEnd(720, 1280, max_frames=C + 1, max_pairs=C, nfeatures=2000) for _ in range(2)]
+    for f in fes:
+        f.upload(frames)
+    opts = fes[0].make_opts(want_points=True)
+
+    def key(r):
+        return np.concatenate([r[k].astype(np.float64).ravel()
+                               for k in ("status", "n_kp1", "n_match", "n_inl", "n_good", "ransac_iters", "R", "t", "E")])
+
+    fes[0].detect(0, C + 1)
+    ref = key(fes[0].run_pairs(pairs, seq["K"], opts)[0])
+    inflight = [None, None]
+    for it in range(10):
+        k = it % 2
+        if inflight[k] is not None:
+            fes[k].wait()
+            assert np.array_equal(key(inflight[k]), ref), f"chunk {it - 2} differs from the synchronous run"
+        fes[k].detect(0, C + 1, wait=False, after=fes[1 - k])
+        inflight[k] = fes[k].run_pairs(pairs, seq["K"], opts, wait=False)[0]
+    for k in range(2):
+        fes[k].wait()
+        assert np.array_equal(key(inflight[k]), ref)

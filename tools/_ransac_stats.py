@@ -1,5 +1,5 @@
 import numpy as np, sys
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visual_odometry_amd import synth
 from visual_odometry_amd.frontend import FrontEnd
 seq = synth.sequence(17, 1280, 720, cache_dir="/tmp")

@@ -99,7 +99,10 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, c
                                          (__attribute__((address_space(3))) void*)(s_b[buf] + (q * MM_THREADS + wave * 64) * 16), 16, 0, 0)
     if (nstages > 0) { MM_GLDS(0, 0); }
     for (int sg = 0; sg < nstages; sg++) {
-        __syncthreads();                                        // stage sg has landed; buffer (sg + 1) & 1 is free
+        // the compiler does not order an LDS-DMA against later ds_reads: drain this wave's copies by hand, then
+        // the barrier makes every wave's part of stage sg visible (and buffer (sg + 1) & 1 free to refill)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (sg + 1 < nstages) { MM_GLDS(sg + 1, (sg + 1) & 1); }
         const uint8_t* sb = s_b[sg & 1];
         const int ng = active ? min(4, (nb - sg * MM_STAGE_ROWS + 15) >> 4) : 0;

@@ -220,7 +220,9 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 #define FT_SCW (FAST_TW + 16)            // LDS score tile: columns x0-4 .. x0+TW+11 (dword aligned with the output)
 #define FT_SCH (FAST_TH + 2)             // rows y0-1 .. y0+TH
 #define FT_GROUPS_X (FAST_TW / 4 + 2)    // dword groups covering x0-4 .. x0+TW+3
-#define FT_QCAP 448                      // candidate queue; a tile that overflows it takes the dense path
+#ifndef FT_QCAP
+#define FT_QCAP 1024                     // candidate queue; a tile that overflows it takes the dense path
+#endif
 
 typedef short vo_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
@@ -282,6 +284,8 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
     __shared__ uint16_t s_q[FT_QCAP + 1];            // + one spare slot for the branch-free push
+    uint16_t* s_g = (uint16_t*)s_sc;                  // group queue of phase B; dead before the score tile is cleared
+    static_assert(FT_GROUPS_X <= 64 && FT_GROUPS_X * FT_SCH * 2 <= FT_SCH * FT_SCW, "tile geometry");
     const int f = blockIdx.y, lane = threadIdx.x;
     const int bid = xcd_tile(blockIdx.x, g.ftiles_total);
     int l = 0;
@@ -292,9 +296,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     const int t = g.fast_thr;
 
-    // A. stage pixels (16-byte loads), clear the score tile
-#pragma unroll
-    for (int i = lane; i < FT_SCH * FT_SCW / 16; i += 64) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
+    // A. stage pixels (16-byte loads)
 #pragma unroll
     for (int i = lane; i < FT_PXH * (FT_PXW / 16); i += 64) {
         const int ry = i / (FT_PXW / 16), rx = (i % (FT_PXW / 16)) * 16;
@@ -305,27 +307,38 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     }
     __syncthreads();
 
-    // B. compass pre-test on the tile + 1 ring, 4 pixels per lane, two pixels per packed 16-bit operation
+    // B. compass pre-test on the tile + 1 ring.  Lane = one column group of 4 pixels (x0-4+4*lane ..), the wave
+    //    sweeps the 18 rows: every row is read from LDS once, split into even / odd 16-bit lanes once and then
+    //    serves as ring 0 of the row three above, as centre, and as ring 8 of the row three below (registers);
+    //    two pixels per packed 16-bit operation.  Groups with a survivor go to the group queue (one ballot per row).
     const uint32_t T2 = (uint32_t)t * 0x00010001u;
     const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
-    int qn = 0;                                       // wave-uniform queue length
     const bool edge_tile = x0 < 4 || x0 + FAST_TW + 4 > lv.w || y0 < 4 || y0 + FAST_TH + 4 > lv.h;
+    uint32_t colmask;                                  // pixels of this lane's group where a corner is possible / needed
+    if (edge_tile) {
+        const int gx0 = x0 - 4 + 4 * lane;
+        const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
+        colmask = hi_b >= lo_b ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
+    } else {
+        colmask = lane == 0 ? 8u : lane == FT_GROUPS_X - 1 ? 1u : 15u;      // ring columns x0-1 and x0+TW only
+    }
+    if (lane >= FT_GROUPS_X) colmask = 0;
+    const uint32_t* colp = (const uint32_t*)s_px + 3 + lane;                 // dword of the group in pixel-tile row 0
+    uint32_t Ev[FT_PXH], Ov[FT_PXH];
 #pragma unroll
-    for (int it = 0; it < (FT_GROUPS_X * FT_SCH + 63) / 64; it++) {
-        const int gi = it * 64 + lane;
-        const bool in_range = gi < FT_GROUPS_X * FT_SCH;
-        const int gr = in_range ? gi / FT_GROUPS_X : 0, gc = in_range ? gi - gr * FT_GROUPS_X : 0;
-        const int gy = y0 - 1 + gr;
-        const uint32_t* rowp = (const uint32_t*)(s_px + (gr + 3) * FT_PXW) + 3 + gc;     // dword of the group itself
+    for (int r = 0; r < 6; r++) { const uint32_t c = colp[r * (FT_PXW / 4)]; Ev[r] = c & 0x00ff00ffu; Ov[r] = (c >> 8) & 0x00ff00ffu; }
+    int gn = 0;                                        // wave-uniform group-queue length
+#pragma unroll
+    for (int gr = 0; gr < FT_SCH; gr++) {
+        { const uint32_t c = colp[(gr + 6) * (FT_PXW / 4)]; Ev[gr + 6] = c & 0x00ff00ffu; Ov[gr + 6] = (c >> 8) & 0x00ff00ffu; }
+        const int r = gr + 3, gy = y0 - 1 + gr;
+        const uint32_t* rowp = colp + r * (FT_PXW / 4);
         const uint32_t c = rowp[0], wl = rowp[-1], wr = rowp[1];
-        const uint32_t up = rowp[-3 * (FT_PXW / 4)], dn = rowp[3 * (FT_PXW / 4)];
-        // even pixels (0, 2) / odd pixels (1, 3) widened to 16-bit lanes
-        const uint32_t c_e = c & 0x00ff00ffu, c_o = (c >> 8) & 0x00ff00ffu;
+        const uint32_t c_e = Ev[r], c_o = Ov[r];
         const uint32_t hi_e = pk_add16(c_e, T2), hi_o = pk_add16(c_o, T2);
         const uint32_t lo_e = pk_sub16(c_e, T2), lo_o = pk_sub16(c_o, T2);
-        // ring 0 (0,+3) and ring 8 (0,-3): aligned dwords; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
-        const uint32_t r0_e = dn & 0x00ff00ffu, r0_o = (dn >> 8) & 0x00ff00ffu;
-        const uint32_t r8_e = up & 0x00ff00ffu, r8_o = (up >> 8) & 0x00ff00ffu;
+        // ring 0 (0,+3) and ring 8 (0,-3): rows r+3 / r-3; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
+        const uint32_t r0_e = Ev[r + 3], r0_o = Ov[r + 3], r8_e = Ev[r - 3], r8_o = Ov[r - 3];
         const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, 0x0c050c03u), r4_o = __builtin_amdgcn_perm(wr, c, 0x0c060c04u);
         const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, 0x0c030c01u), r12_o = __builtin_amdgcn_perm(c, wl, 0x0c040c02u);
         // sign bit of each 16-bit lane: ring > v + t (bright) / ring < v - t (dark)
@@ -333,31 +346,43 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         const uint32_t br_o = (pk_sub16(hi_o, r0_o) | pk_sub16(hi_o, r8_o)) & (pk_sub16(hi_o, r4_o) | pk_sub16(hi_o, r12_o));
         const uint32_t dk_e = (pk_sub16(r0_e, lo_e) | pk_sub16(r8_e, lo_e)) & (pk_sub16(r4_e, lo_e) | pk_sub16(r12_e, lo_e));
         const uint32_t dk_o = (pk_sub16(r0_o, lo_o) | pk_sub16(r8_o, lo_o)) & (pk_sub16(r4_o, lo_o) | pk_sub16(r12_o, lo_o));
-        const uint32_t ce = (br_e | dk_e) & 0x80008000u, co = (br_o | dk_o) & 0x80008000u;
-        // per-pixel candidate bits, clipped to the columns / rows where a corner is possible
-        uint32_t bits = ((ce >> 15) & 1u) | ((co >> 14) & 2u) | ((ce >> 29) & 4u) | ((co >> 28) & 8u);
-        if (edge_tile) {                                             // wave-uniform: tiles touching the image border
-            const int gx0 = x0 - 4 + 4 * gc;
-            const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
-            bits &= (hi_b >= lo_b && gy >= 3 && gy < lv.h - 3) ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
-        } else {
-            bits &= gc == 0 ? 8u : gc == FT_GROUPS_X - 1 ? 1u : 15u;  // ring columns x0-1 and x0+TW only
-        }
-        if (!in_range) bits = 0;
-        if (__ballot(bits != 0)) {                                   // wave-uniform
-            const int entry = gr * 256 + 4 * gc;                     // (score-tile row, column relative to x0-4)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const bool set = (bits >> i) & 1u;
-                const unsigned long long m = __ballot(set);
-                const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                s_q[set && slot < FT_QCAP ? slot : FT_QCAP] = (uint16_t)(entry + i);
-                qn += (int)__popcll(m);
-            }
+        // candidate bits: pixel 0 / 2 = bits 15 / 31 of the even word, pixel 1 / 3 of the odd word
+        const uint32_t tt = (((br_e | dk_e) & 0x80008000u) >> 15) | (((br_o | dk_o) & 0x80008000u) >> 14);
+        uint32_t bits = (tt | (tt >> 14)) & colmask;
+        if (edge_tile && !(gy >= 3 && gy < lv.h - 3)) bits = 0;              // wave-uniform
+        const unsigned long long m = __ballot(bits != 0);
+        if (m) {                                                             // wave-uniform
+            const int slot = gn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (bits) s_g[slot] = (uint16_t)((gr << 10) | (lane << 4) | bits);
+            gn += (int)__popcll(m);
         }
     }
     __syncthreads();
+#if defined(FAST_STOP) && FAST_STOP == 1
+    if (gn >= 0) return;
+#endif
+    // B'. group queue -> pixel queue (score-tile row, column relative to x0-4)
+    int qn = 0;                                       // wave-uniform queue length
+    for (int e0 = 0; e0 < gn; e0 += 64) {
+        const uint32_t gq = e0 + lane < gn ? s_g[e0 + lane] : 0u;
+        const int entry = (int)(gq >> 10) * 256 + (int)((gq >> 4) & 63u) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool set = (gq >> i) & 1u;
+            const unsigned long long m = __ballot(set);
+            const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            s_q[set && slot < FT_QCAP ? slot : FT_QCAP] = (uint16_t)(entry + i);
+            qn += (int)__popcll(m);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = lane; i < FT_SCH * FT_SCW / 16; i += 64) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
 
+#if defined(FAST_STOP) && FAST_STOP == 2
+    if (qn >= 0) return;
+#endif
     if (qn <= FT_QCAP) {
         // C. cornerScore (0 = no corner) for the queued candidates
         for (int e = lane; e < qn; e += 64) {
@@ -365,6 +390,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
             s_sc[gr * FT_SCW + cx] = (uint8_t)fast_score_or_zero(s_px + (gr + 3) * FT_PXW + 12 + cx, t);
         }
         __syncthreads();
+#if defined(FAST_STOP) && FAST_STOP == 3
+        if (qn >= 0) return;
+#endif
         // D. 3x3 non-max suppression on the queue: decide (bit k of `lose` = k-th entry of this lane), then clear
         uint32_t lose = 0;
         for (int e = lane, k = 0; e < qn; e += 64, k++) {
@@ -410,6 +438,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         for (int i = lane; i < FAST_TH * FAST_TW; i += 64) s_sc[(i / FAST_TW + 1) * FT_SCW + 4 + i % FAST_TW] = s_out[i];
         __syncthreads();
     }
+#if defined(FAST_STOP) && FAST_STOP == 4
+    if (qn >= 0) return;
+#endif
     // E. dense store of the tile rows, 16 bytes per lane
 #pragma unroll
     for (int i = lane; i < FAST_TH * (FAST_TW / 16); i += 64) {

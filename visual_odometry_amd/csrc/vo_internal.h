@@ -38,8 +38,12 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
     int tiled;                   // 1: geometry fits k_resize_tiled's LDS tile (scale factor <= 4/3)
 };
 
-#define FAST_TW 64
+#ifndef FAST_TW
+#define FAST_TW 240
+#endif
+#ifndef FAST_TH
 #define FAST_TH 16
+#endif
 #define BLUR_TW 128
 #define BLUR_TH 32
 #define SEL_ROWS 8
