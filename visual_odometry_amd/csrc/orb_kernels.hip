@@ -204,17 +204,20 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 // fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  One WAVEFRONT = one FAST_TW x FAST_TH output tile;
 // a workgroup is a single wave, so the kernel has no cross-wave barrier and every wave runs at its own pace.
 //  A. the tile + halo 4 is staged in LDS with 16-byte global loads (rows are 64-byte aligned in HBM);
-//  B. high-speed pre-test, one lane = 4 horizontally adjacent pixels read as dwords from LDS and compared
-//     two at a time with packed 16-bit subtractions (v_perm_b32 + v_pk_sub_i16): a 9-arc of the 16-ring
-//     always contains two adjacent compass pixels (ring 0, 4, 8, 12), so a pixel can only be a corner if two
-//     adjacent compass pixels are both brighter than v+t or both darker than v-t (OpenCV's own early-out).
-//     Survivors (a few % of the pixels) are appended to a wave-private LDS queue: wavefront ballot of the
-//     candidate bit + v_mbcnt prefix, no atomics;
-//  C. queued pixels get cornerScore directly, two ring differences per packed 16-bit min/max:
-//     A / B = best 9-arc minimum of (v - ring) / (ring - v); corner <=> max(A, B) > t, score = max(A, B) - 1;
-//  D. 3x3 non-max suppression on the queue (decide, then clear the losers in the LDS score tile), survivors
-//     inside the border feed the per-level score histogram retainBest needs (global atomics, ~3 per tile);
+//  B. high-speed pre-test: lane = (row parity, group of 4 horizontally adjacent pixels), the wave sweeps the tile
+//     two rows per step with compile-time LDS offsets; pixels are compared two at a time with packed 16-bit
+//     subtractions (v_perm_b32 + v_pk_sub_i16): a 9-arc of the 16-ring always contains two adjacent compass
+//     pixels (ring 0, 4, 8, 12), so a pixel can only be a corner if two adjacent compass pixels are both brighter
+//     than v+t or both darker than v-t (OpenCV's own early-out).  Groups with a survivor go to a wave-private
+//     LDS queue (one wavefront ballot + v_mbcnt prefix per step, no atomics);
+//  B'. the group queue is expanded into the pixel queue (4 ballots per 64 groups; 5-20 % of the pixels survive);
+//  C. queued pixels get cornerScore directly, two candidates per lane, two ring differences per packed 16-bit
+//     min/max: A / B = best 9-arc minimum of (v - ring) / (ring - v); corner <=> max(A, B) > t, score =
+//     max(A, B) - 1; the real corners (~40 % of the candidates) are compacted in place;
+//  D. 3x3 non-max suppression on the corners (decide, then clear the losers in the LDS score tile), survivors
+//     inside the border feed the per-level score histogram retainBest needs (global atomics, a few per tile);
 //  E. dense 16-byte stores of the score tile.
+// Tile 112 x 24: 30 groups per row = two rows per 64-lane step, 9 KB of LDS per wave (4 waves / SIMD).
 #define FT_PXW (FAST_TW + 32)            // LDS pixel tile: columns x0-16 .. x0+TW+15
 #define FT_PXH (FAST_TH + 8)             // rows y0-4 .. y0+TH+3
 #define FT_SCW (FAST_TW + 16)            // LDS score tile: columns x0-4 .. x0+TW+11 (dword aligned with the output)
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
     __shared__ uint16_t s_q[FT_QCAP + 1];            // + one spare slot for the branch-free push
     uint16_t* s_g = (uint16_t*)s_sc;                  // group queue of phase B; dead before the score tile is cleared
-    static_assert(FT_GROUPS_X <= 64 && FT_GROUPS_X * FT_SCH * 2 <= FT_SCH * FT_SCW, "tile geometry");
+    static_assert(FT_GROUPS_X * FT_SCH * 2 <= FT_SCH * FT_SCW, "the group queue fits the score tile");
     const int f = blockIdx.y, lane = threadIdx.x;
     const int bid = xcd_tile(blockIdx.x, g.ftiles_total);
     int l = 0;
@@ -307,38 +310,39 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     }
     __syncthreads();
 
-    // B. compass pre-test on the tile + 1 ring.  Lane = one column group of 4 pixels (x0-4+4*lane ..), the wave
-    //    sweeps the 18 rows: every row is read from LDS once, split into even / odd 16-bit lanes once and then
-    //    serves as ring 0 of the row three above, as centre, and as ring 8 of the row three below (registers);
-    //    two pixels per packed 16-bit operation.  Groups with a survivor go to the group queue (one ballot per row).
+    // B. compass pre-test on the tile + 1 ring.  Lane = (row parity, column group of 4 pixels): the wave sweeps the
+    //    18 rows two at a time, every LDS address is the lane's base plus a compile-time offset (no index
+    //    arithmetic); two pixels per packed 16-bit operation.  Groups with a survivor go to the group queue (one
+    //    ballot per step), which phase B' turns into the pixel queue.
+    static_assert(FT_GROUPS_X <= 32 && FT_SCH % 2 == 0, "two rows of groups per wavefront step");
     const uint32_t T2 = (uint32_t)t * 0x00010001u;
     const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
     const bool edge_tile = x0 < 4 || x0 + FAST_TW + 4 > lv.w || y0 < 4 || y0 + FAST_TH + 4 > lv.h;
+    const int hp = lane >> 5, gc = lane & 31;
     uint32_t colmask;                                  // pixels of this lane's group where a corner is possible / needed
     if (edge_tile) {
-        const int gx0 = x0 - 4 + 4 * lane;
+        const int gx0 = x0 - 4 + 4 * gc;
         const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
         colmask = hi_b >= lo_b ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
     } else {
-        colmask = lane == 0 ? 8u : lane == FT_GROUPS_X - 1 ? 1u : 15u;      // ring columns x0-1 and x0+TW only
+        colmask = gc == 0 ? 8u : gc == FT_GROUPS_X - 1 ? 1u : 15u;          // ring columns x0-1 and x0+TW only
     }
-    if (lane >= FT_GROUPS_X) colmask = 0;
-    const uint32_t* colp = (const uint32_t*)s_px + 3 + lane;                 // dword of the group in pixel-tile row 0
-    uint32_t Ev[FT_PXH], Ov[FT_PXH];
-#pragma unroll
-    for (int r = 0; r < 6; r++) { const uint32_t c = colp[r * (FT_PXW / 4)]; Ev[r] = c & 0x00ff00ffu; Ov[r] = (c >> 8) & 0x00ff00ffu; }
+    if (gc >= FT_GROUPS_X) colmask = 0;
+    const uint32_t* colp = (const uint32_t*)s_px + 3 + gc + hp * (FT_PXW / 4);   // dword of the group in pixel-tile row hp
     int gn = 0;                                        // wave-uniform group-queue length
 #pragma unroll
-    for (int gr = 0; gr < FT_SCH; gr++) {
-        { const uint32_t c = colp[(gr + 6) * (FT_PXW / 4)]; Ev[gr + 6] = c & 0x00ff00ffu; Ov[gr + 6] = (c >> 8) & 0x00ff00ffu; }
-        const int r = gr + 3, gy = y0 - 1 + gr;
-        const uint32_t* rowp = colp + r * (FT_PXW / 4);
+    for (int st = 0; st < FT_SCH / 2; st++) {
+        const int gr = 2 * st + hp, gy = y0 - 1 + gr;  // score-tile row of this lane
+        const uint32_t* rowp = colp + (2 * st + 3) * (FT_PXW / 4);
         const uint32_t c = rowp[0], wl = rowp[-1], wr = rowp[1];
-        const uint32_t c_e = Ev[r], c_o = Ov[r];
+        const uint32_t up = rowp[-3 * (FT_PXW / 4)], dn = rowp[3 * (FT_PXW / 4)];
+        // even pixels (0, 2) / odd pixels (1, 3) widened to 16-bit lanes
+        const uint32_t c_e = c & 0x00ff00ffu, c_o = (c >> 8) & 0x00ff00ffu;
         const uint32_t hi_e = pk_add16(c_e, T2), hi_o = pk_add16(c_o, T2);
         const uint32_t lo_e = pk_sub16(c_e, T2), lo_o = pk_sub16(c_o, T2);
-        // ring 0 (0,+3) and ring 8 (0,-3): rows r+3 / r-3; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
-        const uint32_t r0_e = Ev[r + 3], r0_o = Ov[r + 3], r8_e = Ev[r - 3], r8_o = Ov[r - 3];
+        // ring 0 (0,+3) and ring 8 (0,-3): aligned dwords; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
+        const uint32_t r0_e = dn & 0x00ff00ffu, r0_o = (dn >> 8) & 0x00ff00ffu;
+        const uint32_t r8_e = up & 0x00ff00ffu, r8_o = (up >> 8) & 0x00ff00ffu;
         const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, 0x0c050c03u), r4_o = __builtin_amdgcn_perm(wr, c, 0x0c060c04u);
         const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, 0x0c030c01u), r12_o = __builtin_amdgcn_perm(c, wl, 0x0c040c02u);
         // sign bit of each 16-bit lane: ring > v + t (bright) / ring < v - t (dark)
@@ -349,18 +353,15 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         // candidate bits: pixel 0 / 2 = bits 15 / 31 of the even word, pixel 1 / 3 of the odd word
         const uint32_t tt = (((br_e | dk_e) & 0x80008000u) >> 15) | (((br_o | dk_o) & 0x80008000u) >> 14);
         uint32_t bits = (tt | (tt >> 14)) & colmask;
-        if (edge_tile && !(gy >= 3 && gy < lv.h - 3)) bits = 0;              // wave-uniform
+        if (edge_tile && !(gy >= 3 && gy < lv.h - 3)) bits = 0;
         const unsigned long long m = __ballot(bits != 0);
         if (m) {                                                             // wave-uniform
             const int slot = gn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (bits) s_g[slot] = (uint16_t)((gr << 10) | (lane << 4) | bits);
+            if (bits) s_g[slot] = (uint16_t)((gr << 10) | (gc << 4) | bits);
             gn += (int)__popcll(m);
         }
     }
     __syncthreads();
-#if defined(FAST_STOP) && FAST_STOP == 1
-    if (gn >= 0) return;
-#endif
     // B'. group queue -> pixel queue (score-tile row, column relative to x0-4)
     int qn = 0;                                       // wave-uniform queue length
     for (int e0 = 0; e0 < gn; e0 += 64) {
@@ -380,38 +381,48 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     for (int i = lane; i < FT_SCH * FT_SCW / 16; i += 64) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
-#if defined(FAST_STOP) && FAST_STOP == 2
-    if (qn >= 0) return;
-#endif
     if (qn <= FT_QCAP) {
-        // C. cornerScore (0 = no corner) for the queued candidates
-        for (int e = lane; e < qn; e += 64) {
-            const int q = s_q[e], gr = q >> 8, cx = q & 255;             // cx: column relative to x0-4
-            s_sc[gr * FT_SCW + cx] = (uint8_t)fast_score_or_zero(s_px + (gr + 3) * FT_PXW + 12 + cx, t);
+        // C. cornerScore for the queued candidates, two per lane (two independent chains of LDS reads in flight);
+        //    the real corners (about 40 % of the candidates) are compacted in place at the front of the queue
+        int nc = 0;
+        for (int e0 = 0; e0 < qn; e0 += 128) {
+            const int ea = e0 + lane, eb = ea + 64;
+            const bool ha = ea < qn, hb = eb < qn;
+            const int qa = s_q[ha ? ea : 0], qb = s_q[hb ? eb : 0];
+            int sa = fast_score_or_zero(s_px + ((qa >> 8) + 3) * FT_PXW + 12 + (qa & 255), t);
+            int sb = fast_score_or_zero(s_px + ((qb >> 8) + 3) * FT_PXW + 12 + (qb & 255), t);
+            sa = ha ? sa : 0; sb = hb ? sb : 0;
+            const unsigned long long ma = __ballot(sa != 0), mb = __ballot(sb != 0);
+            const int pa = nc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+            const int na = (int)__popcll(ma);
+            const int pb = nc + na + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+            if (sa) { s_sc[(qa >> 8) * FT_SCW + (qa & 255)] = (uint8_t)sa; s_q[pa] = (uint16_t)qa; }
+            if (sb) { s_sc[(qb >> 8) * FT_SCW + (qb & 255)] = (uint8_t)sb; s_q[pb] = (uint16_t)qb; }
+            nc += na + (int)__popcll(mb);
         }
         __syncthreads();
-#if defined(FAST_STOP) && FAST_STOP == 3
-        if (qn >= 0) return;
-#endif
-        // D. 3x3 non-max suppression on the queue: decide (bit k of `lose` = k-th entry of this lane), then clear
+        // D. 3x3 non-max suppression on the corners, two per lane: decide (bits 2k, 2k+1 of `lose`), then clear
         uint32_t lose = 0;
-        for (int e = lane, k = 0; e < qn; e += 64, k++) {
-            const int q = s_q[e], gr = q >> 8, cx = q & 255;
-            const uint8_t* c = s_sc + gr * FT_SCW + cx;
-            const int sv = c[0];
-            if (sv) {
+        for (int e0 = 0, k = 0; e0 < nc; e0 += 128, k += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int e = e0 + 64 * h + lane;
+                const bool has = e < nc;
+                const int q = s_q[has ? e : 0], gr = q >> 8, cx = q & 255;
+                const uint8_t* c = s_sc + gr * FT_SCW + cx;
+                const int sv = c[0];
                 const int gx = x0 - 4 + cx, gy = y0 - 1 + gr;
                 const bool inside = gr >= 1 && gr <= FAST_TH && cx >= 4 && cx < 4 + FAST_TW;      // the tile proper, not its ring
                 const bool win = inside && sv > c[-1] && sv > c[1] && sv > c[-FT_SCW - 1] && sv > c[-FT_SCW] && sv > c[-FT_SCW + 1] &&
                                  sv > c[FT_SCW - 1] && sv > c[FT_SCW] && sv > c[FT_SCW + 1];
-                if (!win) lose |= 1u << k;
-                else if (gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge)
+                if (has && !win) lose |= 1u << (k + h);
+                if (has && win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge)
                     atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
             }
         }
         __syncthreads();
-        for (int e = lane, k = 0; e < qn; e += 64, k++)
-            if ((lose >> k) & 1u) { const int q = s_q[e]; s_sc[(q >> 8) * FT_SCW + (q & 255)] = 0; }
+        for (int e0 = 0, k = 0; e0 < nc; e0 += 64, k++)
+            if ((lose >> k) & 1u) { const int q = s_q[e0 + lane]; s_sc[(q >> 8) * FT_SCW + (q & 255)] = 0; }
         __syncthreads();
     } else {
         // the queue overflowed (extremely corner-dense tile): score every pixel of the tile + ring, dense NMS
@@ -438,9 +449,6 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         for (int i = lane; i < FAST_TH * FAST_TW; i += 64) s_sc[(i / FAST_TW + 1) * FT_SCW + 4 + i % FAST_TW] = s_out[i];
         __syncthreads();
     }
-#if defined(FAST_STOP) && FAST_STOP == 4
-    if (qn >= 0) return;
-#endif
     // E. dense store of the tile rows, 16 bytes per lane
 #pragma unroll
     for (int i = lane; i < FAST_TH * (FAST_TW / 16); i += 64) {

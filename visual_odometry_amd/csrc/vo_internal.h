@@ -39,10 +39,10 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
 };
 
 #ifndef FAST_TW
-#define FAST_TW 240
+#define FAST_TW 112
 #endif
 #ifndef FAST_TH
-#define FAST_TH 16
+#define FAST_TH 24
 #endif
 #define BLUR_TW 128
 #define BLUR_TH 32
