@@ -13,5 +13,5 @@ for rep in range(3):
     fe.profile(True)
     for _ in range(4): fe.detect(0, n)
     p = fe.profile_read(); fe.profile(False)
-    out.append(p["fast_score_nms"][0] / p["fast_score_nms"][1])
-print(sys.argv[1] if len(sys.argv) > 1 else "", "fast ms/launch:", " ".join(f"{x:.3f}" for x in out), " kp0:", len(fe.features(0)["xy"]))
+    out.append(" ".join(f"{k[:6]}={v[0]/v[1]:.3f}" for k, v in p.items()))
+print(sys.argv[1] if len(sys.argv) > 1 else "", "stage ms/launch:", out[-1], " kp0:", len(fe.features(0)["xy"]))

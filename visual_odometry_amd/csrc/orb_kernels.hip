@@ -228,6 +228,7 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
 #endif
 
 typedef short vo_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short vo_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) - __builtin_bit_cast(vo_s16x2, b));
@@ -850,8 +851,8 @@ __device__ __forceinline__ int reflect101(int i, int n)
 // Tile BLUR_TW x BLUR_TH per workgroup. The input tile + halo is staged in LDS with 16-byte loads (rows are
 // reflected when staged, the <= 3 halo columns outside the image are patched from their mirror columns);
 // horizontal pass: one lane = 4 pixels, 7 taps as two v_dot4_u32_u8 on byte-aligned windows
-// (v_alignbyte_b32), 16-bit row sums kept in LDS; vertical pass: one lane = 4 columns x 4 rows, the
-// 10 row sums it needs are read once (ds_read_b64) and reused from registers.
+// (v_alignbyte_b32), 16-bit row sums kept in LDS as (even row, odd row) pairs; vertical pass: one lane = 4 columns
+// x 4 rows, the 5 row pairs it needs are read once (ds_read_b128) and each output is 4 x v_dot2_u32_u16.
 #define BL_INW 160                        // staged columns x0-16 .. x0+143
 #define BL_INH (BLUR_TH + 6)              // staged rows y0-3 .. y0+TH+2
 #define BL_ROWS_PER_LANE (BLUR_TH / 8)
@@ -896,43 +897,54 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
         }
     }
     __syncthreads();
-    // horizontal pass: taps {18,34,49,55 | 49,34,18,0}
+    // horizontal pass: taps {18,34,49,55 | 49,34,18,0}; one item = 4 pixels of TWO consecutive staged rows, the two
+    // 16-bit row sums of a column share a dword (low = even row) so that the vertical pass can use v_dot2_u32_u16
     const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
-    for (int i = tid; i < BL_INH * (BLUR_TW / 4); i += 256) {
-        const int ry = i / (BLUR_TW / 4), cg = i % (BLUR_TW / 4);
-        const uint32_t* wp = (const uint32_t*)(s_in + ry * BL_INW) + 4 + cg;      // dword holding pixels x0+4cg..+3
-        const uint32_t w0 = wp[-1], w1 = wp[0], w2 = wp[1];
-        // pixel i needs window bytes 1+i .. 7+i of {w0,w1,w2}
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), a1 = __builtin_amdgcn_alignbyte(w1, w0, 2);
-        const uint32_t a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), a3 = w1;
-        const uint32_t b0 = __builtin_amdgcn_alignbyte(w2, w1, 1), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
-        const uint32_t b2 = __builtin_amdgcn_alignbyte(w2, w1, 3), b3 = w2;
-        const uint32_t h0 = __builtin_amdgcn_udot4(a0, TA, __builtin_amdgcn_udot4(b0, TB, 0u, false), false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(a1, TA, __builtin_amdgcn_udot4(b1, TB, 0u, false), false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(a2, TA, __builtin_amdgcn_udot4(b2, TB, 0u, false), false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(a3, TA, __builtin_amdgcn_udot4(b3, TB, 0u, false), false);
-        *(uint2*)(s_h + ry * BLUR_TW + cg * 4) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    for (int i = tid; i < (BL_INH / 2) * (BLUR_TW / 4); i += 256) {
+        const int rp = i / (BLUR_TW / 4), cg = i % (BLUR_TW / 4);
+        uint32_t h[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t* wp = (const uint32_t*)(s_in + (2 * rp + k) * BL_INW) + 4 + cg;      // dword holding pixels x0+4cg..+3
+            const uint32_t w0 = wp[-1], w1 = wp[0], w2 = wp[1];
+            // pixel j needs window bytes 1+j .. 7+j of {w0,w1,w2}
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), a1 = __builtin_amdgcn_alignbyte(w1, w0, 2);
+            const uint32_t a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), a3 = w1;
+            const uint32_t b0 = __builtin_amdgcn_alignbyte(w2, w1, 1), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+            const uint32_t b2 = __builtin_amdgcn_alignbyte(w2, w1, 3), b3 = w2;
+            h[k][0] = __builtin_amdgcn_udot4(a0, TA, __builtin_amdgcn_udot4(b0, TB, 0u, false), false);
+            h[k][1] = __builtin_amdgcn_udot4(a1, TA, __builtin_amdgcn_udot4(b1, TB, 0u, false), false);
+            h[k][2] = __builtin_amdgcn_udot4(a2, TA, __builtin_amdgcn_udot4(b2, TB, 0u, false), false);
+            h[k][3] = __builtin_amdgcn_udot4(a3, TA, __builtin_amdgcn_udot4(b3, TB, 0u, false), false);
+        }
+        *(uint4*)(s_h + (rp * BLUR_TW + cg * 4) * 2) =
+            make_uint4(h[0][0] | (h[1][0] << 16), h[0][1] | (h[1][1] << 16), h[0][2] | (h[1][2] << 16), h[0][3] | (h[1][3] << 16));
     }
     __syncthreads();
-    // vertical pass: lane = 4 columns x BL_ROWS_PER_LANE rows
+    // vertical pass: lane = 4 columns x BL_ROWS_PER_LANE (4) rows = 5 row pairs; an output row is 4 x v_dot2_u32_u16
+    // over the pairs it spans (tap pairs for rows starting on an even / odd staged row)
+    static_assert(BL_ROWS_PER_LANE == 4 && BL_INH % 2 == 0, "vertical pass works on row pairs");
     const int cg = tid & 31, strip = tid >> 5;
-    uint32_t hv[BL_ROWS_PER_LANE + 6][4];
+    uint4 pr[5];
 #pragma unroll
-    for (int r = 0; r < BL_ROWS_PER_LANE + 6; r++) {
-        const uint2 v = *(const uint2*)(s_h + (strip * BL_ROWS_PER_LANE + r) * BLUR_TW + cg * 4);
-        hv[r][0] = v.x & 0xffffu; hv[r][1] = v.x >> 16; hv[r][2] = v.y & 0xffffu; hv[r][3] = v.y >> 16;
-    }
-    const uint32_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
+    for (int r = 0; r < 5; r++) pr[r] = *(const uint4*)(s_h + ((strip * 2 + r) * BLUR_TW + cg * 4) * 2);
+    const uint32_t TE[4] = {18u | (34u << 16), 49u | (55u << 16), 49u | (34u << 16), 18u};
+    const uint32_t TO[4] = {18u << 16, 34u | (49u << 16), 55u | (49u << 16), 34u | (18u << 16)};
     const int gx = x0 + cg * 4;
 #pragma unroll
     for (int r = 0; r < BL_ROWS_PER_LANE; r++) {
         const int gy = y0 + strip * BL_ROWS_PER_LANE + r;
+        const int p0 = r >> 1;
         uint32_t out = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             uint32_t sum = 1u << 15;
 #pragma unroll
-            for (int k = 0; k < 7; k++) sum += taps[k] * hv[r + k][b];
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = pr[p0 + k];
+                const uint32_t x = b == 0 ? v.x : b == 1 ? v.y : b == 2 ? v.z : v.w;
+                sum = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, x), __builtin_bit_cast(vo_u16x2, (r & 1) ? TO[k] : TE[k]), sum, false);
+            }
             sum >>= 16;
             out |= (sum > 255u ? 255u : sum) << (8 * b);
         }
