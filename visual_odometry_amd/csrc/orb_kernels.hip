@@ -967,6 +967,18 @@ __device__ __forceinline__ uint32_t brief_expand4(uint32_t nib)
     return ~(m * 0xfeu);
 }
 
+// cos / sin of the keypoint angle, one LANE per keypoint (in k_brief the same double-precision calls would run once
+// per wavefront, 64 lanes wide for one value).  Parked in kp_xy, which k_brief overwrites with the exported position.
+__global__ __launch_bounds__(256) void k_brief_trig(PyrGeom g, FrameFeat ff)
+{
+    const int f = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(ff.kp_count[f], g.kp_cap)) return;
+    const size_t ki = (size_t)f * g.kp_cap + k;
+    const float angle = ff.kp_angle[ki] * (float)(3.1415926535897932384626433832795 / 180.f);
+    ff.kp_xy[ki * 2] = (float)cos((double)angle);
+    ff.kp_xy[ki * 2 + 1] = (float)sin((double)angle);
+}
+
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff, uint8_t* desc_x, int cap_x)
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
@@ -982,9 +994,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
     // computeOrbDescriptors re-derives the level position from the scaled keypoint
     const float inv = 1.f / sf;
     const int cx = __float2int_rn(kx * inv), cy = __float2int_rn(ky * inv);
-    const float angle_deg = ff.kp_angle[ki];
-    const float angle = angle_deg * (float)(3.1415926535897932384626433832795 / 180.f);
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const float a = ff.kp_xy[ki * 2], b = ff.kp_xy[ki * 2 + 1];         // k_brief_trig
     const uint8_t* center = blur + (size_t)f * g.frame_bytes + lv.off + (size_t)cy * lv.stride + cx;
     uint64_t words[4];
 #pragma unroll
@@ -1016,5 +1026,6 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
 // desc_x: this launch's first frame, cap_x rows of 256 B per frame
 void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x)
 {
+    hipLaunchKernelGGL(k_brief_trig, dim3((g.kp_cap + 255) / 256, F), dim3(256), 0, s, g, ff);
     hipLaunchKernelGGL(k_brief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x);
 }
