@@ -804,10 +804,13 @@ __constant__ uint32_t c_disc_mask[16][8] = {
 #undef DM
 };
 
-__global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
+__global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, FrameFeat ff, int blocks_per_frame)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // keypoints are stored in (level, y, x) order: a contiguous run of them per XCD lets neighbouring patches
+    // share image lines through that XCD's L2 instead of fetching them once per XCD
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int f = bid / blocks_per_frame, lane = threadIdx.x & 63;
+    const int k = (bid % blocks_per_frame) * 4 + (threadIdx.x >> 6);
     if (k >= min(ff.kp_count[f], g.kp_cap)) return;
     const size_t ki = (size_t)f * g.kp_cap + k;
     const uint32_t pos = ff.kp_pos[ki];
@@ -836,7 +839,8 @@ __global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, Fr
 
 void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F)
 {
-    hipLaunchKernelGGL(k_angle, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, s, pyr, g, ff);
+    const int bpf = (g.kp_cap + 3) / 4;
+    hipLaunchKernelGGL(k_angle, dim3(bpf * F), dim3(256), 0, s, pyr, g, ff, bpf);
 }
 
 // ------------------------------------------------------------------ GaussianBlur(7x7, sigma 2), BORDER_REFLECT_101
@@ -979,10 +983,11 @@ __global__ __launch_bounds__(256) void k_brief_trig(PyrGeom g, FrameFeat ff)
     ff.kp_xy[ki * 2 + 1] = (float)sin((double)angle);
 }
 
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff, uint8_t* desc_x, int cap_x)
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff, uint8_t* desc_x, int cap_x, int blocks_per_frame)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);          // a contiguous run of keypoints per XCD (see k_angle)
+    const int f = bid / blocks_per_frame, lane = threadIdx.x & 63;
+    const int k = (bid % blocks_per_frame) * 4 + (threadIdx.x >> 6);
     if (k >= min(ff.kp_count[f], g.kp_cap)) return;
     const size_t ki = (size_t)f * g.kp_cap + k;
     const uint32_t pos = ff.kp_pos[ki];
@@ -1027,5 +1032,6 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
 void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x)
 {
     hipLaunchKernelGGL(k_brief_trig, dim3((g.kp_cap + 255) / 256, F), dim3(256), 0, s, g, ff);
-    hipLaunchKernelGGL(k_brief, dim3((g.kp_cap + 3) / 4, F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x);
+    const int bpf = (g.kp_cap + 3) / 4;
+    hipLaunchKernelGGL(k_brief, dim3(bpf * F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x, bpf);
 }
