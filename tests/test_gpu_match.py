@@ -75,3 +75,30 @@ def test_real_descriptors(oracle, ctx, seq_small):
     assert len(gq) > 100
     assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
     assert np.all(np.diff(gq) > 0)       # ascending queryIdx, as BFMatcher.match returns them
+
+
+@pytest.mark.parametrize("nq,nt", [(15, 16), (16, 17), (17, 15), (63, 65), (64, 64), (65, 63), (511, 513), (512, 512),
+                                   (513, 511), (1025, 31), (33, 1027), (2, 2), (3, 1)])
+def test_sizes_around_the_mfma_tiles(oracle, ctx, nq, nt):
+    """The matcher works on 16-row MFMA blocks, 64-row LDS stages and 512-row workgroups: every remainder case,
+    all four selection modes, including the second-nearest bookkeeping of knn2."""
+    t = _descs(nq * 7 + nt, nt)
+    q = _descs(nq + nt * 3, nq, dup_from=t, flip_bits=30)
+    for mode in (0, 1, 2):
+        m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+        assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode)))
+    for ratio in (0.6, 1.0):
+        assert all(np.array_equal(a, b) for a, b in zip(_matcher().ratio_match_arrays(q, t, ratio),
+                                                        oracle.knn2_ratio_hamming(q, t, ratio)))
+
+
+def test_extreme_descriptors(oracle, ctx):
+    """All-zero / all-one rows: distances 0 and 256 (the ends of the +1/-1 dot-product range)."""
+    z = np.zeros((40, 32), np.uint8); o = np.full((37, 32), 255, np.uint8)
+    mix = np.concatenate([z[:5], o[:5], _descs(3, 20)])
+    for q, t in ((z, o), (o, z), (mix, o), (z, mix), (mix, mix[::-1].copy())):
+        for mode in (0, 1, 2):
+            m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+            assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode)))
+        assert all(np.array_equal(a, b) for a, b in zip(_matcher().ratio_match_arrays(q, t, 0.9),
+                                                        oracle.knn2_ratio_hamming(q, t, 0.9)))
