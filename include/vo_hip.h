@@ -175,6 +175,16 @@ int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam, const dou
                            const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
                            const double* K, double threshold, double* sqerr, uint8_t* keep);
 
+/* cv2.resize(img, dim) with the default INTER_LINEAR, 8-bit, 1 / 3 / 4 channels — src/visual_slam.py:346-352
+ * (cv2.imread's JPEG decode stays on the host).  Host image in, host image out. */
+int vo_resize_linear(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels, int row_stride,
+                     uint8_t* dst, int dh, int dw, int dst_stride);
+/* The batched form of the same step: F full-resolution host frames are resized on the device to the configured
+ * (w, h), converted to gray as ORB does, and become level 0 of slots first_slot..; resized_out (optional, host,
+ * [F][h][w][channels] dense) receives the resized frames (the reference keeps them as Frame.image). */
+int vo_frames_ingest(vo_ctx* ctx, const uint8_t* frames, int F, int sh, int sw, int channels, int row_stride,
+                     int64_t frame_stride, int first_slot, uint8_t* resized_out);
+
 /* VisualSlam.update_feature_mapper + track_feature_back_in_time — src/visual_slam.py:183-188, :94-99, for ALL
  * features at once.  A feature id is (frame, index) with frame < F, index < cap.  Pair p maps
  * every matched feature (pair_frames[2p+1], mt[k]) to (pair_frames[2p], mq[k]), k in [match_off[p], match_off[p+1]);

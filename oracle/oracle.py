@@ -245,3 +245,16 @@ def reprojection_sqerr(poses, points, obs_cam, obs_pt, obs_xy, K, threshold=100.
     if rc:
         raise IndexError("observation refers to a missing camera or point")
     return err, keep.astype(bool)
+
+
+def resize_linear(src, dw, dh):
+    """cv2.resize(src, (dw, dh)) with INTER_LINEAR, 8-bit, 1 / 3 / 4 channels (voo_ingest.c)."""
+    src = _u8(src)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    f = lib().voo_resize_linear
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rc = f(src.ctypes.data, sw, sh, cn, src.strides[0], dst.ctypes.data, dw, dh, dst.strides[0])
+    assert rc == 0
+    return dst

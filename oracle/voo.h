@@ -86,6 +86,11 @@ int voo_reprojection_sqerr(const double* poses, int ncam, const double* points, 
                            const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
                            const double* K, double threshold, double* sqerr, uint8_t* keep);
 
+/* --- "next" row: frame ingest, cv2.resize(img, dim) INTER_LINEAR, visual_slam.py:346-352 -- */
+int voo_resize_linear_tab(int ssize, int dsize, int32_t* ofs, int16_t* c0, int16_t* c1, int clamp_weight);
+int voo_resize_linear(const uint8_t* src, int sw, int sh, int cn, int sstride,
+                      uint8_t* dst, int dw, int dh, int dstride);
+
 #ifdef __cplusplus
 }
 #endif

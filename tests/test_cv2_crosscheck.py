@@ -34,6 +34,18 @@ def test_resize_matches_inter_linear_exact(oracle, dst):
     assert np.array_equal(oracle.resize_linear_exact(img, dst[0], dst[1]), ref)
 
 
+@pytest.mark.parametrize("shape,dsize", [((216, 384, 3), (115, 64)), ((97, 131), (64, 48)), ((60, 80, 3), (40, 30))])
+def test_ingest_resize_matches_cv2_resize(oracle, shape, dsize):
+    # visual_slam.py:346-352; an IPP-enabled cv2 may differ by one grey level (oracle/voo_ingest.c), so report both
+    rng = np.random.default_rng(31)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    ref = cv2.resize(img, dsize)
+    got = oracle.resize_linear(img, dsize[0], dsize[1])
+    assert np.abs(ref.astype(int) - got.astype(int)).max() <= 1
+    cv2.ipp.setUseIPP(False) if hasattr(cv2, "ipp") else None
+    assert np.array_equal(cv2.resize(img, dsize), got)
+
+
 def test_blur_matches_gaussianblur(oracle):
     img = random_image(12, 240, 320)
     ref = cv2.GaussianBlur(img, (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)

@@ -96,3 +96,37 @@ def test_feature_tracks_match_the_reference_dict_walk(ctx, seq_small):
     assert longest >= 2
     with pytest.raises(Exception):
         mf.feature_tracks(2, 8, [[0, 1], [1, 0]], [(np.array([0]), np.array([0])), (np.array([0]), np.array([0]))])   # a cycle
+
+
+@pytest.mark.parametrize("shape,dsize", [((2160, 3840, 3), (1152, 648)), ((216, 384, 3), (115, 64)), ((97, 131), (64, 48)),
+                                         ((50, 70, 4), (140, 100)), ((60, 80, 3), (40, 30)), ((33, 47), (200, 9)),
+                                         ((5, 5, 3), (1, 1)), ((1, 1), (7, 3))])
+def test_ingest_resize_bit_exact(oracle, ctx, shape, dsize):
+    """cv2.resize(img, dim) (visual_slam.py:346-352; the reference's 3840x2160 -> 1152x648 case first)."""
+    from visual_odometry_amd import ingest
+    rng = np.random.default_rng(sum(shape) + dsize[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(ingest.resize(img, dsize), oracle.resize_linear(img, dsize[0], dsize[1]))
+
+
+def test_ingest_into_the_front_end(oracle, ctx):
+    """Full-resolution BGR frames -> device resize -> gray -> ORB must equal oracle resize + oracle ORB on the result."""
+    from visual_odometry_amd import ingest, synth
+    from visual_odometry_amd.frontend import FrontEnd
+    seq = synth.sequence(2, 1280, 720, cache_dir="/tmp")
+    big = np.stack([np.stack([f, np.roll(f, 3, 1), 255 - f], axis=2) for f in seq["frames"]])       # [2, 720, 1280, 3]
+    fe = FrontEnd(216, 384, max_frames=2, max_pairs=1, nfeatures=500)
+    small = fe.ingest(big, want_resized=True)
+    for i in range(2):
+        assert np.array_equal(small[i], oracle.resize_linear(big[i], 384, 216))
+    fe.detect(0, 2)
+    ref = oracle.orb_detect_and_compute(oracle.resize_linear(big[1], 384, 216), oracle.orb_params(nfeatures=500))
+    got = fe.features(1)
+    assert np.array_equal(got["xy"], ref["xy"]) and np.array_equal(got["desc"], ref["desc"])
+    gray_small = fe.ingest(seq["frames"])                                         # gray input goes straight to level 0
+    assert gray_small is None
+    fe.detect(0, 1)
+    ref = oracle.orb_detect_and_compute(oracle.resize_linear(seq["frames"][0], 384, 216), oracle.orb_params(nfeatures=500))
+    assert np.array_equal(fe.features(0)["desc"], ref["desc"])
+    with pytest.raises(NotImplementedError):
+        ingest.resize(big[0], (10, 10), interpolation=ingest.INTER_AREA)

@@ -75,3 +75,9 @@ def test_geometry_golden(oracle):
     assert np.allclose(R, g["R"], atol=1e-12) and np.allclose(t, g["t"], atol=1e-12)
     # and it is a sane pose: close to the generating motion
     assert np.linalg.norm(R - g["R_true"]) < 0.05 and np.linalg.norm(t.ravel() - g["t_true"]) < 0.1
+
+
+def test_ingest_golden(oracle):
+    g = np.load(os.path.join(G, "ingest_192x108.npz"))
+    for name, (dw, dh) in (("dst_57x32", (57, 32)), ("dst_96x54", (96, 54)), ("dst_250x120", (250, 120))):
+        assert np.array_equal(oracle.resize_linear(g["src"], dw, dh), g[name])

@@ -5,6 +5,7 @@ computing every stage a second, structurally different way (brute force / textbo
 import os
 
 import numpy as np
+import pytest
 
 from conftest import random_image
 
@@ -247,3 +248,46 @@ def test_recover_pose_and_triangulate_with_numpy_svd(oracle):
         ref = tri(P1, P0, q1[i], q2[i])
         a, b = Xo[:, i] / np.linalg.norm(Xo[:, i]), ref / np.linalg.norm(ref)
         assert 1 - abs(a @ b) < 1e-10
+
+
+# ------------------------------------------------------------------ "next" row: frame ingest (cv2.resize INTER_LINEAR)
+def _bilinear_float(src, dw, dh):
+    """Textbook half-pixel-centre bilinear in float64 (what INTER_LINEAR approximates in 11-bit fixed point)."""
+    s = src.astype(np.float64)
+    if s.ndim == 2:
+        s = s[:, :, None]
+    sh, sw = s.shape[:2]
+    fx = (np.arange(dw) + 0.5) * (sw / dw) - 0.5
+    fy = (np.arange(dh) + 0.5) * (sh / dh) - 0.5
+    x0 = np.floor(fx).astype(int); ax = fx - x0
+    y0 = np.floor(fy).astype(int); ay = fy - y0
+    xa, xb = np.clip(x0, 0, sw - 1), np.clip(x0 + 1, 0, sw - 1)
+    ya, yb = np.clip(y0, 0, sh - 1), np.clip(y0 + 1, 0, sh - 1)
+    ax = np.where((x0 < 0) | (x0 >= sw - 1), 0.0, ax)
+    top = s[ya][:, xa] * (1 - ax)[None, :, None] + s[ya][:, xb] * ax[None, :, None]
+    bot = s[yb][:, xa] * (1 - ax)[None, :, None] + s[yb][:, xb] * ax[None, :, None]
+    out = top * (1 - ay)[:, None, None] + bot * ay[:, None, None]
+    return out if src.ndim == 3 else out[:, :, 0]
+
+
+@pytest.mark.parametrize("shape,dsize", [((216, 384, 3), (115, 64)), ((97, 131), (64, 48)), ((50, 70, 4), (140, 100)),
+                                         ((60, 80, 3), (80, 60)), ((33, 47), (200, 9))])
+def test_ingest_resize_close_to_float_bilinear(oracle, shape, dsize):
+    rng = np.random.default_rng(31)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = oracle.resize_linear(img, dsize[0], dsize[1]).astype(np.float64)
+    ref = _bilinear_float(img, dsize[0], dsize[1])
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1.0               # 11-bit weights, truncating shifts: within one grey level
+    assert abs((got - ref).mean()) < 0.3                # and unbiased to first order
+
+
+def test_ingest_resize_identities(oracle):
+    rng = np.random.default_rng(32)
+    img = rng.integers(0, 256, (40, 52, 3), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear(img, 52, 40), img)                 # same size: weights (2048, 0)
+    half = oracle.resize_linear(img, 26, 20)                                      # exact 2:1 is the 2x2 mean (INTER_AREA)
+    ref = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, ref.astype(np.uint8))
+    flat = np.full((30, 30), 77, np.uint8)
+    assert np.all(oracle.resize_linear(flat, 11, 17) == 77)                       # constants survive the fixed point

@@ -53,6 +53,11 @@ def main():
     ng, Rr, tr, pm = O.recover_pose(E[0], p1[mask > 0], p2[mask > 0], Kg)
     np.savez_compressed(os.path.join(OUT, "geometry_400.npz"), K=Kg, p1=p1, p2=p2, R_true=R, t_true=t,
                         E=E[0], mask=mask, n_inl=ninl, n_good=ng, R=Rr, t=tr, pose_mask=pm)
+    # frame ingest: cv2.resize(img, dim) INTER_LINEAR (visual_slam.py:346-352)
+    rng = np.random.default_rng(123)
+    big = rng.integers(0, 256, (108, 192, 3), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "ingest_192x108.npz"), src=big, dst_57x32=O.resize_linear(big, 57, 32),
+                        dst_96x54=O.resize_linear(big, 96, 54), dst_250x120=O.resize_linear(big, 250, 120))
     print("wrote", os.listdir(OUT))
 
 

@@ -200,6 +200,44 @@ void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, con
     hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
 }
 
+// ------------------------------------------------------------------ frame ingest: cv2.resize(img, dim), INTER_LINEAR, 8-bit
+// visual_slam.py:346-352.  OpenCV's generic 8-bit path: 11-bit coefficient tables (built on the
+// host exactly as resize() builds them), HResizeLinear D = S[sx]*a0 + S[sx+cn]*a1, VResizeLinear
+// (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; an exact 2:1 reduction is the 2x2 mean (INTER_AREA fast path).
+// One lane per destination byte; HBM-bound and tiny next to the PCIe copy that feeds it.
+__global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* src, int sw, int sh, int cn, int sstride, int64_t sframe,
+                                                       uint8_t* dst, int dw, int dh, int dstride, int64_t dframe,
+                                                       const int* xofs, const short2* xa, const int* yofs, const short2* yb, int area2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (i >= dw * cn) return;
+    const int dx = i / cn, k = i - dx * cn;
+    const uint8_t* s = src + (size_t)blockIdx.z * sframe;
+    uint8_t* d = dst + (size_t)blockIdx.z * dframe + (size_t)dy * dstride + i;
+    if (area2) {
+        const uint8_t* q = s + (size_t)(2 * dy) * sstride + (size_t)(2 * dx) * cn + k;
+        *d = (uint8_t)((q[0] + q[cn] + q[sstride] + q[sstride + cn] + 2) >> 2);
+        return;
+    }
+    const int sy0 = min(max(yofs[dy], 0), sh - 1), sy1 = min(max(yofs[dy] + 1, 0), sh - 1);
+    const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
+    const short2 a = xa[dx], b = yb[dy];
+    const uint8_t* p0 = s + (size_t)sy0 * sstride; const uint8_t* p1 = s + (size_t)sy1 * sstride;
+    const int r0 = p0[sx * cn + k] * a.x + p0[sx1 * cn + k] * a.y;
+    const int r1 = p1[sx * cn + k] * a.x + p1[sx1 * cn + k] * a.y;
+    const int v = (((b.x * (r0 >> 4)) >> 16) + ((b.y * (r1 >> 4)) >> 16) + 2) >> 2;
+    *d = (uint8_t)min(max(v, 0), 255);
+}
+
+void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, int cn, int sstride, int64_t sframe,
+                          uint8_t* dst, int dw, int dh, int dstride, int64_t dframe,
+                          const int* xofs, const void* xa, const int* yofs, const void* yb, int area2, int F)
+{
+    if (F <= 0) return;
+    hipLaunchKernelGGL(k_resize_linear, dim3((dw * cn + 255) / 256, dh, F), dim3(256), 0, st, src, sw, sh, cn, sstride, sframe,
+                       dst, dw, dh, dstride, dframe, xofs, (const short2*)xa, yofs, (const short2*)yb, area2);
+}
+
 // ------------------------------------------------------------------ FAST-9/16 + cornerScore + 3x3 NMS
 // fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  One WAVEFRONT = one FAST_TW x FAST_TH output tile;
 // a workgroup is a single wave, so the kernel has no cross-wave barrier and every wave runs at its own pace.

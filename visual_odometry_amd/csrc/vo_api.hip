@@ -22,6 +22,8 @@ struct vo_ctx {
     void* tab_mem = nullptr;
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
     uint8_t* desc_x = nullptr;            // descriptors expanded to +1 / -1 bytes for the MFMA matcher
+    uint8_t* ingest_out = nullptr; size_t ingest_out_bytes = 0;      // resized frames (frame ingest)
+    int* ingest_tab = nullptr; size_t ingest_tab_n = 0;              // resize tables
     int *sel_thr = nullptr, *sel_chunk_count = nullptr, *har_kept = nullptr;
     float* har_thr = nullptr;
     size_t staging_bytes = 0;
@@ -253,7 +255,8 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_config(ctx);
     free_pairbuf(ctx->raw_pb);
-    void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab, ctx->raw_desc_x};
+    void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab, ctx->raw_desc_x,
+                    ctx->ingest_out, ctx->ingest_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
     if (ctx->ev_det) (void)hipEventDestroy(ctx->ev_det);
@@ -1023,6 +1026,129 @@ extern "C" int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam
     HIPCHK(hipStreamSynchronize(s));
     if (ctx->prof) prof_collect(ctx);
     if (bad) FAIL(VO_ERR_INVALID, "an observation refers to a missing camera or point");
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------ "next" row: frame ingest (cv2.resize INTER_LINEAR)
+// resize.cpp resize(): fx = (float)((dx + 0.5) * scale_x - 0.5), scale_x = 1. / ((double)dw / sw); columns force
+// (offset, weight) at the borders, rows keep the weight and clamp the row index; coefficients are
+// saturate_cast<short>(cvRound(w * 2048)).
+static void linear_tab(int ssize, int dsize, bool clamp_weight, int* ofs, short* c /*pairs*/)
+{
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (clamp_weight) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        const long r0 = lrintf((1.f - f) * 2048.f), r1 = lrintf(f * 2048.f);
+        c[2 * d] = (short)(r0 > 32767 ? 32767 : r0); c[2 * d + 1] = (short)(r1 > 32767 ? 32767 : r1);
+    }
+}
+
+static int ensure_bytes(vo_ctx* ctx, uint8_t** p, size_t* have, size_t need)
+{
+    if (need <= *have) return VO_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    HIPCHK(hipMalloc((void**)p, need));
+    *have = need;
+    return VO_OK;
+}
+
+// device tables for (sw, sh) -> (dw, dh): [xofs dw][xa dw pairs][yofs dh][yb dh pairs] as ints
+static int ingest_tables(vo_ctx* ctx, int sw, int sh, int dw, int dh, const int** xofs, const void** xa, const int** yofs, const void** yb)
+{
+    const size_t n = (size_t)2 * (dw + dh);
+    if (n > ctx->ingest_tab_n) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->ingest_tab) (void)hipFree(ctx->ingest_tab);
+        ctx->ingest_tab = nullptr; ctx->ingest_tab_n = 0;
+        HIPCHK(dmalloc(&ctx->ingest_tab, n));
+        ctx->ingest_tab_n = n;
+    }
+    std::vector<int> host(n);
+    linear_tab(sw, dw, true, host.data(), (short*)(host.data() + dw));
+    linear_tab(sh, dh, false, host.data() + 2 * dw, (short*)(host.data() + 2 * dw + dh));
+    HIPCHK(hipMemcpyAsync(ctx->ingest_tab, host.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));                       // `host` is a stack vector
+    *xofs = ctx->ingest_tab; *xa = ctx->ingest_tab + dw; *yofs = ctx->ingest_tab + 2 * dw; *yb = ctx->ingest_tab + 2 * dw + dh;
+    return VO_OK;
+}
+
+extern "C" int vo_resize_linear(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels, int row_stride,
+                                uint8_t* dst, int dh, int dw, int dst_stride)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!src || !dst || sh < 1 || sw < 1 || dh < 1 || dw < 1 || (channels != 1 && channels != 3 && channels != 4) ||
+        row_stride < sw * channels || dst_stride < dw * channels) FAIL(VO_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t sbytes = (size_t)row_stride * sh, dbytes = (size_t)dst_stride * dh;
+    int rc = ensure_bytes(ctx, &ctx->staging, &ctx->staging_bytes, sbytes); if (rc) return rc;
+    rc = ensure_bytes(ctx, &ctx->ingest_out, &ctx->ingest_out_bytes, dbytes); if (rc) return rc;
+    const int* xofs; const void* xa; const int* yofs; const void* yb;
+    rc = ingest_tables(ctx, sw, sh, dw, dh, &xofs, &xa, &yofs, &yb); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemcpyAsync(ctx->staging, src, sbytes, hipMemcpyHostToDevice, s));
+    { StageTimer t(ctx, ST_MISC); launch_resize_linear(s, ctx->staging, sw, sh, channels, row_stride, 0, ctx->ingest_out, dw, dh, dst_stride, 0,
+                                                       xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, 1); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst, ctx->ingest_out, dbytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+// Full-resolution frames (host) -> resized to the configured (w, h) on the device -> gray -> level 0 of the slots.
+// `resized_out` (optional, host, [F][h][w][channels] dense) receives the resized frames, which the reference
+// keeps as Frame.image.
+extern "C" int vo_frames_ingest(vo_ctx* ctx, const uint8_t* frames, int F, int sh, int sw, int channels, int row_stride,
+                                int64_t frame_stride, int first_slot, uint8_t* resized_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (sh < 1 || sw < 1 || (channels != 1 && channels != 3 && channels != 4) || row_stride < sw * channels ||
+        frame_stride < (int64_t)row_stride * sh) FAIL(VO_ERR_INVALID, "bad source geometry");
+    if (F == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int dw = ctx->w, dh = ctx->h;
+    const size_t per = (size_t)frame_stride, dper = (size_t)dw * dh * channels;
+    size_t chunk = (size_t)512 * 1024 * 1024 / per; if (chunk < 1) chunk = 1; if (chunk > (size_t)F) chunk = F;
+    int rc = ensure_bytes(ctx, &ctx->staging, &ctx->staging_bytes, per * chunk); if (rc) return rc;
+    rc = ensure_bytes(ctx, &ctx->ingest_out, &ctx->ingest_out_bytes, dper * chunk); if (rc) return rc;
+    const int* xofs; const void* xa; const int* yofs; const void* yb;
+    rc = ingest_tables(ctx, sw, sh, dw, dh, &xofs, &xa, &yofs, &yb); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    const LevelGeom& lv = ctx->g.lv[0];
+    for (int f0 = 0; f0 < F; f0 += (int)chunk) {
+        const int n = F - f0 < (int)chunk ? F - f0 : (int)chunk;
+        HIPCHK(hipMemcpyAsync(ctx->staging, frames + (size_t)f0 * per, per * n, hipMemcpyHostToDevice, s));
+        uint8_t* lvl0 = ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes + lv.off;
+        {
+            StageTimer t(ctx, ST_MISC);
+            if (channels == 1 && !resized_out)                   // gray input: straight into level 0
+                launch_resize_linear(s, ctx->staging, sw, sh, 1, row_stride, (int64_t)per, lvl0, dw, dh, lv.stride, ctx->g.frame_bytes,
+                                     xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, n);
+            else
+                launch_resize_linear(s, ctx->staging, sw, sh, channels, row_stride, (int64_t)per, ctx->ingest_out, dw, dh, dw * channels,
+                                     (int64_t)dper, xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, n);
+        }
+        if (!(channels == 1 && !resized_out)) {
+            StageTimer t(ctx, ST_GRAY);
+            launch_gray(s, ctx->ingest_out, channels, dw * channels, (int64_t)dper,
+                        ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes, ctx->g, n);
+            if (resized_out) HIPCHK(hipMemcpyAsync(resized_out + (size_t)f0 * dper, ctx->ingest_out, dper * n, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    if (ctx->prof) prof_collect(ctx);
     return VO_OK;
 }
 

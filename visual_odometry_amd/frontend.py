@@ -50,6 +50,24 @@ class FrontEnd:
             c.check(c.lib.vo_frames_upload_color(c.handle, f.ctypes.data, f.shape[0], f.shape[3], f.strides[1], f.strides[0],
                                                  int(first_slot)))
 
+    def ingest(self, frames, first_slot=0, want_resized=False):
+        """Full-resolution frames [F, H0, W0] or [F, H0, W0, 3|4] uint8 (as cv2.imread returns them): resized on the
+        device to this front end's (w, h) with cv2.resize's default INTER_LINEAR (visual_slam.py:346-352), converted
+        to gray as ORB does, stored as level 0 of the slots.  Returns the resized frames if want_resized."""
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        if f.ndim == 2 or (f.ndim == 3 and f.shape[-1] in (3, 4) and f.shape[1] > 4):
+            f = f[None]
+        if f.ndim not in (3, 4):
+            raise ValueError("frames must be [F, H, W] or [F, H, W, 3|4] uint8")
+        cn = 1 if f.ndim == 3 else f.shape[3]
+        out = None
+        if want_resized:
+            out = np.empty((f.shape[0], self.h, self.w) if f.ndim == 3 else (f.shape[0], self.h, self.w, cn), np.uint8)
+        c = self.ctx
+        c.check(c.lib.vo_frames_ingest(c.handle, f.ctypes.data, f.shape[0], f.shape[1], f.shape[2], cn, f.strides[1],
+                                       f.strides[0], int(first_slot), _lib.ptr(out)))
+        return out
+
     def detect(self, first_slot, count, wait=True, after=None):
         """ORB detect + describe of `count` resident slots. wait=False only enqueues the work on the ctx stream;
         the next run_pairs (same stream) is ordered after it.  after=<another FrontEnd on this GPU>: start only when
