@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--distinct-frames", type=int, default=17)
     ap.add_argument("--matcher", choices=["crosscheck", "ratio"], default="crosscheck")
     ap.add_argument("--ratio", type=float, default=0.8)
+    ap.add_argument("--matcher-kernel", choices=["mfma", "popcount"], default="mfma",
+                    help="Hamming NN kernel: int8 MFMA over +1/-1 bytes (default) or XOR + popcount (same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-stream-pass", action="store_true", help="skip the frames-streamed-from-host measurement")
@@ -168,6 +170,7 @@ def main():
         t_up = time.perf_counter()
         fe_c.upload(frames)                               # inputs resident in HBM before the timed region
         upload_s = time.perf_counter() - t_up
+        fe_c.ctx.set_matcher_kernel(args.matcher_kernel)
         fes.append(fe_c)
     fe = fes[0]
     opts = fe.make_opts(match_mode=match_mode, ratio=args.ratio, want_points=True)
@@ -281,7 +284,7 @@ def main():
                                     f"{C} independent pairs per GPU per step, both frames of every pair detected ({NF} detections)"),
                        "pairs_per_step_per_gpu": C, "distinct_rendered_frames": args.distinct_frames,
                        "contexts_per_gpu": n_ctx,
-                       "matcher": args.matcher, "ransac": "5-point, conf 0.99, 1 px, seed 2^64-1, <=1000 iters",
+                       "matcher": args.matcher, "matcher_kernel": args.matcher_kernel, "ransac": "5-point, conf 0.99, 1 px, seed 2^64-1, <=1000 iters",
                        "parallelism": f"pair-sharded x{world}, RCCL all_gather of 128 B/pair per step" if world > 1 else "single GPU",
                        "streamed_from_host_pairs_per_s_per_gpu": round(streamed, 1) if streamed else None,
                        "unoverlapped_pageable_upload_ms_per_chunk": round(1000 * upload_s, 2),

@@ -64,6 +64,11 @@ int vo_orb_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int
                               float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
                               int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);
 
+/* Which kernel computes the Hamming nearest neighbours (same results, bit for bit): 0 = int8 MFMA over +1/-1
+ * byte descriptors (default, 3x faster), 1 = XOR + popcount on the packed descriptors (the formulation
+ * BASELINE.json's north_star names). */
+int vo_set_matcher_kernel(vo_ctx* ctx, int kind);
+
 /* self.matcher.match(d1, d2) for cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=...) —
  * src/image_pair.py:234-236, matcher built at src/visual_slam.py:18 / src/image_and_keypoints.py:9.
  * cross_check: 0 = nearest neighbour, 1 = cv2 crossCheck=True semantics, 2 = strict mutual NN.

@@ -102,3 +102,24 @@ def test_extreme_descriptors(oracle, ctx):
             assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode)))
         assert all(np.array_equal(a, b) for a, b in zip(_matcher().ratio_match_arrays(q, t, 0.9),
                                                         oracle.knn2_ratio_hamming(q, t, 0.9)))
+
+
+def test_popcount_kernel_gives_the_same_matches(oracle):
+    """The XOR + popcount kernel (north_star's formulation) and the default MFMA kernel are interchangeable."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.matcher import HammingMatcher
+    c = _lib.Context(0)
+    try:
+        c.set_matcher_kernel("popcount")
+        for nq, nt in ((2000, 2000), (513, 31), (17, 900), (1, 1)):
+            t = _descs(nq + 5, nt)
+            q = _descs(nt + 9, nq, dup_from=t, flip_bits=40)
+            for mode in (0, 1, 2):
+                m = HammingMatcher(crossCheck=mode > 0, strict_mutual=mode == 2, ctx=c)
+                assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode)))
+            m = HammingMatcher(ctx=c)
+            assert all(np.array_equal(a, b) for a, b in zip(m.ratio_match_arrays(q, t, 0.8), oracle.knn2_ratio_hamming(q, t, 0.8)))
+        with pytest.raises(Exception):
+            c.check(c.lib.vo_set_matcher_kernel(c.handle, 7))
+    finally:
+        c.close()

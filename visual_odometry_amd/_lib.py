@@ -63,6 +63,7 @@ _SIGS = {
     "vo_pairs_run": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
     "vo_pairs_run_async": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
     "vo_sync": (C.c_int, [_P]),
+    "vo_set_matcher_kernel": (C.c_int, [_P, C.c_int]),
     "vo_detect_after": (C.c_int, [_P, _P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
@@ -129,6 +130,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_matcher_kernel(self, kind):
+        """'mfma' (default) or 'popcount': which kernel computes the Hamming nearest neighbours (same results)."""
+        self.check(self.lib.vo_set_matcher_kernel(self.handle, {"mfma": 0, "popcount": 1}[kind]))
 
     def check(self, rc):
         if rc < 0:

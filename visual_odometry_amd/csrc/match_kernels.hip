@@ -8,6 +8,101 @@
 #include "vo_internal.h"
 #include <limits.h>
 
+// ------------------------------------------------------------------ XOR + popcount matcher (the formulation BASELINE.json's
+// north_star names: "wavefront ballot/popcount for ... Hamming, no MFMA").  Kept selectable (vo_set_matcher_kernel)
+// and parity-tested beside the MFMA kernel below, which is the default because it is 3x faster (0.19 vs 0.575 ms
+// per 256 pairs of 2000 x 2000 descriptors): this kernel runs at the integer-VALU issue rate (16 instructions per
+// distance), the MFMA one needs 2 VALU instructions per distance.
+#define NN_TILE 256
+
+struct Desc { uint4 a, b; };
+
+__device__ __forceinline__ int hamming(const Desc& x, const uint4& ya, const uint4& yb)
+{
+    return __popc(x.a.x ^ ya.x) + __popc(x.a.y ^ ya.y) + __popc(x.a.z ^ ya.z) + __popc(x.a.w ^ ya.w) +
+           __popc(x.b.x ^ yb.x) + __popc(x.b.y ^ yb.y) + __popc(x.b.z ^ yb.z) + __popc(x.b.w ^ yb.w);
+}
+
+// nearest (and optionally second nearest) row of B for every row of A.  One lane holds NN_Q rows of A in
+// registers; B is streamed through LDS in tiles and read as wave-wide broadcasts (ds_read_b128, one read
+// serves NN_Q distances); 256-bit Hamming distance = 8 x (v_xor, v_bcnt accumulate).
+#define NN_Q 2
+#define NN_ROWS_PER_BLOCK (256 * NN_Q)
+
+template <bool KNN2>
+__device__ __forceinline__ void nn_body(const uint8_t* A, int na, const uint8_t* B, int nb,
+                                        int* idx, int* dist, int* idx2, int* dist2)
+{
+    __shared__ uint4 s_b[NN_TILE * 2];
+    const int tid = threadIdx.x;
+    Desc me[NN_Q];
+    int row[NN_Q];
+    // best / second best as one key (distance << 16 | train row): an unsigned min is the ascending scan with
+    // strict `<` (lowest row wins ties); rows < 65536 is guaranteed by the keypoint capacity check
+    uint32_t k0[NN_Q], k1[NN_Q];
+#pragma unroll
+    for (int q = 0; q < NN_Q; q++) {
+        row[q] = blockIdx.x * NN_ROWS_PER_BLOCK + q * 256 + tid;
+        me[q].a = make_uint4(0, 0, 0, 0); me[q].b = me[q].a;
+        if (row[q] < na) { me[q].a = *(const uint4*)(A + (size_t)row[q] * 32); me[q].b = *(const uint4*)(A + (size_t)row[q] * 32 + 16); }
+        k0[q] = 0xffffffffu; k1[q] = 0xffffffffu;
+    }
+    for (int base = 0; base < nb; base += NN_TILE) {
+        const int j = base + tid;
+        __syncthreads();
+        if (j < nb) { s_b[2 * tid] = *(const uint4*)(B + (size_t)j * 32); s_b[2 * tid + 1] = *(const uint4*)(B + (size_t)j * 32 + 16); }
+        __syncthreads();
+        const int lim = min(NN_TILE, nb - base);
+#pragma unroll 4
+        for (int k = 0; k < lim; k++) {
+            const uint4 ba = s_b[2 * k], bb = s_b[2 * k + 1];
+#pragma unroll
+            for (int q = 0; q < NN_Q; q++) {
+                const uint32_t key = ((uint32_t)hamming(me[q], ba, bb) << 16) | (uint32_t)(base + k);
+                if (KNN2) k1[q] = min(k1[q], max(k0[q], key));
+                k0[q] = min(k0[q], key);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NN_Q; q++) {
+        if (row[q] < na) {
+            const bool has0 = k0[q] != 0xffffffffu, has1 = k1[q] != 0xffffffffu;
+            idx[row[q]] = has0 ? (int)(k0[q] & 0xffffu) : -1; dist[row[q]] = has0 ? (int)(k0[q] >> 16) : INT_MAX;
+            if (KNN2) { idx2[row[q]] = has1 ? (int)(k1[q] & 0xffffu) : -1; dist2[row[q]] = has1 ? (int)(k1[q] >> 16) : INT_MAX; }
+        }
+    }
+}
+
+template <bool KNN2>
+__global__ __launch_bounds__(256) void k_nn_pairs(const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb,
+                                                  int dir_first)
+{
+    const int p = blockIdx.y, dir = dir_first + blockIdx.z;
+    const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
+    const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
+    if ((int)(blockIdx.x * NN_ROWS_PER_BLOCK) >= na) return;
+    const size_t o = ((size_t)p * 2 + dir) * kp_cap;
+    nn_body<KNN2>(desc + (size_t)fa * kp_cap * 32, na, desc + (size_t)fb * kp_cap * 32, nb,
+                  pb.nn_idx + o, pb.nn_dist + o, pb.nn_idx2 + (size_t)p * kp_cap, pb.nn_dist2 + (size_t)p * kp_cap);
+}
+
+// dirs_mask: bit 0 = forward (frame1 -> frame2), bit 1 = reverse. knn2 applies to the forward direction.
+void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb, int P,
+                              int dirs_mask, int knn2)
+{
+    if (P <= 0) return;
+    dim3 block(256);
+    const int gx = (kp_cap + NN_ROWS_PER_BLOCK - 1) / NN_ROWS_PER_BLOCK;
+    if (knn2) {
+        hipLaunchKernelGGL(k_nn_pairs<true>, dim3(gx, P, 1), block, 0, s, desc, kp_count, kp_cap, pb, 0);
+        return;
+    }
+    if (dirs_mask == 3) hipLaunchKernelGGL(k_nn_pairs<false>, dim3(gx, P, 2), block, 0, s, desc, kp_count, kp_cap, pb, 0);
+    else if (dirs_mask == 1) hipLaunchKernelGGL(k_nn_pairs<false>, dim3(gx, P, 1), block, 0, s, desc, kp_count, kp_cap, pb, 0);
+    else if (dirs_mask == 2) hipLaunchKernelGGL(k_nn_pairs<false>, dim3(gx, P, 1), block, 0, s, desc, kp_count, kp_cap, pb, 1);
+}
+
 // ------------------------------------------------------------------ Hamming matrix on the matrix cores
 // 256-bit Hamming distance is a dot product once the bits are written as +1 / -1 bytes:
 // sum_k a_k b_k = 256 - 2 * hamming, exact in int32.  The descriptor sets of a pair are a 2000 x 2000 x 256

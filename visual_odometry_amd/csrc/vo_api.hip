@@ -50,6 +50,7 @@ struct vo_ctx {
     bool ev_ready = false;
     hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
     bool ev_det_set = false;
+    int matcher_kernel = 0;               // 0: int8 MFMA on +1/-1 bytes (default), 1: XOR + popcount
 };
 
 static const char* k_stage_names[VO_STAGE_COUNT] = {
@@ -262,6 +263,14 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->ev_det) (void)hipEventDestroy(ctx->ev_det);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" int vo_set_matcher_kernel(vo_ctx* ctx, int kind)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "matcher kernel must be 0 (MFMA) or 1 (XOR + popcount)");
+    ctx->matcher_kernel = kind;
+    return VO_OK;
 }
 
 extern "C" const char* vo_last_error(const vo_ctx* ctx) { return ctx ? ctx->err : "ctx is NULL"; }
@@ -652,7 +661,7 @@ static int ensure_rng(vo_ctx* ctx, uint64_t seed)
 
 static int map_select_mode(int match_mode) { return match_mode == 0 ? 1 : 3; }
 
-static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc_x, const float* kp_xy, const int* kp_count, int cap,
+static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t* desc_x, const float* kp_xy, const int* kp_count, int cap,
                      int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points)
 {
     hipStream_t s = ctx->stream;
@@ -660,8 +669,12 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc_x, const float
     {
         StageTimer t(ctx, ST_MATCH_NN);
         const int cx = desc_x_rows(cap);
-        if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1);
-        else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3, 0);
+        const int dirs = select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3;
+        if (ctx->matcher_kernel == 1) {                          // XOR + popcount on the packed descriptors
+            if (select_mode == 3) launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, 1, 1);
+            else launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, dirs, 0);
+        } else if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1);
+        else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, dirs, 0);
     }
     { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
     if (!do_geometry) return VO_OK;
@@ -693,7 +706,7 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
     rp.seed = opts->ransac_seed; rp.dist_thresh = opts->pose_dist_thresh;
     memcpy(rp.K, K, sizeof(rp.K));
     const bool wp = opts->want_points != 0;
-    int rc = run_pairs(ctx, ctx->pb, ctx->desc_x, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
+    int rc = run_pairs(ctx, ctx->pb, ctx->ff.desc, ctx->desc_x, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
                        map_select_mode(opts->match_mode), opts->ratio, rp, true, wp);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -813,7 +826,7 @@ static int match_raw(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, in
     HIPCHK(hipMemcpyAsync(ctx->dK, Kid, sizeof(Kid), hipMemcpyHostToDevice, s));
     RansacParams rp{};
     { StageTimer tm(ctx, ST_BRIEF); launch_desc_expand(s, ctx->raw_desc, ctx->raw_count, cap, desc_x_rows(cap), ctx->raw_desc_x, 2); }
-    rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc_x, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false);
+    rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc, ctx->raw_desc_x, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     int n = 0;

@@ -129,6 +129,8 @@ static inline int desc_x_rows(int kp_cap) { return (kp_cap + 255) & ~255; }
 void launch_desc_expand(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int F);
 void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,
                      int dirs_mask, int knn2);
+void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb, int P,
+                              int dirs_mask, int knn2);
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
                          int mode, double ratio, const double* K);
 
