@@ -20,6 +20,27 @@ __constant__ int c_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
 
 // ------------------------------------------------------------------ XCD-aware tile order
 
+// ------------------------------------------------------------------ packed 16-bit helpers (two pixels per VALU operation)
+typedef short vo_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short vo_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) - __builtin_bit_cast(vo_s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) + __builtin_bit_cast(vo_s16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(vo_s16x2, a), __builtin_bit_cast(vo_s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vo_s16x2, a), __builtin_bit_cast(vo_s16x2, b)));
+}
+__device__ __forceinline__ uint32_t swap16(uint32_t a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+
 // ------------------------------------------------------------------ block-wide exclusive scan (<= 1024 threads)
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
@@ -120,16 +141,12 @@ __global__ void k_resize(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom
     *(uint32_t*)(dp + (size_t)dy * dst.stride + dx0) = out;
 }
 
-// Tiled version for scale factors up to 4/3 (tab.tiled): a RS_TW x RS_TH destination tile per workgroup.
+// Tiled version for scale factors up to 4/3 (tab.tiled): a RS_TW x RS_TH destination tile per workgroup (vo_internal.h).
 // The source rows/columns the tile needs are staged in LDS with 16-byte loads; horizontal pass: one lane =
 // 4 destination pixels, their 4+4 source bytes are picked out of a 12-byte window with two v_perm_b32
 // (selector built once per lane from the offset table) and blended in 8.8 fixed point; the 16-bit row
 // results stay in LDS; vertical pass blends two of them per destination row (16.16, round half up).
 // Edge replication needs no special case: the tables hold (offset 0 / last, weight 0) there.
-#define RS_TW 128
-#define RS_TH 16
-#define RS_LW 192
-#define RS_LH 24
 
 __global__ __launch_bounds__(256) void k_resize_tiled(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom dst, ResizeTab tab)
 {
@@ -144,12 +161,22 @@ __global__ __launch_bounds__(256) void k_resize_tiled(uint8_t* pyr, int frame_by
     const int nrows = min(tab.yofs[y_last] + 2 - sy0, RS_LH);
     const int ncol16 = min((tab.xofs[x_last] + 2 - sx0 + 15) >> 4, RS_LW / 16);
     const uint8_t* sp = pyr + (size_t)f * frame_bytes + src.off;
-    for (int i = tid; i < nrows * (RS_LW / 16); i += 256) {
+    // all of a lane's 16-byte loads are issued before the first one is consumed (the kernel is bound by the latency
+    // of this staging step, not by its arithmetic)
+    constexpr int RS_NLD = (RS_LH * (RS_LW / 16) + 255) / 256;
+    uint4 sv[RS_NLD];
+#pragma unroll
+    for (int k = 0; k < RS_NLD; k++) {
+        const int i = tid + 256 * k;
         const int ry = i / (RS_LW / 16), c = i % (RS_LW / 16);
         const int gy = sy0 + ry, gx = sx0 + 16 * c;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < ncol16 && gy < src.h && gx + 16 <= src.stride) v = *(const uint4*)(sp + (size_t)gy * src.stride + gx);
-        *(uint4*)(s_src + ry * RS_LW + 16 * c) = v;
+        sv[k] = make_uint4(0, 0, 0, 0);
+        if (i < nrows * (RS_LW / 16) && c < ncol16 && gy < src.h && gx + 16 <= src.stride) sv[k] = *(const uint4*)(sp + (size_t)gy * src.stride + gx);
+    }
+#pragma unroll
+    for (int k = 0; k < RS_NLD; k++) {
+        const int i = tid + 256 * k;
+        if (i < nrows * (RS_LW / 16)) *(uint4*)(s_src + (i / (RS_LW / 16)) * RS_LW + 16 * (i % (RS_LW / 16))) = sv[k];
     }
     const int dxg = tid & 31, rl = tid >> 5, dx = x0 + 4 * dxg;
     int o[4], c1[4];
@@ -157,32 +184,35 @@ __global__ __launch_bounds__(256) void k_resize_tiled(uint8_t* pyr, int frame_by
     for (int i = 0; i < 4; i++) { const int xi = min(dx + i, dst.w - 1); o[i] = tab.xofs[xi] - sx0; c1[i] = tab.xc1[xi]; }
     const int base = o[0] & ~3;
     const uint32_t sel = (uint32_t)(o[0] - base) | ((uint32_t)(o[1] - base) << 8) | ((uint32_t)(o[2] - base) << 16) | ((uint32_t)(o[3] - base) << 24);
+    const uint32_t c1e = (uint32_t)c1[0] | ((uint32_t)c1[2] << 16), c1o = (uint32_t)c1[1] | ((uint32_t)c1[3] << 16);
     __syncthreads();
+    // horizontal pass, two pixels per packed 16-bit operation: h = (a << 8) + c1 * (b - a) = (256 - c1) * a + c1 * b is
+    // at most 65280, so the low 16 bits of the packed multiply-add are the exact value.  Stored as (h0, h2), (h1, h3).
     for (int r = rl; r < nrows; r += 8) {
         const uint32_t* wp = (const uint32_t*)(s_src + r * RS_LW + base);
         const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
         const uint32_t lo = __builtin_amdgcn_perm(w1, w0, sel);
         const uint32_t hi = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(w2, w1, 1), __builtin_amdgcn_alignbyte(w1, w0, 1), sel);
-        uint32_t h[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int a = (lo >> (8 * i)) & 255, b = (hi >> (8 * i)) & 255;
-            h[i] = (uint32_t)((a << 8) + c1[i] * (b - a));          // (256 - c1) * a + c1 * b
-        }
-        *(uint2*)(s_h + r * RS_TW + 4 * dxg) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        const uint32_t a_e = lo & 0x00ff00ffu, a_o = (lo >> 8) & 0x00ff00ffu;
+        const uint32_t b_e = hi & 0x00ff00ffu, b_o = (hi >> 8) & 0x00ff00ffu;
+        const vo_u16x2 h_e = __builtin_bit_cast(vo_u16x2, c1e) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_e, a_e)) + __builtin_bit_cast(vo_u16x2, a_e << 8);
+        const vo_u16x2 h_o = __builtin_bit_cast(vo_u16x2, c1o) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_o, a_o)) + __builtin_bit_cast(vo_u16x2, a_o << 8);
+        *(uint2*)(s_h + r * RS_TW + 4 * dxg) = make_uint2(__builtin_bit_cast(uint32_t, h_e), __builtin_bit_cast(uint32_t, h_o));
     }
     __syncthreads();
+    // vertical pass: (upper row, lower row) of a pixel paired by v_perm_b32, blended by one v_dot2_u32_u16 (16.16, + 1/2)
     uint8_t* dp = pyr + (size_t)f * frame_bytes + dst.off;
     for (int rr = rl; rr < RS_TH; rr += 8) {
         const int dy = y0 + rr;
         if (dy >= dst.h) break;
         const int r0 = tab.yofs[dy] - sy0;
-        const uint32_t w1 = tab.yc1[dy], w0 = 256 - w1;
+        const uint32_t w1 = tab.yc1[dy], wq = (256u - w1) | (w1 << 16);
         const uint2 a = *(const uint2*)(s_h + r0 * RS_TW + 4 * dxg), b = *(const uint2*)(s_h + (r0 + 1) * RS_TW + 4 * dxg);
-        const uint32_t v0 = ((a.x & 0xffffu) * w0 + (b.x & 0xffffu) * w1 + 32768u) >> 16;
-        const uint32_t v1 = ((a.x >> 16) * w0 + (b.x >> 16) * w1 + 32768u) >> 16;
-        const uint32_t v2 = ((a.y & 0xffffu) * w0 + (b.y & 0xffffu) * w1 + 32768u) >> 16;
-        const uint32_t v3 = ((a.y >> 16) * w0 + (b.y >> 16) * w1 + 32768u) >> 16;
+        const vo_u16x2 wv = __builtin_bit_cast(vo_u16x2, wq);
+        const uint32_t v0 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.x, a.x, 0x05040100u)), wv, 32768u, false) >> 16;
+        const uint32_t v2 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.x, a.x, 0x07060302u)), wv, 32768u, false) >> 16;
+        const uint32_t v1 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.y, a.y, 0x05040100u)), wv, 32768u, false) >> 16;
+        const uint32_t v3 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.y, a.y, 0x07060302u)), wv, 32768u, false) >> 16;
         if (dx < dst.stride)
             *(uint32_t*)(dp + (size_t)dy * dst.stride + dx) = min(v0, 255u) | (min(v1, 255u) << 8) | (min(v2, 255u) << 16) | (min(v3, 255u) << 24);
     }
@@ -265,26 +295,6 @@ void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, in
 #define FT_QCAP 1024                     // candidate queue; a tile that overflows it takes the dense path
 #endif
 
-typedef short vo_s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short vo_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) - __builtin_bit_cast(vo_s16x2, b));
-}
-__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_s16x2, a) + __builtin_bit_cast(vo_s16x2, b));
-}
-__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(vo_s16x2, a), __builtin_bit_cast(vo_s16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vo_s16x2, a), __builtin_bit_cast(vo_s16x2, b)));
-}
-__device__ __forceinline__ uint32_t swap16(uint32_t a) { return __builtin_amdgcn_alignbit(a, a, 16); }
-
 // cornerScore<16> with the corner decision folded in: 0 if the pixel at c (centre in the LDS pixel tile) is
 // no FAST-9 corner, else max(A, B) - 1.  Q[k] holds the ring differences (d[k], d[k+8]) as two int16.
 __device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)
@@ -338,14 +348,25 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     const int t = g.fast_thr;
 
-    // A. stage pixels (16-byte loads)
+    // A. stage pixels: every 16-byte load of the lane is in flight before the first is consumed (addresses are
+    //    clamped into the level and out-of-image chunks zeroed afterwards, so the loads carry no control flow)
+    {
+        constexpr int NLD = (FT_PXH * (FT_PXW / 16) + 63) / 64;
+        uint4 pv[NLD];
 #pragma unroll
-    for (int i = lane; i < FT_PXH * (FT_PXW / 16); i += 64) {
-        const int ry = i / (FT_PXW / 16), rx = (i % (FT_PXW / 16)) * 16;
-        const int gy = y0 - 4 + ry, gx = x0 - 16 + rx;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < lv.h && gx >= 0 && gx + 16 <= lv.stride) v = *(const uint4*)(img + (size_t)gy * lv.stride + gx);
-        *(uint4*)(s_px + ry * FT_PXW + rx) = v;
+        for (int k = 0; k < NLD; k++) {
+            const int i = min(lane + 64 * k, FT_PXH * (FT_PXW / 16) - 1);
+            const int ry = i / (FT_PXW / 16), rx = (i % (FT_PXW / 16)) * 16;
+            const int gy = y0 - 4 + ry, gx = x0 - 16 + rx;
+            const bool in = gy >= 0 && gy < lv.h && gx >= 0 && gx + 16 <= lv.stride;
+            const uint4 v = *(const uint4*)(img + (size_t)min(max(gy, 0), lv.h - 1) * lv.stride + min(max(gx, 0), lv.stride - 16));
+            pv[k] = in ? v : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = lane + 64 * k;
+            if (i < FT_PXH * (FT_PXW / 16)) *(uint4*)(s_px + (i / (FT_PXW / 16)) * FT_PXW + (i % (FT_PXW / 16)) * 16) = pv[k];
+        }
     }
     __syncthreads();
 
@@ -912,12 +933,22 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
     const int x0 = (tile % lv.btiles_x) * BLUR_TW, y0 = (tile / lv.btiles_x) * BLUR_TH;
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     if (lv.w >= 16 && lv.h >= 4) {
-        for (int i = tid; i < BL_INH * (BL_INW / 16); i += 256) {
-            const int ry = i / (BL_INW / 16), rx = (i % (BL_INW / 16)) * 16;
-            const int gy = reflect101(y0 - 3 + ry, lv.h), gx = x0 - 16 + rx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gx >= 0 && gx + 16 <= lv.stride) v = *(const uint4*)(img + (size_t)gy * lv.stride + gx);
-            *(uint4*)(s_in + ry * BL_INW + rx) = v;
+        {   // all 16-byte loads of the lane in flight before the first is consumed
+            constexpr int NLD = (BL_INH * (BL_INW / 16) + 255) / 256;
+            uint4 bv[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int i = min(tid + 256 * k, BL_INH * (BL_INW / 16) - 1);
+                const int ry = i / (BL_INW / 16), rx = (i % (BL_INW / 16)) * 16;
+                const int gy = reflect101(y0 - 3 + ry, lv.h), gx = x0 - 16 + rx;
+                const uint4 v = *(const uint4*)(img + (size_t)gy * lv.stride + min(max(gx, 0), lv.stride - 16));
+                bv[k] = gx >= 0 && gx + 16 <= lv.stride ? v : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int i = tid + 256 * k;
+                if (i < BL_INH * (BL_INW / 16)) *(uint4*)(s_in + (i / (BL_INW / 16)) * BL_INW + (i % (BL_INW / 16)) * 16) = bv[k];
+            }
         }
         const bool left = x0 == 0, right = x0 + BLUR_TW + 3 > lv.w;
         if (left || right) {
@@ -965,11 +996,12 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
     __syncthreads();
     // vertical pass: lane = 4 columns x BL_ROWS_PER_LANE (4) rows = 5 row pairs; an output row is 4 x v_dot2_u32_u16
     // over the pairs it spans (tap pairs for rows starting on an even / odd staged row)
-    static_assert(BL_ROWS_PER_LANE == 4 && BL_INH % 2 == 0, "vertical pass works on row pairs");
+    static_assert(BL_ROWS_PER_LANE % 2 == 0 && BL_INH % 2 == 0, "vertical pass works on row pairs");
+    constexpr int BL_NP = BL_ROWS_PER_LANE / 2 + 3;
     const int cg = tid & 31, strip = tid >> 5;
-    uint4 pr[5];
+    uint4 pr[BL_NP];
 #pragma unroll
-    for (int r = 0; r < 5; r++) pr[r] = *(const uint4*)(s_h + ((strip * 2 + r) * BLUR_TW + cg * 4) * 2);
+    for (int r = 0; r < BL_NP; r++) pr[r] = *(const uint4*)(s_h + ((strip * (BL_ROWS_PER_LANE / 2) + r) * BLUR_TW + cg * 4) * 2);
     const uint32_t TE[4] = {18u | (34u << 16), 49u | (55u << 16), 49u | (34u << 16), 18u};
     const uint32_t TO[4] = {18u << 16, 34u | (49u << 16), 55u | (49u << 16), 34u | (18u << 16)};
     const int gx = x0 + cg * 4;

@@ -311,14 +311,14 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
         t.xofs = d_ofs + oi; t.xc1 = d_c + oi; oi += d.w;
         build_lin_tab(s.h, d.h, &hofs[oi], &hc[oi], &t.min_y, &t.max_y);
         t.yofs = d_ofs + oi; t.yc1 = d_c + oi; oi += d.h;
-        // does every 128 x 16 destination tile fit the tiled kernel's LDS window (192 x 24 source bytes,
+        // does every RS_TW x RS_TH destination tile fit the tiled kernel's LDS window (RS_LW x RS_LH source bytes,
         // 4 destination pixels within 8 source bytes)?
         {
             const int* xo = &hofs[oi - d.h - d.w]; const int* yo = &hofs[oi - d.h];
             bool ok = true;
             for (int x = 0; x + 3 < d.w && ok; x++) ok = xo[x + 3] - xo[x] <= 4;
-            for (int x0 = 0; x0 < d.w && ok; x0 += 128) { const int xl = (x0 + 128 < d.w ? x0 + 128 : d.w) - 1; ok = xo[xl] + 2 - (xo[x0] & ~15) <= 192 - 12; }
-            for (int y0 = 0; y0 < d.h && ok; y0 += 16) { const int yl = (y0 + 16 < d.h ? y0 + 16 : d.h) - 1; ok = yo[yl] + 2 - yo[y0] <= 24; }
+            for (int x0 = 0; x0 < d.w && ok; x0 += RS_TW) { const int xl = (x0 + RS_TW < d.w ? x0 + RS_TW : d.w) - 1; ok = xo[xl] + 2 - (xo[x0] & ~15) <= RS_LW - 12; }
+            for (int y0 = 0; y0 < d.h && ok; y0 += RS_TH) { const int yl = (y0 + RS_TH < d.h ? y0 + RS_TH : d.h) - 1; ok = yo[yl] + 2 - yo[y0] <= RS_LH; }
             t.tiled = ok ? 1 : 0;
         }
     }

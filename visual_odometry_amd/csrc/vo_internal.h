@@ -38,6 +38,13 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
     int tiled;                   // 1: geometry fits k_resize_tiled's LDS tile (scale factor <= 4/3)
 };
 
+// k_resize_tiled: destination tile and the LDS window of source bytes / rows it may need at scale factors <= 4/3
+#define RS_TW 128
+#ifndef RS_TH
+#define RS_TH 32
+#endif
+#define RS_LW 192
+#define RS_LH ((RS_TH * 4 + 2) / 3 + 3)
 #ifndef FAST_TW
 #define FAST_TW 112
 #endif
@@ -45,7 +52,9 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
 #define FAST_TH 24
 #endif
 #define BLUR_TW 128
-#define BLUR_TH 32
+#ifndef BLUR_TH
+#define BLUR_TH 48
+#endif
 #define SEL_ROWS 8
 
 // per-frame feature arrays (device), F = number of slots
