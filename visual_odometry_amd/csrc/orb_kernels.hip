@@ -617,39 +617,57 @@ __global__ __launch_bounds__(64) void k_sel_scan(const uint8_t* score, PyrGeom g
     float* out_resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
     int total = 0;
     bool overflow = false;
-    for (int y = y_first; y < y_last; y++) {
-        const uint8_t* row = sc + (size_t)y * lv.stride;
-        for (int s0 = 0; s0 < nseg; s0 += 64) {
-            const int seg = s0 + lane;
-            uint32_t m = 0;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int sx = (seg_lo + seg) * 16;
-            if (seg < nseg) {
-                v = *(const uint4*)(row + sx);
-                if (v.x | v.y | v.z | v.w) {
-                    m = mask16_ge(v, t4);
-                    const int lo = max(xlo - sx, 0), hi = min(xhi - sx, 16);
-                    m &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                }
-            }
-            const int cnt = __popc(m);
-            if (!EMIT) { total += cnt; continue; }
-            int inc = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-            int pos = base + total + inc - cnt;
-            total += __shfl(inc, 63, 64);
-            while (m) {
-                const int b = __ffs((int)m) - 1;
-                m &= m - 1;
-                const uint32_t word = b < 4 ? v.x : b < 8 ? v.y : b < 12 ? v.z : v.w;
-                if (pos < lv.cand_cap) {
-                    out_pos[pos] = ((uint32_t)y << 16) | (uint32_t)(sx + b);
-                    out_resp[pos] = (float)((word >> (8 * (b & 3))) & 255u);
-                } else overflow = true;
-                pos++;
-            }
+    // one 16-byte segment of row y: count / emit the kept pixels (raster order is the order of the calls)
+    auto body = [&](const uint4 v, const int y, const int seg) {
+        uint32_t m = 0;
+        const int sx = (seg_lo + seg) * 16;
+        if (seg < nseg && (v.x | v.y | v.z | v.w)) {
+            m = mask16_ge(v, t4);
+            const int lo = max(xlo - sx, 0), hi = min(xhi - sx, 16);
+            m &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
         }
+        const int cnt = __popc(m);
+        if (!EMIT) { total += cnt; return; }
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        int pos = base + total + inc - cnt;
+        total += __shfl(inc, 63, 64);
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            const uint32_t word = b < 4 ? v.x : b < 8 ? v.y : b < 12 ? v.z : v.w;
+            if (pos < lv.cand_cap) {
+                out_pos[pos] = ((uint32_t)y << 16) | (uint32_t)(sx + b);
+                out_resp[pos] = (float)((word >> (8 * (b & 3))) & 255u);
+            } else overflow = true;
+            pos++;
+        }
+    };
+    if (nseg <= 128) {
+        // the whole chunk (SEL_ROWS rows x up to two 64-segment blocks) is requested before the first segment is
+        // looked at: the scan is bound by load latency, not by its arithmetic
+        uint4 v[SEL_ROWS][2];
+#pragma unroll
+        for (int r = 0; r < SEL_ROWS; r++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const int y = min(y_first + r, y_last - 1), seg = min(64 * b + lane, nseg - 1);
+                v[r][b] = (b == 0 || nseg > 64) ? *(const uint4*)(sc + (size_t)y * lv.stride + (seg_lo + seg) * 16) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < SEL_ROWS; r++) {
+            if (y_first + r >= y_last) break;                      // wave-uniform
+            body(v[r][0], y_first + r, lane);
+            if (nseg > 64) body(v[r][1], y_first + r, 64 + lane);
+        }
+    } else {
+        for (int y = y_first; y < y_last; y++)
+            for (int s0 = 0; s0 < nseg; s0 += 64) {
+                const int seg = s0 + lane;
+                const uint4 v = *(const uint4*)(sc + (size_t)y * lv.stride + (seg_lo + min(seg, nseg - 1)) * 16);
+                body(v, y, seg);
+            }
     }
     if (!EMIT) {
 #pragma unroll
@@ -672,10 +690,12 @@ void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, F
 // ------------------------------------------------------------------ Harris response (orb.cpp HarrisResponses)
 // One lane per candidate; the 9x9 neighbourhood is fetched as 9 rows x 3 unaligned dwords and kept in
 // registers, the 49 Sobel pairs are evaluated from there (no per-tap memory access).
-__global__ __launch_bounds__(256) void k_harris(const uint8_t* pyr, PyrGeom g, FrameFeat ff)
+__global__ __launch_bounds__(256) void k_harris(const uint8_t* pyr, PyrGeom g, FrameFeat ff, int blocks_per_level)
 {
-    const int l = blockIdx.y, f = blockIdx.z;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // candidates are in raster order: consecutive blocks of one (frame, level) share image rows, keep them on one XCD
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int f = bid / (blocks_per_level * g.nlevels), l = (bid / blocks_per_level) % g.nlevels;
+    const int i = (bid % blocks_per_level) * 256 + threadIdx.x;
     const LevelGeom lv = g.lv[l];
     if (i >= min(ff.cand_count[f * VO_MAX_LEVELS + l], lv.cand_cap)) return;
     const size_t ci = (size_t)f * g.cand_total + lv.cand_off + i;
@@ -714,7 +734,8 @@ void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFea
 {
     int maxcap = 0;
     for (int l = 0; l < g.nlevels; l++) maxcap = g.lv[l].cand_cap > maxcap ? g.lv[l].cand_cap : maxcap;
-    hipLaunchKernelGGL(k_harris, dim3((maxcap + 255) / 256, g.nlevels, F), dim3(256), 0, s, pyr, g, ff);
+    const int bpl = (maxcap + 255) / 256;
+    hipLaunchKernelGGL(k_harris, dim3(bpl * g.nlevels * F), dim3(256), 0, s, pyr, g, ff, bpl);
 }
 
 // ------------------------------------------------------------------ retainBest by response (per level), canonical order
@@ -863,42 +884,63 @@ __constant__ uint32_t c_disc_mask[16][8] = {
 #undef DM
 };
 
+#ifndef ANG_KPW
+#define ANG_KPW 4                         // keypoints per wavefront: their dependent load chains overlap
+#endif
 __global__ __launch_bounds__(256) void k_angle(const uint8_t* pyr, PyrGeom g, FrameFeat ff, int blocks_per_frame)
 {
     // keypoints are stored in (level, y, x) order: a contiguous run of them per XCD lets neighbouring patches
     // share image lines through that XCD's L2 instead of fetching them once per XCD
     const int bid = xcd_tile(blockIdx.x, gridDim.x);
     const int f = bid / blocks_per_frame, lane = threadIdx.x & 63;
-    const int k = (bid % blocks_per_frame) * 4 + (threadIdx.x >> 6);
-    if (k >= min(ff.kp_count[f], g.kp_cap)) return;
-    const size_t ki = (size_t)f * g.kp_cap + k;
-    const uint32_t pos = ff.kp_pos[ki];
-    const LevelGeom lv = g.lv[ff.kp_level[ki]];
-    const int x0 = pos & 0xffff, y0 = pos >> 16;
-    const uint8_t* corner = pyr + (size_t)f * g.frame_bytes + lv.off + (size_t)(y0 - 15) * lv.stride + (x0 - 15);
-    int m10 = 0, m01 = 0;
+    const int k0 = ((bid % blocks_per_frame) * 4 + (threadIdx.x >> 6)) * ANG_KPW;
+    const int cnt = min(ff.kp_count[f], g.kp_cap);
+    if (k0 >= cnt) return;
+    // the kernel is bound by the latency of (keypoint record -> patch rows): all records first, then all 16 patch
+    // loads of the lane, then the arithmetic
+    const uint8_t* corner[ANG_KPW];
+    int stride[ANG_KPW];
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int idx = it * 64 + lane;
-        if (idx < 248) {
-            const int r = idx >> 3, j = idx & 7, v = r - 15, av = v < 0 ? -v : v;
-            uint32_t w;
-            __builtin_memcpy(&w, corner + (size_t)r * lv.stride + 4 * j, 4);
-            w &= c_disc_mask[av][j];
-            const int sum = (int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
-            const int wsum = (int)__builtin_amdgcn_udot4(w, 0x03020100u, 0u, false);
+    for (int q = 0; q < ANG_KPW; q++) {
+        const size_t ki = (size_t)f * g.kp_cap + min(k0 + q, cnt - 1);
+        const uint32_t pos = __builtin_amdgcn_readfirstlane(ff.kp_pos[ki]);
+        const int level = __builtin_amdgcn_readfirstlane(ff.kp_level[ki]);
+        stride[q] = g.lv[level].stride;
+        corner[q] = pyr + (size_t)f * g.frame_bytes + g.lv[level].off + (size_t)((int)(pos >> 16) - 15) * stride[q] + ((int)(pos & 0xffff) - 15);
+    }
+    uint32_t w[ANG_KPW][4];
+#pragma unroll
+    for (int q = 0; q < ANG_KPW; q++)
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int idx = min(it * 64 + lane, 247);
+            __builtin_memcpy(&w[q][it], corner[q] + (size_t)(idx >> 3) * stride[q] + 4 * (idx & 7), 4);
+        }
+    float m10f = 0.f, m01f = 0.f;
+#pragma unroll
+    for (int q = 0; q < ANG_KPW; q++) {
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int idx = it * 64 + lane;
+            const int r = min(idx, 247) >> 3, j = idx & 7, v = r - 15, av = v < 0 ? -v : v;
+            const uint32_t x = idx < 248 ? w[q][it] & c_disc_mask[av][j] : 0u;
+            const int sum = (int)__builtin_amdgcn_udot4(x, 0x01010101u, 0u, false);
+            const int wsum = (int)__builtin_amdgcn_udot4(x, 0x03020100u, 0u, false);
             m10 += (4 * j - 15) * sum + wsum;
             m01 += v * sum;
         }
-    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
-    if (lane == 0) ff.kp_angle[ki] = fast_atan2_deg((float)m01, (float)m10);
+        for (int d = 32; d >= 1; d >>= 1) { m10 += __shfl_xor(m10, d, 64); m01 += __shfl_xor(m01, d, 64); }
+        if (lane == q) { m10f = (float)m10; m01f = (float)m01; }
+    }
+    // lane q finishes keypoint q
+    if (lane < ANG_KPW && k0 + lane < cnt) ff.kp_angle[(size_t)f * g.kp_cap + k0 + lane] = fast_atan2_deg(m01f, m10f);
 }
 
 void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F)
 {
-    const int bpf = (g.kp_cap + 3) / 4;
+    const int bpf = (g.kp_cap + 4 * ANG_KPW - 1) / (4 * ANG_KPW);
     hipLaunchKernelGGL(k_angle, dim3(bpf * F), dim3(256), 0, s, pyr, g, ff, bpf);
 }
 
@@ -1053,48 +1095,90 @@ __global__ __launch_bounds__(256) void k_brief_trig(PyrGeom g, FrameFeat ff)
     ff.kp_xy[ki * 2 + 1] = (float)sin((double)angle);
 }
 
+// The 256 test pairs sample a disc of radius 18.4 around the keypoint (the pattern's extreme point is (-13, -13)):
+// 512 single-byte gathers per keypoint saturate the texture addresser, so each wavefront first copies its
+// keypoint's 37-row x 48/64-byte window into LDS with aligned 16-byte loads and then gathers from LDS.
+#define BR_R 18
+#define BR_ROWS (2 * BR_R + 1)
+#ifndef BR_KPW
+#define BR_KPW 2                          // keypoints per wavefront: their record -> window -> gather chains overlap
+#endif
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff, uint8_t* desc_x, int cap_x, int blocks_per_frame)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][BR_KPW][BR_ROWS * 64];
     const int bid = xcd_tile(blockIdx.x, gridDim.x);          // a contiguous run of keypoints per XCD (see k_angle)
-    const int f = bid / blocks_per_frame, lane = threadIdx.x & 63;
-    const int k = (bid % blocks_per_frame) * 4 + (threadIdx.x >> 6);
-    if (k >= min(ff.kp_count[f], g.kp_cap)) return;
-    const size_t ki = (size_t)f * g.kp_cap + k;
-    const uint32_t pos = ff.kp_pos[ki];
-    const int level = ff.kp_level[ki];
-    const LevelGeom lv = g.lv[level];
-    const int x0 = pos & 0xffff, y0 = pos >> 16;
-    const float sf = lv.scale;
-    const float kx = (float)x0 * sf, ky = (float)y0 * sf;
-    // computeOrbDescriptors re-derives the level position from the scaled keypoint
-    const float inv = 1.f / sf;
-    const int cx = __float2int_rn(kx * inv), cy = __float2int_rn(ky * inv);
-    const float a = ff.kp_xy[ki * 2], b = ff.kp_xy[ki * 2 + 1];         // k_brief_trig
-    const uint8_t* center = blur + (size_t)f * g.frame_bytes + lv.off + (size_t)cy * lv.stride + cx;
-    uint64_t words[4];
+    const int f = bid / blocks_per_frame, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = ((bid % blocks_per_frame) * 4 + wave) * BR_KPW;
+    const int cnt = min(ff.kp_count[f], g.kp_cap);
+    if (k0 >= cnt) return;
+    float ca[BR_KPW], cb[BR_KPW], kxs[BR_KPW], kys[BR_KPW], sfs[BR_KPW];
+    int coff[BR_KPW];
+    uint4 wv[BR_KPW][3];
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const int8_t* pt = c_pattern + (w * 64 + lane) * 4;
-        const float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
-        const float xa = px0 * a - py0 * b, ya = px0 * b + py0 * a;
-        const float xb = px1 * a - py1 * b, yb = px1 * b + py1 * a;
-        const int t0 = center[__float2int_rn(ya) * lv.stride + __float2int_rn(xa)];
-        const int t1 = center[__float2int_rn(yb) * lv.stride + __float2int_rn(xb)];
-        words[w] = __ballot(t0 < t1);
+    for (int q = 0; q < BR_KPW; q++) {
+        const size_t ki = (size_t)f * g.kp_cap + min(k0 + q, cnt - 1);
+        const uint32_t pos = __builtin_amdgcn_readfirstlane(ff.kp_pos[ki]);
+        const int level = __builtin_amdgcn_readfirstlane(ff.kp_level[ki]);
+        const float sf = g.lv[level].scale;
+        const int stride = g.lv[level].stride, lh = g.lv[level].h;
+        const float kx = (float)(pos & 0xffff) * sf, ky = (float)(pos >> 16) * sf;
+        // computeOrbDescriptors re-derives the level position from the scaled keypoint
+        const float inv = 1.f / sf;
+        const int cx = __float2int_rn(kx * inv), cy = __float2int_rn(ky * inv);
+        ca[q] = ff.kp_xy[ki * 2]; cb[q] = ff.kp_xy[ki * 2 + 1];             // k_brief_trig
+        kxs[q] = kx; kys[q] = ky; sfs[q] = sf;
+        const uint8_t* img = blur + (size_t)f * g.frame_bytes + g.lv[level].off;
+        const int xs = (cx - BR_R) & ~15;                      // window columns xs .. xs + 63 (keypoints keep 32 px to the border)
+        const int nchunk = (cx - BR_R - xs) + 2 * BR_R + 1 > 48 ? 4 : 3;     // 16-byte chunks the 37 columns really span
+        coff[q] = BR_R * 64 + (cx - xs);
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int idx = min(it * 64 + lane, BR_ROWS * 4 - 1);
+            const int r = idx >> 2, c = idx & 3;
+            // an unneeded fourth chunk re-reads the first one (same line, no control flow around the loads)
+            const int gy = min(max(cy - BR_R + r, 0), lh - 1), gx = min(max(xs + (c < nchunk ? 16 * c : 0), 0), stride - 16);
+            wv[q][it] = *(const uint4*)(img + (size_t)gy * stride + gx);
+        }
     }
-    if (lane < 4) {
-        uint64_t wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-        *(uint64_t*)(ff.desc + ki * 32 + lane * 8) = wv;
-    }
-    if (lane < 16) {
-        const uint64_t wv = lane < 4 ? words[0] : lane < 8 ? words[1] : lane < 12 ? words[2] : words[3];
-        const uint32_t bits = (uint32_t)(wv >> (16 * (lane & 3))) & 0xffffu;
-        const uint4 o = make_uint4(brief_expand4(bits & 15u), brief_expand4((bits >> 4) & 15u), brief_expand4((bits >> 8) & 15u), brief_expand4(bits >> 12));
-        *(uint4*)(desc_x + (((size_t)f * cap_x + (k & ~15)) * 16 + (size_t)lane * 16 + (k & 15)) * 16) = o;
-    }
-    if (lane == 0) {
-        ff.kp_xy[ki * 2] = kx; ff.kp_xy[ki * 2 + 1] = ky;
-        ff.kp_size[ki] = 31 * sf;
+#pragma unroll
+    for (int q = 0; q < BR_KPW; q++)
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int idx = it * 64 + lane;
+            if (idx < BR_ROWS * 4) *(uint4*)(s_win[wave][q] + idx * 16) = wv[q][it];
+        }
+#pragma unroll
+    for (int q = 0; q < BR_KPW; q++) {
+        const int k = k0 + q;
+        if (k >= cnt) break;                                   // wave-uniform
+        const size_t ki = (size_t)f * g.kp_cap + k;
+        const uint8_t* center = s_win[wave][q] + coff[q];
+        const float a = ca[q], b = cb[q];
+        uint64_t words[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int8_t* pt = c_pattern + (w * 64 + lane) * 4;
+            const float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
+            const float xa = px0 * a - py0 * b, ya = px0 * b + py0 * a;
+            const float xb = px1 * a - py1 * b, yb = px1 * b + py1 * a;
+            const int t0 = center[__float2int_rn(ya) * 64 + __float2int_rn(xa)];
+            const int t1 = center[__float2int_rn(yb) * 64 + __float2int_rn(xb)];
+            words[w] = __ballot(t0 < t1);
+        }
+        if (lane < 4) {
+            uint64_t wv8 = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+            *(uint64_t*)(ff.desc + ki * 32 + lane * 8) = wv8;
+        }
+        if (lane < 16) {
+            const uint64_t wv8 = lane < 4 ? words[0] : lane < 8 ? words[1] : lane < 12 ? words[2] : words[3];
+            const uint32_t bits = (uint32_t)(wv8 >> (16 * (lane & 3))) & 0xffffu;
+            const uint4 o = make_uint4(brief_expand4(bits & 15u), brief_expand4((bits >> 4) & 15u), brief_expand4((bits >> 8) & 15u), brief_expand4(bits >> 12));
+            *(uint4*)(desc_x + (((size_t)f * cap_x + (k & ~15)) * 16 + (size_t)lane * 16 + (k & 15)) * 16) = o;
+        }
+        if (lane == 0) {
+            ff.kp_xy[ki * 2] = kxs[q]; ff.kp_xy[ki * 2 + 1] = kys[q];
+            ff.kp_size[ki] = 31 * sfs[q];
+        }
     }
 }
 
@@ -1102,6 +1186,6 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
 void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x)
 {
     hipLaunchKernelGGL(k_brief_trig, dim3((g.kp_cap + 255) / 256, F), dim3(256), 0, s, g, ff);
-    const int bpf = (g.kp_cap + 3) / 4;
+    const int bpf = (g.kp_cap + 4 * BR_KPW - 1) / (4 * BR_KPW);
     hipLaunchKernelGGL(k_brief, dim3(bpf * F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x, bpf);
 }
