@@ -38,10 +38,10 @@ def ping_pong(n_distinct, n_total, start=0):
     return np.array(idx)
 
 
-STAGE_KERNELS = {"fast_score_nms": [("k_fast", 1)], "gaussian_blur": [("k_blur", 1)],
+STAGE_KERNELS = {"fast_score_nms": [("k_fast<false>", 1)], "gaussian_blur": [("k_blur", 1)],
                  "pyramid_resize": [("k_resize_tiled", 7)],
-                 "select_fast": [("k_sel_threshold", 1), ("k_sel_scan<false>", 1), ("k_sel_scan<true>", 1)],
-                 "match_nn": [("k_nn_pairs<false>", 1)], "essential_ransac": [("k_ransac", 1)]}
+                 "select_fast": [("k_sel_threshold", 1), ("k_sel_rows<false>", 1), ("k_sel_rows<true>", 1)],
+                 "match_nn": [("k_nn_mfma<false>", 1)], "essential_ransac": [("k_ransac", 1)]}
 
 
 def pmc_traffic(stage, nframes):
@@ -306,7 +306,7 @@ def main():
                                 "measured": f"HIP events, {prof_steps} single-context steps right after the timed region "
                                             f"(the timed region overlaps {n_ctx} contexts)"}
             hbm_stages = {}
-            for k in ("pyramid_resize", "fast_score_nms", "select_fast", "gaussian_blur"):
+            for k in ("pyramid_resize", "fast_score_nms", "gaussian_blur"):
                 if k in prof:
                     bb = fe.stage_bytes(k, nframes)
                     hbm_stages[k] = round(bb / (prof[k][0] / prof[k][1] * 1e-3) / 1e9, 1)

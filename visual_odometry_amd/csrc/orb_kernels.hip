@@ -291,6 +291,7 @@ void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, in
 #define FT_SCW (FAST_TW + 16)            // LDS score tile: columns x0-4 .. x0+TW+11 (dword aligned with the output)
 #define FT_SCH (FAST_TH + 2)             // rows y0-1 .. y0+TH
 #define FT_GROUPS_X (FAST_TW / 4 + 2)    // dword groups covering x0-4 .. x0+TW+3
+#define FT_LISTCAP ((FAST_TW / 2) * (FAST_TH / 2))   // a 3x3 NMS leaves at most one winner per 2x2 block
 #ifndef FT_QCAP
 #define FT_QCAP 1024                     // candidate queue; a tile that overflows it takes the dense path
 #endif
@@ -331,7 +332,12 @@ __device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)
     return m > t ? m - 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g)
+// DENSE = true writes the score map (the stage API / tests); false (the pipeline) writes, per tile, the list of NMS
+// winners inside the border as (score << 16 | row in tile << 8 | column in tile) and their number: retainBest then
+// works on a few thousand entries per frame instead of scanning 2.9 M score bytes twice.
+template <bool DENSE>
+__global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g,
+                                             uint32_t* tile_list, int* tile_count)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
@@ -441,6 +447,8 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     for (int i = lane; i < FT_SCH * FT_SCW / 16; i += 64) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
+    int nw = 0;                                       // wave-uniform number of listed winners
+    uint32_t* my_list = DENSE ? nullptr : tile_list + ((size_t)f * g.ftiles_total + bid) * FT_LISTCAP;
     if (qn <= FT_QCAP) {
         // C. cornerScore for the queued candidates, two per lane (two independent chains of LDS reads in flight);
         //    the real corners (about 40 % of the candidates) are compacted in place at the front of the queue
@@ -476,8 +484,16 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
                 const bool win = inside && sv > c[-1] && sv > c[1] && sv > c[-FT_SCW - 1] && sv > c[-FT_SCW] && sv > c[-FT_SCW + 1] &&
                                  sv > c[FT_SCW - 1] && sv > c[FT_SCW] && sv > c[FT_SCW + 1];
                 if (has && !win) lose |= 1u << (k + h);
-                if (has && win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge)
-                    atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
+                const bool keep = has && win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge;
+                if (keep) atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
+                if (!DENSE) {
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {                                                   // wave-uniform
+                        const int slot = nw + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (keep) my_list[slot] = ((uint32_t)sv << 16) | ((uint32_t)(gr - 1) << 8) | (uint32_t)(cx - 4);
+                        nw += (int)__popcll(m);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -502,12 +518,22 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
                              sv > c[FT_SCW - 1] && sv > c[FT_SCW] && sv > c[FT_SCW + 1];
             s_out[i] = win ? (uint8_t)sv : 0;
             const int gx = x0 + tx, gy = y0 + ty;
-            if (win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge)
-                atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
+            const bool keep = win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge;
+            if (keep) atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
+            if (!DENSE) {                                  // FAST_TH * FAST_TW is a multiple of 64: every lane gets here
+                const unsigned long long m = __ballot(keep);
+                const int slot = nw + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (keep) my_list[slot] = ((uint32_t)sv << 16) | ((uint32_t)ty << 8) | (uint32_t)tx;
+                nw += (int)__popcll(m);
+            }
         }
         __syncthreads();
         for (int i = lane; i < FAST_TH * FAST_TW; i += 64) s_sc[(i / FAST_TW + 1) * FT_SCW + 4 + i % FAST_TW] = s_out[i];
         __syncthreads();
+    }
+    if (!DENSE) {
+        if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = nw;
+        return;
     }
     // E. dense store of the tile rows, 16 bytes per lane
 #pragma unroll
@@ -520,9 +546,12 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     }
 }
 
-void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F)
+static_assert((FAST_TH * FAST_TW) % 64 == 0, "the dense fallback appends with full-wave ballots");
+void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F,
+                 uint32_t* tile_list, int* tile_count)
 {
-    hipLaunchKernelGGL(k_fast, dim3(g.ftiles_total, F), dim3(64), 0, s, pyr, score, hist, g);
+    if (tile_list) hipLaunchKernelGGL(k_fast<false>, dim3(g.ftiles_total, F), dim3(64), 0, s, pyr, score, hist, g, tile_list, tile_count);
+    else hipLaunchKernelGGL(k_fast<true>, dim3(g.ftiles_total, F), dim3(64), 0, s, pyr, score, hist, g, tile_list, tile_count);
 }
 
 // ------------------------------------------------------------------ retainBest by FAST score
@@ -584,15 +613,20 @@ __global__ __launch_bounds__(64) void k_sel_threshold(PyrGeom g, FrameFeat ff, i
     }
 }
 
+// One wavefront per (frame, level, row of FAST tiles).  COUNT: how many listed winners reach the threshold.
+// EMIT: the kept winners of the tile row are gathered into LDS (ballot + prefix), each one's rank among them in
+// (y, x) order is counted against the LDS copy (keys are unique), and it is written at base + rank, base = the kept
+// counts of the tile rows above: canonical raster order without sorting and without touching a score map.
 template <bool EMIT>
-__global__ __launch_bounds__(64) void k_sel_scan(const uint8_t* score, PyrGeom g, FrameFeat ff, const int* thr,
-                                                 int* chunk_count)
+__global__ __launch_bounds__(64) void k_sel_rows(const uint32_t* tile_list, const int* tile_count, PyrGeom g, FrameFeat ff,
+                                                 const int* thr, int* chunk_count, int lds_cap)
 {
+    extern __shared__ uint32_t s_sel[];               // EMIT: keys [lds_cap] then scores [lds_cap]
     const int f = blockIdx.y, lane = threadIdx.x;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].sel_chunk_base) l++;
     const LevelGeom lv = g.lv[l];
-    const int chunk = blockIdx.x - lv.sel_chunk_base;
+    const int chunk = blockIdx.x - lv.sel_chunk_base;                 // tile row
     const int T = thr[f * VO_MAX_LEVELS + l];
     int* my_count = chunk_count + (size_t)f * g.sel_chunks_total + blockIdx.x;
     const int nchunks = (l + 1 < g.nlevels ? g.lv[l + 1].sel_chunk_base : g.sel_chunks_total) - lv.sel_chunk_base;
@@ -601,11 +635,7 @@ __global__ __launch_bounds__(64) void k_sel_scan(const uint8_t* score, PyrGeom g
         if (EMIT && chunk == 0 && lane == 0) ff.cand_count[f * VO_MAX_LEVELS + l] = 0;
         return;
     }
-    const int edge = g.edge, xlo = edge, xhi = lv.w - edge;            // kept columns [xlo, xhi)
-    const int y_first = edge + chunk * SEL_ROWS, y_last = min(y_first + SEL_ROWS, lv.h - edge);
-    const int seg_lo = xlo >> 4, nseg = ((xhi - 1) >> 4) - seg_lo + 1;   // 16-byte segments per row
-    const uint8_t* sc = score + (size_t)f * g.frame_bytes + lv.off;
-    const uint32_t t4 = (uint32_t)T * 0x01010101u;
+    const size_t tile0 = (size_t)f * g.ftiles_total + lv.ftile_base + (size_t)chunk * lv.ftiles_x;
     int base = 0;
     if (EMIT) {
         const int* cc = chunk_count + (size_t)f * g.sel_chunks_total + lv.sel_chunk_base;
@@ -613,78 +643,60 @@ __global__ __launch_bounds__(64) void k_sel_scan(const uint8_t* score, PyrGeom g
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) base += __shfl_xor(base, d, 64);
     }
-    uint32_t* out_pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
-    float* out_resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
-    int total = 0;
-    bool overflow = false;
-    // one 16-byte segment of row y: count / emit the kept pixels (raster order is the order of the calls)
-    auto body = [&](const uint4 v, const int y, const int seg) {
-        uint32_t m = 0;
-        const int sx = (seg_lo + seg) * 16;
-        if (seg < nseg && (v.x | v.y | v.z | v.w)) {
-            m = mask16_ge(v, t4);
-            const int lo = max(xlo - sx, 0), hi = min(xhi - sx, 16);
-            m &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-        }
-        const int cnt = __popc(m);
-        if (!EMIT) { total += cnt; return; }
-        int inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-        int pos = base + total + inc - cnt;
-        total += __shfl(inc, 63, 64);
-        while (m) {
-            const int b = __ffs((int)m) - 1;
-            m &= m - 1;
-            const uint32_t word = b < 4 ? v.x : b < 8 ? v.y : b < 12 ? v.z : v.w;
-            if (pos < lv.cand_cap) {
-                out_pos[pos] = ((uint32_t)y << 16) | (uint32_t)(sx + b);
-                out_resp[pos] = (float)((word >> (8 * (b & 3))) & 255u);
-            } else overflow = true;
-            pos++;
-        }
-    };
-    if (nseg <= 128) {
-        // the whole chunk (SEL_ROWS rows x up to two 64-segment blocks) is requested before the first segment is
-        // looked at: the scan is bound by load latency, not by its arithmetic
-        uint4 v[SEL_ROWS][2];
-#pragma unroll
-        for (int r = 0; r < SEL_ROWS; r++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                const int y = min(y_first + r, y_last - 1), seg = min(64 * b + lane, nseg - 1);
-                v[r][b] = (b == 0 || nseg > 64) ? *(const uint4*)(sc + (size_t)y * lv.stride + (seg_lo + seg) * 16) : make_uint4(0, 0, 0, 0);
+    int n = 0;                                        // wave-uniform: kept winners of this tile row
+    for (int t = 0; t < lv.ftiles_x; t++) {
+        const int cnt = min(tile_count[tile0 + t], FT_LISTCAP);
+        const uint32_t* lst = tile_list + (tile0 + t) * FT_LISTCAP;
+        for (int j0 = 0; j0 < cnt; j0 += 64) {
+            const int j = j0 + lane;
+            const uint32_t e = j < cnt ? lst[j] : 0u;
+            const bool kept = j < cnt && (int)(e >> 16) >= T;
+            const unsigned long long m = __ballot(kept);
+            if (EMIT) {
+                const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (kept && slot < lds_cap) {
+                    const uint32_t gy = (uint32_t)(chunk * FAST_TH) + ((e >> 8) & 255u), gx = (uint32_t)(t * FAST_TW) + (e & 255u);
+                    s_sel[slot] = (gy << 16) | gx;
+                    s_sel[lds_cap + slot] = e >> 16;
+                }
             }
-#pragma unroll
-        for (int r = 0; r < SEL_ROWS; r++) {
-            if (y_first + r >= y_last) break;                      // wave-uniform
-            body(v[r][0], y_first + r, lane);
-            if (nseg > 64) body(v[r][1], y_first + r, 64 + lane);
+            n += (int)__popcll(m);
         }
-    } else {
-        for (int y = y_first; y < y_last; y++)
-            for (int s0 = 0; s0 < nseg; s0 += 64) {
-                const int seg = s0 + lane;
-                const uint4 v = *(const uint4*)(sc + (size_t)y * lv.stride + (seg_lo + min(seg, nseg - 1)) * 16);
-                body(v, y, seg);
-            }
     }
     if (!EMIT) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
-        if (lane == 0) *my_count = total;
-    } else {
-        if (overflow) atomicOr(&ff.flags[f], 1);
-        if (chunk == nchunks - 1 && lane == 0) ff.cand_count[f * VO_MAX_LEVELS + l] = min(base + total, lv.cand_cap);
+        if (lane == 0) *my_count = n;
+        return;
     }
+    bool overflow = n > lds_cap;
+    const int nk = min(n, lds_cap);
+    __syncthreads();
+    uint32_t* out_pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
+    float* out_resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
+    for (int i0 = 0; i0 < nk; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t key = s_sel[min(i, nk - 1)];
+        int rank = 0;
+        for (int j = 0; j < nk; j++) rank += s_sel[j] < key ? 1 : 0;       // wave-wide broadcast reads
+        const int pos = base + rank;
+        if (i < nk) {
+            if (pos < lv.cand_cap) { out_pos[pos] = key; out_resp[pos] = (float)s_sel[lds_cap + i]; }
+            else overflow = true;
+        }
+    }
+    if (overflow) atomicOr(&ff.flags[f], 1);
+    if (chunk == nchunks - 1 && lane == 0) ff.cand_count[f * VO_MAX_LEVELS + l] = min(base + n, lv.cand_cap);
 }
 
-void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count)
+void launch_select_fast(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count,
+                        const uint32_t* tile_list, const int* tile_count)
 {
     hipLaunchKernelGGL(k_sel_threshold, dim3(g.nlevels, F), dim3(64), 0, s, g, ff, thr);
     if (g.sel_chunks_total <= 0) return;
-    hipLaunchKernelGGL(k_sel_scan<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, score, g, ff, thr, chunk_count);
-    hipLaunchKernelGGL(k_sel_scan<true>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, score, g, ff, thr, chunk_count);
+    int cap = 0;
+    for (int l = 0; l < g.nlevels; l++) cap = g.lv[l].cand_cap > cap ? g.lv[l].cand_cap : cap;
+    if (cap > 7680) cap = 7680;                       // 60 KB of LDS; a tile row holding more kept corners is truncated and flagged
+    hipLaunchKernelGGL(k_sel_rows<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, tile_list, tile_count, g, ff, thr, chunk_count, cap);
+    hipLaunchKernelGGL(k_sel_rows<true>, dim3(g.sel_chunks_total, F), dim3(64), (size_t)cap * 8, s, tile_list, tile_count, g, ff, thr, chunk_count, cap);
 }
 
 // ------------------------------------------------------------------ Harris response (orb.cpp HarrisResponses)

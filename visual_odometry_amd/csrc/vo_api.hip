@@ -148,7 +148,7 @@ static int make_geometry(vo_ctx* ctx, int h, int w, const vo_orb_params* p, PyrG
         bt += lv.btiles_x * ((lv.h + BLUR_TH - 1) / BLUR_TH);
         const int want = p->score_type == 0 ? 2 * lv.quota : lv.quota;
         lv.sel_chunk_base = sc;
-        { const int rows = lv.h - 2 * p->edge_threshold; if (rows > 0 && lv.w > 2 * p->edge_threshold) sc += (rows + SEL_ROWS - 1) / SEL_ROWS; }
+        sc += (lv.h + FAST_TH - 1) / FAST_TH;
         lv.cand_off = co;
         lv.cand_cap = align_up(want + (want > 1024 ? want : 1024), 8);
         co += lv.cand_cap;
@@ -218,7 +218,7 @@ static void free_config(vo_ctx* c)
 {
     void* ptrs[] = {c->tab_mem, c->pyr, c->blur, c->score, c->ff.cand_pos, c->ff.cand_resp, c->ff.cand_count,
                     c->ff.kp_pos, c->ff.kp_level, c->ff.kp_resp, c->ff.kp_angle, c->ff.kp_xy, c->ff.kp_size,
-                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->sel_thr, c->sel_chunk_count, c->har_kept, c->har_thr, c->desc_x};
+                    c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->ff.tile_list, c->ff.tile_count, c->sel_thr, c->sel_chunk_count, c->har_kept, c->har_thr, c->desc_x};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->tab_mem = nullptr; c->pyr = c->blur = c->score = nullptr; c->desc_x = nullptr; c->sel_thr = c->sel_chunk_count = c->har_kept = nullptr; c->har_thr = nullptr;
     memset(&c->ff, 0, sizeof(c->ff));
@@ -340,6 +340,8 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     HIPCHK(dmalloc(&ctx->desc_x, F * (size_t)desc_x_rows(g.kp_cap) * 256));
     HIPCHK(dmalloc(&ff.kp_count, F)); HIPCHK(dmalloc(&ff.flags, F));
     HIPCHK(dmalloc(&ff.hist, F * VO_MAX_LEVELS * 256));
+    HIPCHK(dmalloc(&ff.tile_list, F * (size_t)g.ftiles_total * FAST_LISTCAP));
+    HIPCHK(dmalloc(&ff.tile_count, F * (size_t)g.ftiles_total));
     HIPCHK(dmalloc(&ctx->sel_thr, F * VO_MAX_LEVELS));
     HIPCHK(dmalloc(&ctx->har_kept, F * VO_MAX_LEVELS));
     HIPCHK(dmalloc(&ctx->har_thr, F * VO_MAX_LEVELS));
@@ -439,6 +441,7 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     ff.desc += (size_t)first_slot * g.kp_cap * 32;
     ff.kp_count += first_slot; ff.flags += first_slot;
     ff.hist += (size_t)first_slot * VO_MAX_LEVELS * 256;
+    ff.tile_list += (size_t)first_slot * g.ftiles_total * FAST_LISTCAP; ff.tile_count += (size_t)first_slot * g.ftiles_total;
     {
         StageTimer t(ctx, ST_RESIZE);
         for (int l = 1; l < g.nlevels; l++) launch_resize(s, pyr, g, l, ctx->tabs[l], F);
@@ -449,9 +452,9 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
         HIPCHK(hipMemsetAsync(ff.hist, 0, (size_t)F * VO_MAX_LEVELS * 256 * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ff.flags, 0, (size_t)F * sizeof(int), s));
     }
-    { StageTimer t(ctx, ST_FAST); launch_fast(s, pyr, score, ff.hist, g, F); }
+    { StageTimer t(ctx, ST_FAST); launch_fast(s, pyr, score, ff.hist, g, F, upto < 2 ? nullptr : ff.tile_list, ff.tile_count); }
     if (upto < 2) return VO_OK;
-    { StageTimer t(ctx, ST_SELECT_FAST); launch_select_fast(s, score, g, ff, F, ctx->sel_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->sel_chunk_count + (size_t)first_slot * g.sel_chunks_total); }
+    { StageTimer t(ctx, ST_SELECT_FAST); launch_select_fast(s, g, ff, F, ctx->sel_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->sel_chunk_count + (size_t)first_slot * g.sel_chunks_total, ff.tile_list, ff.tile_count); }
     if (g.score_type == 0) { StageTimer t(ctx, ST_HARRIS); launch_harris(s, pyr, g, ff, F); }
     { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F, ctx->har_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->har_kept + (size_t)first_slot * VO_MAX_LEVELS); }
     { StageTimer t(ctx, ST_ANGLE); launch_angle(s, pyr, g, ff, F); }
@@ -1261,8 +1264,8 @@ extern "C" double vo_stage_bytes(vo_ctx* ctx, int stage, int F)
     double b = 0;
     switch (stage) {
     case ST_RESIZE: b = (total - px[g.nlevels - 1]) + (total - px[0]); break;   // reads levels 0..L-2, writes 1..L-1
-    case ST_FAST: b = total + total; break;                                       // reads the pyramid, writes the score map
-    case ST_SELECT_FAST: b = total; break;
+    case ST_FAST: b = total; break;                                               // FAST reads P (winner lists are a few KB)
+    case ST_SELECT_FAST: b = 2 * 2 * N * 12; break;                               // ~2N kept winners: list entry read twice, 8 B written
     case ST_HARRIS: b = 2 * N * 81 + 2 * N * 4; break;
     case ST_ANGLE: b = N * 749; break;
     case ST_BLUR: b = total + total; break;

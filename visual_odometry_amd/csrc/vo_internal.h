@@ -19,7 +19,7 @@ struct LevelGeom {
     int ftile_base, ftiles_x;    // FAST tiles (prefix over levels)
     int btile_base, btiles_x;    // blur tiles
     int cand_off, cand_cap;      // candidate slots of this level inside a frame's candidate arrays
-    int sel_chunk_base;          // first selection chunk (SEL_ROWS rows inside the border) of this level
+    int sel_chunk_base;          // first selection chunk (= row of FAST tiles) of this level
 };
 
 struct PyrGeom {
@@ -55,7 +55,7 @@ struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (dev
 #ifndef BLUR_TH
 #define BLUR_TH 48
 #endif
-#define SEL_ROWS 8
+#define FAST_LISTCAP ((FAST_TW / 2) * (FAST_TH / 2))
 
 // per-frame feature arrays (device), F = number of slots
 struct FrameFeat {
@@ -72,6 +72,8 @@ struct FrameFeat {
     int*      kp_count;   // [F]
     int*      flags;      // [F]  bit0: capacity overflow
     uint32_t* hist;       // [F][VO_MAX_LEVELS][256] FAST score histogram
+    uint32_t* tile_list;  // [F][ftiles_total][FAST_LISTCAP] NMS winners inside the border, per FAST tile
+    int*      tile_count; // [F][ftiles_total]
 };
 
 // per-pair arrays (device), P = number of pairs
@@ -112,8 +114,10 @@ struct RansacParams {
 void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
                  uint8_t* pyr, const PyrGeom& g, int F);
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F);
-void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F);
-void launch_select_fast(hipStream_t s, const uint8_t* score, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count);
+void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F,
+                 uint32_t* tile_list, int* tile_count);      // tile_list == nullptr: dense score map instead of winner lists
+void launch_select_fast(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count,
+                        const uint32_t* tile_list, const int* tile_count);
 void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
 void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, float* thr, int* kept);
 void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
