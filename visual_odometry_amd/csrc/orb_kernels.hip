@@ -411,11 +411,12 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         const uint32_t r8_e = up & 0x00ff00ffu, r8_o = (up >> 8) & 0x00ff00ffu;
         const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, 0x0c050c03u), r4_o = __builtin_amdgcn_perm(wr, c, 0x0c060c04u);
         const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, 0x0c030c01u), r12_o = __builtin_amdgcn_perm(c, wl, 0x0c040c02u);
-        // sign bit of each 16-bit lane: ring > v + t (bright) / ring < v - t (dark)
-        const uint32_t br_e = (pk_sub16(hi_e, r0_e) | pk_sub16(hi_e, r8_e)) & (pk_sub16(hi_e, r4_e) | pk_sub16(hi_e, r12_e));
-        const uint32_t br_o = (pk_sub16(hi_o, r0_o) | pk_sub16(hi_o, r8_o)) & (pk_sub16(hi_o, r4_o) | pk_sub16(hi_o, r12_o));
-        const uint32_t dk_e = (pk_sub16(r0_e, lo_e) | pk_sub16(r8_e, lo_e)) & (pk_sub16(r4_e, lo_e) | pk_sub16(r12_e, lo_e));
-        const uint32_t dk_o = (pk_sub16(r0_o, lo_o) | pk_sub16(r8_o, lo_o)) & (pk_sub16(r4_o, lo_o) | pk_sub16(r12_o, lo_o));
+        // two adjacent compass pixels both brighter than v + t  <=>  min(max(r0, r8), max(r4, r12)) > v + t, both darker
+        // <=> max(min(r0, r8), min(r4, r12)) < v - t; the sign bit of the packed difference is the per-pixel answer
+        const uint32_t br_e = pk_sub16(hi_e, pk_min16(pk_max16(r0_e, r8_e), pk_max16(r4_e, r12_e)));
+        const uint32_t br_o = pk_sub16(hi_o, pk_min16(pk_max16(r0_o, r8_o), pk_max16(r4_o, r12_o)));
+        const uint32_t dk_e = pk_sub16(pk_max16(pk_min16(r0_e, r8_e), pk_min16(r4_e, r12_e)), lo_e);
+        const uint32_t dk_o = pk_sub16(pk_max16(pk_min16(r0_o, r8_o), pk_min16(r4_o, r12_o)), lo_o);
         // candidate bits: pixel 0 / 2 = bits 15 / 31 of the even word, pixel 1 / 3 of the odd word
         const uint32_t tt = (((br_e | dk_e) & 0x80008000u) >> 15) | (((br_o | dk_o) & 0x80008000u) >> 14);
         uint32_t bits = (tt | (tt >> 14)) & colmask;
