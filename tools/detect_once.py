@@ -1,3 +1,4 @@
+"""Upload + three detections of N frames: a small target for rocprofv3 --pmc runs on single kernels."""
 import numpy as np, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visual_odometry_amd import synth

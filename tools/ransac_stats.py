@@ -1,3 +1,4 @@
+"""RANSAC iteration counts / matches / inliers of 16 consecutive pairs of the bench sequence."""
 import numpy as np, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visual_odometry_amd import synth

@@ -1,3 +1,4 @@
+"""Per-stage HIP-event times of the detection chain alone (257 frames 1280x720, 2000 features), three repeats."""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visual_odometry_amd import synth

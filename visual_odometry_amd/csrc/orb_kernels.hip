@@ -558,29 +558,10 @@ void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hi
 // ------------------------------------------------------------------ retainBest by FAST score
 // KeyPointsFilter::runByImageBorder + retainBest(2*quota): the kept SET is {score >= n-th largest score}.
 // (1) k_sel_threshold: the n-th largest score per (frame, level) from the 256-bin histogram;
-// (2) k_sel_count: the score map inside the border is cut into chunks of SEL_ROWS rows, one wavefront per
-//     chunk streams it with 16-byte loads and counts the kept pixels (packed byte compare + popcount);
-// (3) k_sel_emit: each wavefront sums the counts of the chunks before it (its output offset), streams its
-//     chunk again and writes the kept (x, y, score) in raster order (wave prefix sums) — canonical (y, x)
-//     order with no workgroup barrier anywhere.
-
-__device__ __forceinline__ uint32_t bytes_ge(uint32_t x, uint32_t t7, uint32_t tnot, uint32_t t)
-{
-    // per byte: 0x80 where x >= t (t7 = t & 0x7f7f7f7f, tnot = ~t), no carries between bytes
-    const uint32_t d = (x | 0x80808080u) - t7;
-    return ((x & tnot) | (~(x ^ t) & d)) & 0x80808080u;
-}
-
-// 16-bit mask of the bytes of v that are >= T, bit i = byte i
-__device__ __forceinline__ uint32_t mask16_ge(uint4 v, uint32_t t)
-{
-    const uint32_t t7 = t & 0x7f7f7f7fu, tn = ~t;
-    const uint32_t a = (bytes_ge(v.x, t7, tn, t) >> 7) * 0x01020408u >> 24;
-    const uint32_t b = (bytes_ge(v.y, t7, tn, t) >> 7) * 0x01020408u >> 24;
-    const uint32_t c = (bytes_ge(v.z, t7, tn, t) >> 7) * 0x01020408u >> 24;
-    const uint32_t d = (bytes_ge(v.w, t7, tn, t) >> 7) * 0x01020408u >> 24;
-    return (a & 15u) | ((b & 15u) << 4) | ((c & 15u) << 8) | ((d & 15u) << 12);
-}
+// (2) k_sel_rows<count>: one wavefront per row of FAST tiles counts the listed winners that reach the threshold;
+// (3) k_sel_rows<emit>: each wavefront sums the counts of the tile rows above it (its output offset), gathers its
+//     kept winners into LDS, ranks them in (y, x) order and writes (x, y, score) at offset + rank — canonical
+//     raster order with no sort, no workgroup barrier and no pass over a score map.
 
 __global__ __launch_bounds__(64) void k_sel_threshold(PyrGeom g, FrameFeat ff, int* thr)
 {
