@@ -163,21 +163,20 @@ __global__ __launch_bounds__(256) void k_resize_tiled(uint8_t* pyr, int frame_by
     const uint8_t* sp = pyr + (size_t)f * frame_bytes + src.off;
     // all of a lane's 16-byte loads are issued before the first one is consumed (the kernel is bound by the latency
     // of this staging step, not by its arithmetic)
-    constexpr int RS_NLD = (RS_LH * (RS_LW / 16) + 255) / 256;
+    constexpr int RS_NCH = RS_LW / 16, RS_RPS = 256 / RS_NCH, RS_NLD = (RS_LH + RS_RPS - 1) / RS_RPS;   // 12 chunks, 21 rows per step
+    const int sc = tid % RS_NCH, sr = tid / RS_NCH;
+    const bool s_ok = tid < RS_RPS * RS_NCH && sc < ncol16 && sx0 + 16 * sc + 16 <= src.stride;
+    const uint8_t* sbase = sp + min(sx0 + 16 * sc, src.stride - 16);
     uint4 sv[RS_NLD];
 #pragma unroll
     for (int k = 0; k < RS_NLD; k++) {
-        const int i = tid + 256 * k;
-        const int ry = i / (RS_LW / 16), c = i % (RS_LW / 16);
-        const int gy = sy0 + ry, gx = sx0 + 16 * c;
-        sv[k] = make_uint4(0, 0, 0, 0);
-        if (i < nrows * (RS_LW / 16) && c < ncol16 && gy < src.h && gx + 16 <= src.stride) sv[k] = *(const uint4*)(sp + (size_t)gy * src.stride + gx);
+        const int gy = sy0 + min(sr + RS_RPS * k, nrows - 1);          // rows the tile does not need re-read a needed one
+        const uint4 v = *(const uint4*)(sbase + (size_t)min(gy, src.h - 1) * src.stride);
+        sv[k] = s_ok && gy < src.h ? v : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int k = 0; k < RS_NLD; k++) {
-        const int i = tid + 256 * k;
-        if (i < nrows * (RS_LW / 16)) *(uint4*)(s_src + (i / (RS_LW / 16)) * RS_LW + 16 * (i % (RS_LW / 16))) = sv[k];
-    }
+    for (int k = 0; k < RS_NLD; k++)
+        if (tid < RS_RPS * RS_NCH && sr + RS_RPS * k < nrows) *(uint4*)(s_src + (sr + RS_RPS * k) * RS_LW + 16 * sc) = sv[k];
     const int dxg = tid & 31, rl = tid >> 5, dx = x0 + 4 * dxg;
     int o[4], c1[4];
 #pragma unroll
@@ -354,25 +353,36 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     const int t = g.fast_thr;
 
-    // A. stage pixels: every 16-byte load of the lane is in flight before the first is consumed (addresses are
-    //    clamped into the level and out-of-image chunks zeroed afterwards, so the loads carry no control flow)
+    // A. stage pixels: lane = (row lane / 9, 16-byte chunk lane % 9) once, then rows advance by 7 per step, so a step
+    //    costs an address add; every load of the lane is in flight before the first is consumed.  Tiles whose halo
+    //    leaves the image clamp the address and zero the chunk afterwards (no control flow around the loads).
     {
-        constexpr int NLD = (FT_PXH * (FT_PXW / 16) + 63) / 64;
+        constexpr int NCH = FT_PXW / 16, RPS = 64 / NCH, NLD = (FT_PXH + RPS - 1) / RPS;     // 9 chunks, 7 rows per step
+        const int c9 = lane % NCH, r9 = lane / NCH;
+        const bool lane_ok = lane < RPS * NCH;
+        const int gx = x0 - 16 + 16 * c9;
+        const bool halo_inside = x0 >= 16 && x0 + FAST_TW + 16 <= lv.stride && y0 >= 4 && y0 + FAST_TH + 4 <= lv.h;
         uint4 pv[NLD];
+        if (halo_inside) {
+            const uint8_t* src = img + (size_t)(y0 - 4 + r9) * lv.stride + gx;
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int i = min(lane + 64 * k, FT_PXH * (FT_PXW / 16) - 1);
-            const int ry = i / (FT_PXW / 16), rx = (i % (FT_PXW / 16)) * 16;
-            const int gy = y0 - 4 + ry, gx = x0 - 16 + rx;
-            const bool in = gy >= 0 && gy < lv.h && gx >= 0 && gx + 16 <= lv.stride;
-            const uint4 v = *(const uint4*)(img + (size_t)min(max(gy, 0), lv.h - 1) * lv.stride + min(max(gx, 0), lv.stride - 16));
-            pv[k] = in ? v : make_uint4(0, 0, 0, 0);
+            for (int k = 0; k < NLD; k++) {
+                const bool in = lane_ok && r9 + RPS * k < FT_PXH;
+                pv[k] = *(const uint4*)(src + (size_t)(in ? RPS * k : 0) * lv.stride);
+            }
+        } else {
+            const bool inx = gx >= 0 && gx + 16 <= lv.stride;
+            const uint8_t* src = img + min(max(gx, 0), lv.stride - 16);
+#pragma unroll
+            for (int k = 0; k < NLD; k++) {
+                const int gy = y0 - 4 + r9 + RPS * k;
+                const uint4 v = *(const uint4*)(src + (size_t)min(max(gy, 0), lv.h - 1) * lv.stride);
+                pv[k] = inx && gy >= 0 && gy < lv.h ? v : make_uint4(0, 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int i = lane + 64 * k;
-            if (i < FT_PXH * (FT_PXW / 16)) *(uint4*)(s_px + (i / (FT_PXW / 16)) * FT_PXW + (i % (FT_PXW / 16)) * 16) = pv[k];
-        }
+        for (int k = 0; k < NLD; k++)
+            if (lane_ok && r9 + RPS * k < FT_PXH) *(uint4*)(s_px + (r9 + RPS * k) * FT_PXW + 16 * c9) = pv[k];
     }
     __syncthreads();
 
@@ -969,22 +979,26 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
     const int x0 = (tile % lv.btiles_x) * BLUR_TW, y0 = (tile / lv.btiles_x) * BLUR_TH;
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     if (lv.w >= 16 && lv.h >= 4) {
-        {   // all 16-byte loads of the lane in flight before the first is consumed
-            constexpr int NLD = (BL_INH * (BL_INW / 16) + 255) / 256;
+        {   // lane = (row tid / 10, 16-byte chunk tid % 10) once, rows advance by 25 per step; all loads of the lane
+            // are in flight before the first is consumed
+            constexpr int NCH = BL_INW / 16, RPS = 256 / NCH, NLD = (BL_INH + RPS - 1) / RPS;
+            const int cc = tid % NCH, rr = tid / NCH;
+            const bool lane_ok = tid < RPS * NCH;
+            const int gx = x0 - 16 + 16 * cc;
+            const bool inx = gx >= 0 && gx + 16 <= lv.stride;
+            const uint8_t* src = img + min(max(gx, 0), lv.stride - 16);
+            const bool rows_inside = y0 >= 3 && y0 + BLUR_TH + 3 <= lv.h;
             uint4 bv[NLD];
 #pragma unroll
             for (int k = 0; k < NLD; k++) {
-                const int i = min(tid + 256 * k, BL_INH * (BL_INW / 16) - 1);
-                const int ry = i / (BL_INW / 16), rx = (i % (BL_INW / 16)) * 16;
-                const int gy = reflect101(y0 - 3 + ry, lv.h), gx = x0 - 16 + rx;
-                const uint4 v = *(const uint4*)(img + (size_t)gy * lv.stride + min(max(gx, 0), lv.stride - 16));
-                bv[k] = gx >= 0 && gx + 16 <= lv.stride ? v : make_uint4(0, 0, 0, 0);
+                const int ry = min(rr + RPS * k, BL_INH - 1);
+                const int gy = rows_inside ? y0 - 3 + ry : reflect101(y0 - 3 + ry, lv.h);
+                const uint4 v = *(const uint4*)(src + (size_t)gy * lv.stride);
+                bv[k] = inx ? v : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int k = 0; k < NLD; k++) {
-                const int i = tid + 256 * k;
-                if (i < BL_INH * (BL_INW / 16)) *(uint4*)(s_in + (i / (BL_INW / 16)) * BL_INW + (i % (BL_INW / 16)) * 16) = bv[k];
-            }
+            for (int k = 0; k < NLD; k++)
+                if (lane_ok && rr + RPS * k < BL_INH) *(uint4*)(s_in + (rr + RPS * k) * BL_INW + 16 * cc) = bv[k];
         }
         const bool left = x0 == 0, right = x0 + BLUR_TW + 3 > lv.w;
         if (left || right) {
