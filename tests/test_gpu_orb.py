@@ -126,3 +126,62 @@ def test_fast_corner_dense_tiles_take_the_fallback_path(oracle, ctx):
     ref = oracle.orb_detect_and_compute(img, p)
     g = _det(500, 3).detect_arrays(img)
     assert np.array_equal(g["xy"], ref["xy"]) and np.array_equal(g["desc"], ref["desc"])
+
+
+@pytest.mark.parametrize("h,w,nfeatures,nlevels,thr", [
+    (97, 113, 150, 3, 20), (120, 224, 200, 4, 20), (121, 225, 200, 5, 10), (144, 336, 400, 6, 20), (145, 337, 400, 8, 35),
+    (96, 112, 100, 2, 20), (73, 449, 300, 3, 20), (449, 73, 300, 3, 20), (1080, 1920, 4000, 4, 20), (376, 1241, 2000, 8, 20),
+    (240, 320, 50, 8, 5), (241, 383, 3000, 8, 20)])
+def test_shapes_around_the_kernel_tiles(oracle, ctx, h, w, nfeatures, nlevels, thr):
+    """Image sizes on and next to the tile edges of the FAST (112x24), resize (128x32) and blur (128x48) kernels,
+    few / many features, several pyramid depths and FAST thresholds: the whole detector, bit for bit."""
+    img = random_image(h * 7 + w, h, w)
+    p = oracle.orb_params(nfeatures=nfeatures, nlevels=nlevels, fast_threshold=thr)
+    ref = oracle.orb_detect_and_compute(img, p)
+    got = _det(nfeatures, nlevels, fastThreshold=thr).detect_arrays(img)
+    assert got["truncated"] == ref["overflow"]
+    if not ref["overflow"]:
+        for k in ("xy", "octave", "response", "angle", "size", "desc"):
+            assert np.array_equal(got[k], ref[k]), k
+
+
+def test_api_rejects_bad_arguments(ctx):
+    """Every entry point reports VO_ERR_INVALID (ValueError in Python) instead of touching memory."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    lib, hnd = ctx.lib, ctx.handle
+    img = np.zeros((64, 64), np.uint8)
+    n = np.zeros(1, np.int32)
+    assert lib.vo_orb_detect_and_compute(hnd, img.ctypes.data, 64, 64, 2, 64, None, None, None, None, None, None, None, 10,
+                                         n.ctypes.data) == _lib.VO_ERR_INVALID                     # 2 channels
+    assert lib.vo_match_hamming(hnd, None, 5, img.ctypes.data, 5, 1, None, None, None, n.ctypes.data) == _lib.VO_ERR_INVALID
+    assert lib.vo_set_matcher_kernel(hnd, 3) == _lib.VO_ERR_INVALID
+    assert b"matcher kernel" in lib.vo_last_error(hnd)
+    fe = FrontEnd(64, 96, max_frames=2, max_pairs=1, nfeatures=50)
+    with pytest.raises(_lib.VoError, match="slot range"):
+        fe.upload(np.zeros((3, 64, 96), np.uint8))                                                  # more frames than slots
+    with pytest.raises(ValueError):
+        fe.run_pairs([[0, 1], [1, 0]], np.eye(3))                                                   # more pairs than configured
+    with pytest.raises(Exception):
+        fe.run_pairs([[0, 5]], np.eye(3))                                                           # slot out of range
+    with pytest.raises(Exception):
+        fe.detect(1, 2)
+
+
+def test_contexts_can_be_created_reconfigured_and_destroyed(oracle):
+    """Create / configure / use / destroy in a loop with different shapes: no stale state between configurations."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    for k, (h, w, nf) in enumerate([(120, 160, 100), (243, 331, 300), (96, 112, 80), (120, 160, 100)]):
+        c = _lib.Context(0)
+        fe = FrontEnd(h, w, max_frames=2, max_pairs=1, nfeatures=nf, ctx=c)
+        img = random_image(50 + k, h, w)
+        fe.upload(np.stack([img, img])); fe.detect(0, 2)
+        ref = oracle.orb_detect_and_compute(img, oracle.orb_params(nfeatures=nf))
+        assert np.array_equal(fe.features(0)["desc"], ref["desc"]) and np.array_equal(fe.features(1)["desc"], ref["desc"])
+        fe2 = FrontEnd(h + 8, w + 16, max_frames=1, max_pairs=1, nfeatures=nf, ctx=c)             # reconfigure the same ctx
+        img2 = random_image(90 + k, h + 8, w + 16)
+        fe2.upload(img2[None]); fe2.detect(0, 1)
+        ref2 = oracle.orb_detect_and_compute(img2, oracle.orb_params(nfeatures=nf))
+        assert np.array_equal(fe2.features(0)["desc"], ref2["desc"])
+        c.close()

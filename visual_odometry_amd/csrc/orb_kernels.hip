@@ -413,12 +413,12 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         const uint32_t c = rowp[0], wl = rowp[-1], wr = rowp[1];
         const uint32_t up = rowp[-3 * (FT_PXW / 4)], dn = rowp[3 * (FT_PXW / 4)];
         // even pixels (0, 2) / odd pixels (1, 3) widened to 16-bit lanes
-        const uint32_t c_e = c & 0x00ff00ffu, c_o = (c >> 8) & 0x00ff00ffu;
+        const uint32_t c_e = c & 0x00ff00ffu, c_o = __builtin_amdgcn_perm(0u, c, 0x0c030c01u);      // bytes 1, 3 -> 16-bit lanes
         const uint32_t hi_e = pk_add16(c_e, T2), hi_o = pk_add16(c_o, T2);
         const uint32_t lo_e = pk_sub16(c_e, T2), lo_o = pk_sub16(c_o, T2);
         // ring 0 (0,+3) and ring 8 (0,-3): aligned dwords; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
-        const uint32_t r0_e = dn & 0x00ff00ffu, r0_o = (dn >> 8) & 0x00ff00ffu;
-        const uint32_t r8_e = up & 0x00ff00ffu, r8_o = (up >> 8) & 0x00ff00ffu;
+        const uint32_t r0_e = dn & 0x00ff00ffu, r0_o = __builtin_amdgcn_perm(0u, dn, 0x0c030c01u);
+        const uint32_t r8_e = up & 0x00ff00ffu, r8_o = __builtin_amdgcn_perm(0u, up, 0x0c030c01u);
         const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, 0x0c050c03u), r4_o = __builtin_amdgcn_perm(wr, c, 0x0c060c04u);
         const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, 0x0c030c01u), r12_o = __builtin_amdgcn_perm(c, wl, 0x0c040c02u);
         // two adjacent compass pixels both brighter than v + t  <=>  min(max(r0, r8), max(r4, r12)) > v + t, both darker
