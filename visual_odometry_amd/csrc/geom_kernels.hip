@@ -864,19 +864,23 @@ __device__ __forceinline__ bool cheirality(const double* P0, const double* P, co
     return m && (z > 0) && (z < dist);
 }
 
-__global__ __launch_bounds__(256) void k_pose(PairBuf pb, int kp_cap, RansacParams rp)
+// 1024 threads: the inlier compaction uses the first 256; then the four (R, t) candidates are tested in parallel, four
+// wavefronts each, so every SIMD holds four waves of independent f64 Jacobi sweeps instead of one (the kernel is
+// bound by the dependent-issue latency of those sweeps).
+__global__ __launch_bounds__(1024) void k_pose(PairBuf pb, int kp_cap, RansacParams rp)
 {
     __shared__ int s_w[4];
     __shared__ int s_good[4];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, cand = threadIdx.x >> 8;
+    const bool first = cand == 0;                       // the 256 threads that compact and write
     vo_pair_result* res = pb.res + p;
     if (res->status != VO_OK) {
-        if (tid == 0) res->n_good = 0;
+        if (first && tid == 0) res->n_good = 0;
         return;
     }
     if (res->reserved != 1) {           // M == 5: stacked solutions; decomposeEssentialMat needs a single 3x3 matrix
         __syncthreads();
-        if (tid == 0) { res->status = VO_ERR_AMBIGUOUS; res->n_good = 0; }
+        if (first && tid == 0) { res->status = VO_ERR_AMBIGUOUS; res->n_good = 0; }
         return;
     }
     const int M = pb.m_count[p];
@@ -884,14 +888,14 @@ __global__ __launch_bounds__(256) void k_pose(PairBuf pb, int kp_cap, RansacPara
     const uint8_t* mask = pb.mask + (size_t)p * kp_cap;
     double* in1 = pb.in1 + base2; double* in2 = pb.in2 + base2;
     double* ip1 = pb.ipx1 + base2; double* ip2 = pb.ipx2 + base2;
-    if (tid < 4) s_good[tid] = 0;
+    if (first && tid < 4) s_good[tid] = 0;
     int ninl = 0;
     for (int b = 0; b < M; b += 256) {
         const int i = b + tid;
-        const bool f = i < M && mask[i] != 0;
+        const bool f = first && i < M && mask[i] != 0;
         const unsigned long long bal = __ballot(f);
         __syncthreads();
-        if (lane == 0) s_w[wave] = __popcll(bal);
+        if (first && lane == 0) s_w[wave] = __popcll(bal);
         __syncthreads();
         int off = 0, tot = 0;
 #pragma unroll
@@ -911,8 +915,8 @@ __global__ __launch_bounds__(256) void k_pose(PairBuf pb, int kp_cap, RansacPara
     for (int k = 0; k < 9; k++) E[k] = res->E[k];
     decompose_essential(E, R1, R2, tt);
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-#pragma unroll 1
-    for (int c = 0; c < 4; c++) {
+    {
+        const int c = cand;                              // wave-uniform: four waves per candidate
         const double* Rc = (c & 1) ? R2 : R1;
         const double sgn = c >= 2 ? -1.0 : 1.0;
         double P[12];
@@ -948,9 +952,9 @@ __global__ __launch_bounds__(256) void k_pose(PairBuf pb, int kp_cap, RansacPara
             P[r * 4 + 3] = sgn * tt[r];
         }
         uint8_t* pm = pb.pose_mask + (size_t)p * kp_cap;
-        for (int i = tid; i < ninl; i += 256) pm[i] = cheirality(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh) ? 255 : 0;
+        for (int i = threadIdx.x; i < ninl; i += 1024) pm[i] = cheirality(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh) ? 255 : 0;
     }
-    if (tid == 0) {
+    if (first && tid == 0) {
         const double* Rb = (best & 1) ? R2 : R1;
 #pragma unroll
         for (int k = 0; k < 9; k++) res->R[k] = Rb[k];
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(256) void k_pose(PairBuf pb, int kp_cap, RansacPara
 
 void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
 {
-    hipLaunchKernelGGL(k_pose, dim3(P), dim3(256), 0, s, pb, kp_cap, rp);
+    hipLaunchKernelGGL(k_pose, dim3(P), dim3(1024), 0, s, pb, kp_cap, rp);
 }
 
 // ------------------------------------------------------------------ single five-point sample (stage test)
