@@ -29,6 +29,7 @@ extern "C" {
 #define VO_ERR_TOO_FEW       -3   /* fewer than 5 correspondences (cv2.findEssentialMat returns None) */
 #define VO_ERR_NO_MODEL      -4   /* RANSAC found no model with > 4 inliers */
 #define VO_ERR_NOT_CONFIGURED -5
+#define VO_ERR_UNSUPPORTED    -7   /* a branch of the cv2 call that is not built (solvePnPRansac with exactly 4 points: P3P) */
 #define VO_ERR_AMBIGUOUS      -6   /* exactly 5 correspondences: findEssentialMat stacks up to 10 solutions, which
                                      cv2.recoverPose (and the reference) cannot consume */
 
@@ -179,6 +180,21 @@ int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* 
 int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam, const double* points, int npt,
                            const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, int nobs,
                            const double* K, double threshold, double* sqerr, uint8_t* keep);
+
+/* cv2.solvePnPRansac(objectPoints, imagePoints, K, zeros(4)) with its default arguments (iterationsCount 100,
+ * reprojectionError 8.0, confidence 0.99, SOLVEPNP_ITERATIVE) — src/visual_slam.py:231-235.
+ * obj n x 3, img n x 2 (float64, row-major); rvec / tvec as cv2 returns them; mask[n] = 1 for inliers (cv2 returns
+ * their indices).  VO_ERR_TOO_FEW: n < 4 (cv2 asserts); VO_ERR_UNSUPPORTED: n == 4; VO_ERR_NO_MODEL = retval False. */
+int vo_solve_pnp_ransac(vo_ctx* ctx, const double* obj, const double* img, int n, const double K[9], int iterations,
+                        double reproj_err, double confidence, uint64_t seed, double rvec[3], double tvec[3],
+                        uint8_t* mask, int32_t* n_inl);
+/* B independent problems in one launch (one workgroup each): problem b owns points offsets[b] .. offsets[b+1];
+ * rvec / tvec are B x 3, mask has offsets[B] bytes, n_inl and status B ints (status[b] as the single call returns). */
+int vo_solve_pnp_ransac_batch(vo_ctx* ctx, const double* obj, const double* img, const int32_t* offsets, int B,
+                              const double K[9], int iterations, double reproj_err, double confidence, uint64_t seed,
+                              double* rvec, double* tvec, uint8_t* mask, int32_t* n_inl, int32_t* status);
+/* cv2.Rodrigues (src/visual_slam.py:243): in_is_matrix = 0: 3-vector -> 3x3 (row-major); 1: 3x3 -> 3-vector. */
+int vo_rodrigues(vo_ctx* ctx, const double* in, int in_is_matrix, double* out);
 
 /* cv2.resize(img, dim) with the default INTER_LINEAR, 8-bit, 1 / 3 / 4 channels — src/visual_slam.py:346-352
  * (cv2.imread's JPEG decode stays on the host).  Host image in, host image out. */

@@ -258,3 +258,27 @@ def resize_linear(src, dw, dh):
     rc = f(src.ctypes.data, sw, sh, cn, src.strides[0], dst.ctypes.data, dw, dh, dst.strides[0])
     assert rc == 0
     return dst
+
+
+def solve_pnp_ransac(obj, img, K, iterations=100, reproj_err=8.0, confidence=0.99, seed=0xFFFFFFFFFFFFFFFF):
+    """cv2.solvePnPRansac(obj, img, K, zeros(4)) -> (rc, rvec [3], tvec [3], inlier mask, n_inliers)  (voo_pnp.c)."""
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3); img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64)
+    n = len(obj)
+    rvec = np.zeros(3); tvec = np.zeros(3); mask = np.zeros(max(n, 1), np.uint8); ninl = C.c_int32(0)
+    f = lib().voo_solve_pnp_ransac
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_uint64,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = f(obj.ctypes.data, img.ctypes.data, n, K.ctypes.data, iterations, reproj_err, confidence, seed,
+           rvec.ctypes.data, tvec.ctypes.data, mask.ctypes.data, C.addressof(ninl))
+    return rc, rvec, tvec, mask[:n].copy(), ninl.value
+
+
+def rodrigues(x):
+    """cv2.Rodrigues: 3-vector -> 3x3 matrix, 3x3 matrix -> 3-vector."""
+    x = np.ascontiguousarray(x, np.float64)
+    f = lib().voo_rodrigues
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    if x.size == 9:
+        out = np.zeros(3); f(x.ctypes.data, 1, out.ctypes.data); return out
+    out = np.zeros((3, 3)); f(x.reshape(3).ctypes.data, 0, out.ctypes.data); return out

@@ -91,6 +91,12 @@ int voo_resize_linear_tab(int ssize, int dsize, int32_t* ofs, int16_t* c0, int16
 int voo_resize_linear(const uint8_t* src, int sw, int sh, int cn, int sstride,
                       uint8_t* dst, int dw, int dh, int dstride);
 
+/* --- "next" row: localisation, cv2.solvePnPRansac + cv2.Rodrigues, visual_slam.py:231-243 ---- */
+int voo_solve_pnp_ransac(const double* obj /*n x 3*/, const double* img /*n x 2*/, int n, const double* K,
+                         int iterations, double reproj_err, double confidence, uint64_t seed,
+                         double* rvec, double* tvec, uint8_t* mask, int32_t* n_inl);
+int voo_rodrigues(const double* in, int in_is_matrix, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,624 @@
+/* voo_pnp.c — CPU ORACLE (test infrastructure only, see voo.h) for the localisation step that follows the pair
+ * path in steady state: cv2.solvePnPRansac(map_coords, image_coords, K, zeros(4)) + cv2.Rodrigues
+ * (/root/reference/src/visual_slam.py:231-243).
+ *
+ * Restates OpenCV 4.7 calib3d (solvepnp.cpp solvePnPRansac, epnp.cpp, ptsetreg.cpp) with its default arguments
+ * (iterationsCount 100, reprojectionError 8, confidence 0.99, SOLVEPNP_ITERATIVE):
+ *   - the points are converted to float32 for the RANSAC stage, as solvePnPRansac does;
+ *   - RANSACPointSetRegistrator::run with 5-point samples (same MWC generator, seed 2^64-1, same duplicate
+ *     rejection, same adaptive iteration count as the essential-matrix RANSAC of voo_geom.c);
+ *   - minimal solver = solvePnP(SOLVEPNP_EPNP): undistortPoints (float32 normalised coordinates), epnp.cpp's
+ *     control points / barycentric coordinates / M^T M null space / three beta approximations / 5 Gauss-Newton
+ *     steps / absolute orientation, best of the three by reprojection error;
+ *   - error = squared float32 distance between the image point and projectPoints' float32 output, inlier iff
+ *     err <= 64;
+ *   - final pose = reprojection-error minimum over the inliers (solvePnP SOLVEPNP_ITERATIVE), then Rodrigues.
+ * PARITY UNPINNED, and only to tolerance even in principle: opencv-python takes the 12x12 SVD of epnp.cpp from LAPACK
+ * (any basis of its 2-dimensional null space is a valid answer for 5 points), so hypotheses agree with cv2's to
+ * rounding-sensitive noise, not bit for bit.  [deviation] the final Levenberg-Marquardt runs from the best RANSAC
+ * hypothesis with an so(3) increment and to tight convergence; cv2 starts from a DLT (or homography) initial
+ * guess, uses the rvec parametrisation and stops after 20 iterations or a FLT_EPSILON step: same cost, same
+ * minimum, agreement to the optimiser's tolerance. */
+#include "voo.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline double pn_hypot(double a, double b)
+{
+    a = fabs(a); b = fabs(b);
+    if (a < b) { double t = a; a = b; b = t; }
+    if (a == 0) return 0;
+    double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
+/* one-sided Jacobi SVD (lapack.cpp JacobiSVDImpl_): At = n rows of length m (row i = column i of A, m >= n).
+ * On return row i of At = sigma_i u_i, W descending, Vt rows = right singular vectors. */
+static void pn_jacobi_svd(double* At, int m, int n, double* W, double* Vt)
+{
+    const double eps = DBL_EPSILON * 10;
+    int max_iter = m > 30 ? m : 30;
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) sd += At[i * m + k] * At[i * m + k];
+        W[i] = sd;
+        for (int k = 0; k < n; k++) Vt[i * n + k] = 0;
+        Vt[i * n + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        int changed = 0;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                double *Ai = At + i * m, *Aj = At + j * m;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = pn_hypot(p, beta), c, s;
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    double t0 = c * Ai[k] + s * Aj[k];
+                    double t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = 1;
+                double *Vi = Vt + i * n, *Vj = Vt + j * n;
+                for (int k = 0; k < n; k++) {
+                    double t0 = c * Vi[k] + s * Vj[k];
+                    double t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) sd += At[i * m + k] * At[i * m + k];
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (int k = 0; k < m; k++) { t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
+            for (int k = 0; k < n; k++) { t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t; }
+        }
+    }
+}
+
+/* cvSolve(A, b, x, CV_SVD) for an m x n system, m >= n <= 5, m <= 6: SVD::backSubst with OpenCV's threshold */
+static void pn_svd_solve(const double* A, int m, int n, const double* b, double* x)
+{
+    double At[5 * 6], W[5], Vt[25];
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) At[j * m + i] = A[i * n + j];
+    pn_jacobi_svd(At, m, n, W, Vt);
+    double thr = 0;
+    for (int j = 0; j < n; j++) thr += W[j];
+    thr *= DBL_EPSILON * 2;
+    for (int k = 0; k < n; k++) x[k] = 0;
+    for (int j = 0; j < n; j++) {
+        if (W[j] <= thr) continue;
+        double s = 0;                                     /* u_j . b / w_j, u_j = At row j / w_j */
+        for (int i = 0; i < m; i++) s += At[j * m + i] * b[i];
+        s /= W[j] * W[j];
+        for (int k = 0; k < n; k++) x[k] += s * Vt[j * n + k];
+    }
+}
+
+/* cvInvert(A, Ai, CV_SVD) for 3 x 3 */
+static void pn_inv3_svd(const double* A, double* Ai)
+{
+    double At[9], W[3], Vt[9];
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = A[i * 3 + j];
+    pn_jacobi_svd(At, 3, 3, W, Vt);
+    double thr = (W[0] + W[1] + W[2]) * DBL_EPSILON * 2;
+    for (int k = 0; k < 9; k++) Ai[k] = 0;
+    for (int j = 0; j < 3; j++) {
+        if (W[j] <= thr) continue;
+        const double iw2 = 1. / (W[j] * W[j]);           /* A^-1 = sum v_j u_j^T / w_j, u_j = At row j / w_j */
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ai[r * 3 + c] += Vt[j * 3 + r] * At[j * 3 + c] * iw2;
+    }
+}
+
+/* epnp.cpp qr_solve: Householder least squares for the 6 x 4 Gauss-Newton system (A is destroyed) */
+static void pn_qr_solve_6x4(double* A, double* b, double* X)
+{
+    const int nr = 6, nc = 4;
+    double A1[4], A2[4];
+    for (int k = 0; k < nc; k++) {
+        double eta = 0;
+        for (int i = k; i < nr; i++) { double e = fabs(A[i * nc + k]); if (e > eta) eta = e; }
+        if (eta == 0) { A1[k] = A2[k] = 0; continue; }   /* singular: epnp.cpp prints and returns; the step is then zero */
+        double sum = 0, inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) { A[i * nc + k] *= inv_eta; sum += A[i * nc + k] * A[i * nc + k]; }
+        double sigma = sqrt(sum);
+        if (A[k * nc + k] < 0) sigma = -sigma;
+        A[k * nc + k] += sigma;
+        A1[k] = sigma * A[k * nc + k];
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double s = 0;
+            for (int i = k; i < nr; i++) s += A[i * nc + k] * A[i * nc + j];
+            double tau = s / A1[k];
+            for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
+        }
+    }
+    for (int j = 0; j < nc; j++) {                        /* b <- Q^T b */
+        if (A1[j] == 0) continue;
+        double s = 0;
+        for (int i = j; i < nr; i++) s += A[i * nc + j] * b[i];
+        double tau = s / A1[j];
+        for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
+    }
+    for (int i = nc - 1; i >= 0; i--) {                   /* R x = b */
+        if (A2[i] == 0) { X[i] = 0; continue; }
+        double s = b[i];
+        for (int j = i + 1; j < nc; j++) s -= A[i * nc + j] * X[j];
+        X[i] = s / A2[i];
+    }
+}
+
+typedef struct { double fu, fv, uc, vc; } pn_cam;
+
+static double pn_dist2(const double* a, const double* b)
+{
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+static double pn_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+#define PN_MAXN 8        /* the minimal solver is called with 5 points (model_points) */
+
+/* epnp::compute_R_and_t: control points in the camera frame from the betas, sign, absolute orientation, error */
+static double pn_R_and_t(const double* v /*4 x 12, v[0] = smallest*/, const double* betas, const double* alphas,
+                         const double* pws, const double* us, int n, pn_cam K, double* R, double* t)
+{
+    double ccs[4][3], pcs[PN_MAXN][3];
+    for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[i * 12 + 3 * j + k];
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+            pcs[i][k] = alphas[4 * i] * ccs[0][k] + alphas[4 * i + 1] * ccs[1][k] + alphas[4 * i + 2] * ccs[2][k] + alphas[4 * i + 3] * ccs[3][k];
+    if (pcs[0][2] < 0) {                                  /* solve_for_sign */
+        for (int i = 0; i < 4; i++) for (int k = 0; k < 3; k++) ccs[i][k] = -ccs[i][k];
+        for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) pcs[i][k] = -pcs[i][k];
+    }
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};       /* estimate_R_and_t */
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { pc0[k] += pcs[i][k]; pw0[k] += pws[3 * i + k]; }
+    for (int k = 0; k < 3; k++) { pc0[k] /= n; pw0[k] /= n; }
+    double abt[9] = {0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pcs[i][j] - pc0[j]) * (pws[3 * i] - pw0[0]);
+            abt[3 * j + 1] += (pcs[i][j] - pc0[j]) * (pws[3 * i + 1] - pw0[1]);
+            abt[3 * j + 2] += (pcs[i][j] - pc0[j]) * (pws[3 * i + 2] - pw0[2]);
+        }
+    double At[9], W[3], Vt[9], U[9];
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = abt[i * 3 + j];
+    pn_jacobi_svd(At, 3, 3, W, Vt);
+    for (int j = 0; j < 3; j++) {                          /* U column j = At row j / w_j */
+        double iw = W[j] > 0 ? 1. / W[j] : 0;
+        for (int i = 0; i < 3; i++) U[i * 3 + j] = At[j * 3 + i] * iw;
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = U[i * 3] * Vt[j] + U[i * 3 + 1] * Vt[3 + j] + U[i * 3 + 2] * Vt[6 + j];
+    const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    for (int k = 0; k < 3; k++) t[k] = pc0[k] - pn_dot3(R + 3 * k, pw0);
+    double sum2 = 0;                                       /* reprojection_error */
+    for (int i = 0; i < n; i++) {
+        const double* pw = pws + 3 * i;
+        double Xc = pn_dot3(R, pw) + t[0], Yc = pn_dot3(R + 3, pw) + t[1], inv_Zc = 1.0 / (pn_dot3(R + 6, pw) + t[2]);
+        double ue = K.uc + K.fu * Xc * inv_Zc, ve = K.vc + K.fv * Yc * inv_Zc;
+        double u = us[2 * i], vv = us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (vv - ve) * (vv - ve));
+    }
+    return sum2 / n;
+}
+
+/* epnp::compute_pose for n <= PN_MAXN points: pws world points, us pixel coordinates */
+static void pn_epnp(const double* pws, const double* us, int n, pn_cam K, double* Rbest, double* tbest)
+{
+    double cws[4][3];
+    /* choose_control_points */
+    cws[0][0] = cws[0][1] = cws[0][2] = 0;
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) cws[0][k] += pws[3 * i + k];
+    for (int k = 0; k < 3; k++) cws[0][k] /= n;
+    {
+        double ptp[9] = {0};                              /* PW0^T PW0 */
+        for (int i = 0; i < n; i++)
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+                ptp[r * 3 + c] += (pws[3 * i + r] - cws[0][r]) * (pws[3 * i + c] - cws[0][c]);
+        double At[9], dc[3], Vt[9];
+        for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = ptp[i * 3 + j];
+        pn_jacobi_svd(At, 3, 3, dc, Vt);
+        for (int i = 1; i < 4; i++) {
+            double k = sqrt(dc[i - 1] / n);
+            for (int j = 0; j < 3; j++) cws[i][j] = cws[0][j] + k * Vt[3 * (i - 1) + j];      /* symmetric: u_i = v_i */
+        }
+    }
+    /* compute_barycentric_coordinates */
+    double alphas[4 * PN_MAXN];
+    {
+        double cc[9], ci[9];
+        for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
+        pn_inv3_svd(cc, ci);
+        for (int i = 0; i < n; i++) {
+            const double* pi = pws + 3 * i;
+            double* a = alphas + 4 * i;
+            for (int j = 0; j < 3; j++)
+                a[1 + j] = ci[3 * j] * (pi[0] - cws[0][0]) + ci[3 * j + 1] * (pi[1] - cws[0][1]) + ci[3 * j + 2] * (pi[2] - cws[0][2]);
+            a[0] = 1.0 - a[1] - a[2] - a[3];
+        }
+    }
+    /* M (2n x 12), M^T M, its eigenvectors (rows of Vt; the four smallest are the null-space candidates) */
+    double M[2 * PN_MAXN * 12];
+    for (int i = 0; i < n; i++) {
+        double* M1 = M + (2 * i) * 12; double* M2 = M1 + 12;
+        const double* as = alphas + 4 * i;
+        for (int j = 0; j < 4; j++) {
+            M1[3 * j] = as[j] * K.fu; M1[3 * j + 1] = 0.0; M1[3 * j + 2] = as[j] * (K.uc - us[2 * i]);
+            M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * K.fv; M2[3 * j + 2] = as[j] * (K.vc - us[2 * i + 1]);
+        }
+    }
+    double mtm[144], At[144], D[12], Vt[144];
+    for (int r = 0; r < 12; r++)
+        for (int c = 0; c < 12; c++) {
+            double s = 0;
+            for (int i = 0; i < 2 * n; i++) s += M[i * 12 + r] * M[i * 12 + c];
+            mtm[r * 12 + c] = s;
+        }
+    for (int j = 0; j < 12; j++) for (int i = 0; i < 12; i++) At[j * 12 + i] = mtm[i * 12 + j];
+    pn_jacobi_svd(At, 12, 12, D, Vt);
+    double v[4 * 12];                                      /* v[0] = smallest singular value's vector (ut + 12*11) ... */
+    for (int i = 0; i < 4; i++) memcpy(v + 12 * i, Vt + 12 * (11 - i), sizeof(double) * 12);
+    /* compute_L_6x10, compute_rho */
+    double l[60], rho[6];
+    {
+        double dv[4][6][3];
+        for (int i = 0; i < 4; i++) {
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; j++) {
+                for (int k = 0; k < 3; k++) dv[i][j][k] = v[12 * i + 3 * a + k] - v[12 * i + 3 * b + k];
+                b++;
+                if (b > 3) { a++; b = a + 1; }
+            }
+        }
+        for (int i = 0; i < 6; i++) {
+            double* row = l + 10 * i;
+            row[0] = pn_dot3(dv[0][i], dv[0][i]);
+            row[1] = 2.0 * pn_dot3(dv[0][i], dv[1][i]);
+            row[2] = pn_dot3(dv[1][i], dv[1][i]);
+            row[3] = 2.0 * pn_dot3(dv[0][i], dv[2][i]);
+            row[4] = 2.0 * pn_dot3(dv[1][i], dv[2][i]);
+            row[5] = pn_dot3(dv[2][i], dv[2][i]);
+            row[6] = 2.0 * pn_dot3(dv[0][i], dv[3][i]);
+            row[7] = 2.0 * pn_dot3(dv[1][i], dv[3][i]);
+            row[8] = 2.0 * pn_dot3(dv[2][i], dv[3][i]);
+            row[9] = pn_dot3(dv[3][i], dv[3][i]);
+        }
+        rho[0] = pn_dist2(cws[0], cws[1]); rho[1] = pn_dist2(cws[0], cws[2]); rho[2] = pn_dist2(cws[0], cws[3]);
+        rho[3] = pn_dist2(cws[1], cws[2]); rho[4] = pn_dist2(cws[1], cws[3]); rho[5] = pn_dist2(cws[2], cws[3]);
+    }
+    double betas[4][4], rep[4], Rs[4][9], ts[4][3];
+    for (int N = 1; N <= 3; N++) {
+        double* be = betas[N];
+        if (N == 1) {                                      /* find_betas_approx_1: [B11 B12 B13 B14] */
+            double L4[24], b4[4];
+            for (int i = 0; i < 6; i++) { L4[4 * i] = l[10 * i]; L4[4 * i + 1] = l[10 * i + 1]; L4[4 * i + 2] = l[10 * i + 3]; L4[4 * i + 3] = l[10 * i + 6]; }
+            pn_svd_solve(L4, 6, 4, rho, b4);
+            if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
+            else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
+        } else if (N == 2) {                               /* find_betas_approx_2: [B11 B12 B22] */
+            double L3[18], b3[3];
+            for (int i = 0; i < 6; i++) { L3[3 * i] = l[10 * i]; L3[3 * i + 1] = l[10 * i + 1]; L3[3 * i + 2] = l[10 * i + 2]; }
+            pn_svd_solve(L3, 6, 3, rho, b3);
+            if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+            else { be[0] = sqrt(b3[0]); be[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+            if (b3[1] < 0) be[0] = -be[0];
+            be[2] = 0.0; be[3] = 0.0;
+        } else {                                           /* find_betas_approx_3: [B11 B12 B22 B13 B23] */
+            double L5[30], b5[5];
+            for (int i = 0; i < 6; i++) for (int k = 0; k < 5; k++) L5[5 * i + k] = l[10 * i + k];
+            pn_svd_solve(L5, 6, 5, rho, b5);
+            if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+            else { be[0] = sqrt(b5[0]); be[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+            if (b5[1] < 0) be[0] = -be[0];
+            be[2] = b5[3] / be[0]; be[3] = 0.0;
+        }
+        for (int it = 0; it < 5; it++) {                   /* gauss_newton */
+            double A[24], b[6], x[4];
+            for (int i = 0; i < 6; i++) {
+                const double* rl = l + 10 * i; double* ra = A + 4 * i;
+                ra[0] = 2 * rl[0] * be[0] + rl[1] * be[1] + rl[3] * be[2] + rl[6] * be[3];
+                ra[1] = rl[1] * be[0] + 2 * rl[2] * be[1] + rl[4] * be[2] + rl[7] * be[3];
+                ra[2] = rl[3] * be[0] + rl[4] * be[1] + 2 * rl[5] * be[2] + rl[8] * be[3];
+                ra[3] = rl[6] * be[0] + rl[7] * be[1] + rl[8] * be[2] + 2 * rl[9] * be[3];
+                b[i] = rho[i] - (rl[0] * be[0] * be[0] + rl[1] * be[0] * be[1] + rl[2] * be[1] * be[1] + rl[3] * be[0] * be[2] +
+                                 rl[4] * be[1] * be[2] + rl[5] * be[2] * be[2] + rl[6] * be[0] * be[3] + rl[7] * be[1] * be[3] +
+                                 rl[8] * be[2] * be[3] + rl[9] * be[3] * be[3]);
+            }
+            pn_qr_solve_6x4(A, b, x);
+            for (int i = 0; i < 4; i++) be[i] += x[i];
+        }
+        rep[N] = pn_R_and_t(v, be, alphas, pws, us, n, K, Rs[N], ts[N]);
+    }
+    int N = 1;
+    if (rep[2] < rep[1]) N = 2;
+    if (rep[3] < rep[N]) N = 3;
+    memcpy(Rbest, Rs[N], sizeof(double) * 9); memcpy(tbest, ts[N], sizeof(double) * 3);
+}
+
+/* cv::Rodrigues, matrix -> vector (calibration.cpp cvRodrigues2) */
+static void pn_rodrigues_to_vec(const double* R, double* r)
+{
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (R[0] + 1) * 0.5; rx = sqrt(t > 0 ? t : 0);
+        t = (R[4] + 1) * 0.5; ry = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+        theta /= sqrt(rx * rx + ry * ry + rz * rz);
+        r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
+        return;
+    }
+    double vth = 1 / (2 * s);
+    vth *= theta;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+/* cv::Rodrigues, vector -> matrix */
+static void pn_rodrigues_to_mat(const double* r, double* R)
+{
+    double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < DBL_EPSILON) { memset(R, 0, sizeof(double) * 9); R[0] = R[4] = R[8] = 1; return; }
+    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
+    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+int voo_rodrigues(const double* in, int in_is_matrix, double* out)
+{
+    if (in_is_matrix) pn_rodrigues_to_vec(in, out); else pn_rodrigues_to_mat(in, out);
+    return 0;
+}
+
+/* PnPRansacCallback::computeError + findInliers: projectPoints (double inside, float32 out), squared float32 distance */
+static int pn_find_inliers(const float* obj, const float* img, int n, const double* R, const double* t, pn_cam K,
+                           float thr, uint8_t* mask)
+{
+    int nz = 0;
+    for (int i = 0; i < n; i++) {
+        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + t[0], y = R[3] * X + R[4] * Y + R[5] * Z + t[1], z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        const float pu = (float)(x * K.fu + K.uc), pv = (float)(y * K.fv + K.vc);
+        const float du = img[2 * i] - pu, dv = img[2 * i + 1] - pv;
+        const float err = du * du + dv * dv;
+        const int f = err <= thr;
+        mask[i] = (uint8_t)f;
+        nz += f;
+    }
+    return nz;
+}
+
+static inline uint32_t pn_rng_next(uint64_t* state)
+{
+    *state = (uint64_t)(uint32_t)*state * 4164903690U + (uint32_t)(*state >> 32);
+    return (uint32_t)*state;
+}
+
+static int pn_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p < 0 ? 0 : p; p = p > 1 ? 1 : p;
+    ep = ep < 0 ? 0 : ep; ep = ep > 1 ? 1 : ep;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+
+/* solvePnP(SOLVEPNP_EPNP) on the float32 sample: undistortPoints gives float32 normalised coordinates, which
+ * epnp::init_points maps back to pixels in double */
+static void pn_minimal(const float* obj, const float* img, const int* idx, int n, pn_cam K, double* R, double* t)
+{
+    double pws[3 * PN_MAXN], us[2 * PN_MAXN];
+    const double ifx = 1. / K.fu, ify = 1. / K.fv;
+    for (int i = 0; i < n; i++) {
+        const int j = idx ? idx[i] : i;
+        pws[3 * i] = obj[3 * j]; pws[3 * i + 1] = obj[3 * j + 1]; pws[3 * i + 2] = obj[3 * j + 2];
+        const float xn = (float)(((double)img[2 * j] - K.uc) * ifx), yn = (float)(((double)img[2 * j + 1] - K.vc) * ify);
+        us[2 * i] = (double)xn * K.fu + K.uc; us[2 * i + 1] = (double)yn * K.fv + K.vc;
+    }
+    pn_epnp(pws, us, n, K, R, t);
+}
+
+/* 3 x 3 rotation from an so(3) increment w: exp([w]x) (Rodrigues' formula) */
+static void pn_exp_so3(const double* w, double* E)
+{
+    pn_rodrigues_to_mat(w, E);
+}
+
+static void pn_mat3mul(const double* a, const double* b, double* r)
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+/* cost and normal equations of the pixel reprojection error at (R, t), increment (w, dt): x = exp(w) R X + t + dt.
+ * Summation order (any order restates the same sums; this one is what a 256-thread workgroup does, so that the HIP
+ * kernel can reproduce it bit for bit): partial sums over the points k, k + 256, k + 512, ... for k = 0..255, then the
+ * 256 partials added in increasing k.  acc = [cost, Jte (6), upper triangle of JtJ (21)]. */
+#define PN_LANES 256
+static void pn_point_terms(const double* Xw, const double* uv, const double* R, const double* t, pn_cam K, int want_j, double* acc)
+{
+    const double a = pn_dot3(R, Xw), b = pn_dot3(R + 3, Xw), c = pn_dot3(R + 6, Xw);      /* R X */
+    const double x = a + t[0], y = b + t[1], z = c + t[2];
+    const double iz = 1. / z;
+    const double eu = K.fu * x * iz + K.uc - uv[0], ev = K.fv * y * iz + K.vc - uv[1];
+    acc[0] += eu * eu + ev * ev;
+    if (!want_j) return;
+    /* d(u)/d(x,y,z), then d(x,y,z)/d(w) = -[R X]x, d/d(dt) = I */
+    const double ux = K.fu * iz, uz = -K.fu * x * iz * iz, vy = K.fv * iz, vz = -K.fv * y * iz * iz;
+    double Ju[6], Jv[6];
+    Ju[0] = uz * b;            Ju[1] = ux * c - uz * a;   Ju[2] = -ux * b;          /* row (ux, 0, uz) * -[RX]x */
+    Jv[0] = -vy * c + vz * b;  Jv[1] = -vz * a;           Jv[2] = vy * a;           /* row (0, vy, vz) * -[RX]x */
+    Ju[3] = ux; Ju[4] = 0;  Ju[5] = uz;
+    Jv[3] = 0;  Jv[4] = vy; Jv[5] = vz;
+    int q = 7;
+    for (int r = 0; r < 6; r++) {
+        acc[1 + r] += Ju[r] * eu + Jv[r] * ev;
+        for (int s = r; s < 6; s++) acc[q++] += Ju[r] * Ju[s] + Jv[r] * Jv[s];
+    }
+}
+
+static double pn_normal_eq(const double* obj, const double* img, const uint8_t* mask, int n, const double* R, const double* t,
+                           pn_cam K, double* JtJ /*36*/, double* Jte /*6*/)
+{
+    double tot[28];
+    for (int q = 0; q < 28; q++) tot[q] = 0;
+    for (int k = 0; k < PN_LANES; k++) {
+        double acc[28];
+        for (int q = 0; q < 28; q++) acc[q] = 0;
+        for (int i = k; i < n; i += PN_LANES) {
+            if (mask && !mask[i]) continue;
+            pn_point_terms(obj + 3 * i, img + 2 * i, R, t, K, JtJ != NULL, acc);
+        }
+        for (int q = 0; q < 28; q++) tot[q] += acc[q];
+    }
+    if (JtJ) {
+        int q = 7;
+        for (int r = 0; r < 6; r++) {
+            Jte[r] = tot[1 + r];
+            for (int s2 = r; s2 < 6; s2++) { JtJ[r * 6 + s2] = tot[q]; JtJ[s2 * 6 + r] = tot[q]; q++; }
+        }
+    }
+    return tot[0];
+}
+
+/* symmetric positive definite 6 x 6 solve by Cholesky; returns 0 if not positive definite */
+static int pn_chol6(const double* A, const double* b, double* x)
+{
+    double L[36];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (s <= 0) return 0; L[i * 6 + i] = sqrt(s); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+    return 1;
+}
+
+/* reprojection-error minimum over the masked points from (R, t): Levenberg-Marquardt, multiplicative damping */
+static void pn_refine(const double* obj, const double* img, const uint8_t* mask, int n, pn_cam K, double* R, double* t)
+{
+    double lambda = 1e-3, JtJ[36], Jte[6];
+    double cost = pn_normal_eq(obj, img, mask, n, R, t, K, JtJ, Jte);
+    for (int it = 0; it < 100; it++) {
+        double A[36], rhs[6], d[6];
+        memcpy(A, JtJ, sizeof(A));
+        for (int k = 0; k < 6; k++) { A[k * 6 + k] *= 1. + lambda; rhs[k] = -Jte[k]; }
+        if (!pn_chol6(A, rhs, d)) { lambda *= 10; if (lambda > 1e12) break; continue; }
+        double E[9], Rn[9], tn[3];
+        pn_exp_so3(d, E);
+        pn_mat3mul(E, R, Rn);
+        for (int k = 0; k < 3; k++) tn[k] = t[k] + d[3 + k];
+        const double cn = pn_normal_eq(obj, img, mask, n, Rn, tn, K, NULL, NULL);
+        if (cn < cost) {
+            const double step = fabs(d[0]) + fabs(d[1]) + fabs(d[2]) + fabs(d[3]) + fabs(d[4]) + fabs(d[5]);
+            memcpy(R, Rn, sizeof(Rn)); memcpy(t, tn, sizeof(tn));
+            cost = pn_normal_eq(obj, img, mask, n, R, t, K, JtJ, Jte);
+            lambda = lambda > 1e-12 ? lambda * 0.1 : lambda;
+            if (step < 1e-13 * (1. + fabs(t[0]) + fabs(t[1]) + fabs(t[2]))) break;
+        } else {
+            lambda *= 10;
+            if (lambda > 1e12) break;
+        }
+    }
+}
+
+/* returns 0 and (rvec, tvec, inlier mask) like cv2.solvePnPRansac's retval True; -3: fewer than 4 points,
+ * -4: no model, -7: exactly 4 points (the P3P path of solvePnPRansac is not restated) */
+int voo_solve_pnp_ransac(const double* obj, const double* img, int n, const double* Kd, int iterations, double reproj_err,
+                         double confidence, uint64_t seed, double* rvec, double* tvec, uint8_t* mask, int32_t* n_inl)
+{
+    *n_inl = 0;
+    if (n < 4) return -3;
+    if (n == 4) return -7;
+    if (!(confidence > 0 && confidence < 1)) return -1;
+    const pn_cam K = {Kd[0], Kd[4], Kd[2], Kd[5]};
+    float* of = (float*)malloc(sizeof(float) * 5 * (size_t)n);
+    float* imf = of + 3 * (size_t)n;
+    for (int i = 0; i < 3 * n; i++) of[i] = (float)obj[i];
+    for (int i = 0; i < 2 * n; i++) imf[i] = (float)img[i];
+    double R[9], t[3];
+    if (n == 5) {                                          /* model_points == npoints: one EPnP, every point an inlier */
+        pn_minimal(of, imf, NULL, 5, K, R, t);
+        pn_rodrigues_to_vec(R, rvec);
+        memcpy(tvec, t, sizeof(t));
+        memset(mask, 1, 5);
+        *n_inl = 5;
+        free(of);
+        return 0;
+    }
+    const float thr = (float)(reproj_err * reproj_err);
+    uint64_t state = seed ? seed : 0xffffffffULL;
+    uint8_t* cur = (uint8_t*)malloc((size_t)n);
+    int niters = iterations > 1 ? iterations : 1, max_good = 0;
+    double Rb[9], tb[3];
+    for (int iter = 0; iter < niters; iter++) {
+        int idx[5];
+        for (int i = 0; i < 5; i++) {
+            int idx_i, dup;
+            do {
+                idx_i = (int)(pn_rng_next(&state) % (uint32_t)n);
+                dup = 0;
+                for (int k = 0; k < i; k++) dup |= idx[k] == idx_i;
+            } while (dup);
+            idx[i] = idx_i;
+        }
+        pn_minimal(of, imf, idx, 5, K, R, t);
+        const int good = pn_find_inliers(of, imf, n, R, t, K, thr, cur);
+        if (good > (max_good > 4 ? max_good : 4)) {
+            memcpy(mask, cur, (size_t)n);
+            memcpy(Rb, R, sizeof(R)); memcpy(tb, t, sizeof(t));
+            max_good = good;
+            niters = pn_update_num_iters(confidence, (double)(n - good) / n, 5, niters);
+        }
+    }
+    free(cur); free(of);
+    if (max_good <= 0) { memset(mask, 0, (size_t)n); return -4; }
+    pn_refine(obj, img, mask, n, K, Rb, tb);               /* solvePnP(SOLVEPNP_ITERATIVE) on the inliers, in double */
+    pn_rodrigues_to_vec(Rb, rvec);
+    memcpy(tvec, tb, sizeof(tb));
+    *n_inl = max_good;
+    return 0;
+}

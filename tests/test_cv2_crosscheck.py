@@ -133,3 +133,21 @@ def test_recover_pose_and_triangulate(oracle, frames):
     X = X / X[3]; X2 = X2 / X2[3]
     near = np.linalg.norm(X[:3], axis=0) < 10 * np.median(np.linalg.norm(X[:3], axis=0))
     assert np.abs(X[:3, near] - X2[:3, near]).max() < 1e-3 * np.abs(X[:3, near]).max()
+
+
+def test_solve_pnp_ransac_and_rodrigues(oracle):
+    """visual_slam.py:231-243.  Tolerance only: cv2's EPnP takes its 12x12 SVD from LAPACK (oracle/voo_pnp.c)."""
+    rng = np.random.default_rng(77)
+    K = np.array([[800., 0, 320], [0, 800, 240], [0, 0, 1]])
+    r_true = np.array([0.1, -0.3, 0.2]); t_true = np.array([0.2, -0.1, 5.5])
+    X = rng.uniform(-2, 2, (240, 3)); Xc = X @ cv2.Rodrigues(r_true)[0].T + t_true
+    uv = ((Xc / Xc[:, 2:]) @ K.T)[:, :2] + rng.normal(0, 0.4, (240, 2))
+    bad = rng.random(240) < 0.35
+    uv[bad] += rng.uniform(-80, 80, (int(bad.sum()), 2))
+    ok, rvec, tvec, inl = cv2.solvePnPRansac(X, uv, K, np.zeros(4))
+    rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(X, uv, K)
+    assert ok and rc == 0
+    ref = np.zeros(240, bool); ref[inl.ravel()] = True
+    assert (ref == (mask > 0)).mean() > 0.98                    # threshold-edge points may flip with the hypothesis noise
+    assert np.abs(rvec.ravel() - rv).max() < 1e-3 and np.abs(tvec.ravel() - tv).max() < 1e-2
+    assert np.abs(cv2.Rodrigues(rv)[0] - oracle.rodrigues(rv)).max() < 1e-12

@@ -81,3 +81,11 @@ def test_ingest_golden(oracle):
     g = np.load(os.path.join(G, "ingest_192x108.npz"))
     for name, (dw, dh) in (("dst_57x32", (57, 32)), ("dst_96x54", (96, 54)), ("dst_250x120", (250, 120))):
         assert np.array_equal(oracle.resize_linear(g["src"], dw, dh), g[name])
+
+
+def test_pnp_golden(oracle):
+    g = np.load(os.path.join(G, "pnp_240.npz"))
+    rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(g["obj"], g["img"], g["K"])
+    assert rc == int(g["rc"]) == 0 and ninl == int(g["n_inl"]) and np.array_equal(mask, g["mask"])
+    assert np.allclose(rv, g["rvec"], atol=1e-12) and np.allclose(tv, g["tvec"], atol=1e-12)
+    assert np.abs(oracle.rodrigues(rv) - g["R_true"]).max() < 0.01 and np.abs(tv - g["t_true"]).max() < 0.05

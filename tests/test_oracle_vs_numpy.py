@@ -291,3 +291,59 @@ def test_ingest_resize_identities(oracle):
     assert np.array_equal(half, ref.astype(np.uint8))
     flat = np.full((30, 30), 77, np.uint8)
     assert np.all(oracle.resize_linear(flat, 11, 17) == 77)                       # constants survive the fixed point
+
+
+# ------------------------------------------------------------------ "next" row: PnP-RANSAC localisation (visual_slam.py:231-243)
+def _pnp_problem(seed, n, outl, noise=0.5):
+    rng = np.random.default_rng(seed)
+    K = np.array([[800., 0, 320], [0, 800, 240], [0, 0, 1]])
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax); th = rng.uniform(0.1, 0.6)
+    kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(th) * kx + (1 - np.cos(th)) * kx @ kx
+    t = np.array([0.3, -0.2, 6.0]) + rng.normal(0, 0.3, 3)
+    X = rng.uniform(-2, 2, (n, 3))
+    Xc = X @ R.T + t
+    uv = ((Xc / Xc[:, 2:]) @ K.T)[:, :2] + rng.normal(0, noise, (n, 2))
+    bad = rng.random(n) < outl
+    uv[bad] += rng.uniform(-100, 100, (int(bad.sum()), 2))
+    return K, X, uv, R, t, bad
+
+
+@pytest.mark.parametrize("seed,n,outl", [(1, 200, 0.3), (2, 50, 0.1), (3, 1000, 0.5), (4, 12, 0.0), (6, 5, 0.0)])
+def test_pnp_ransac_recovers_the_pose_and_the_lm_minimum(oracle, seed, n, outl):
+    """The restated solvePnPRansac finds the generating pose and inlier set; its refined pose is the reprojection-error
+    minimum over those inliers, checked against scipy's own Levenberg-Marquardt in the rvec parametrisation cv2 uses."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    K, X, uv, R, t, bad = _pnp_problem(seed, n, outl)
+    rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(X, uv, K)
+    assert rc == 0 and ninl == int(mask.sum())
+    assert ((mask > 0) == ~bad).mean() > 0.97
+    tol = 0.02 if n > 6 else 0.2
+    assert np.abs(oracle.rodrigues(rv) - R).max() < tol and np.abs(tv - t).max() < 5 * tol
+    if n > 5:
+        inl = mask > 0
+
+        def res(p):
+            Xc = X[inl] @ Rotation.from_rotvec(p[:3]).as_matrix().T + p[3:]
+            return (((Xc / Xc[:, 2:]) @ K.T)[:, :2] - uv[inl]).ravel()
+        sol = least_squares(res, np.concatenate([rv, tv]) + 1e-3, xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        assert np.abs(sol.x[:3] - rv).max() < 1e-7 and np.abs(sol.x[3:] - tv).max() < 1e-7
+    rc2, rv2, tv2, mask2, _ = oracle.solve_pnp_ransac(X, uv, K)             # fixed seed: deterministic
+    assert np.array_equal(rv, rv2) and np.array_equal(tv, tv2) and np.array_equal(mask, mask2)
+
+
+def test_pnp_error_codes_and_rodrigues(oracle):
+    from scipy.spatial.transform import Rotation
+    K, X, uv, *_ = _pnp_problem(3, 4, 0.0)
+    assert oracle.solve_pnp_ransac(X[:3], uv[:3], K)[0] == -3                # cv2 asserts npoints >= 4
+    assert oracle.solve_pnp_ransac(X, uv, K)[0] == -7                        # exactly 4: cv2's P3P branch, not restated
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        r = rng.normal(0, 1.3, 3)
+        Rm = oracle.rodrigues(r)
+        assert np.abs(Rm - Rotation.from_rotvec(r).as_matrix()).max() < 1e-14
+        assert np.abs(oracle.rodrigues(Rm) - Rotation.from_matrix(Rm).as_rotvec()).max() < 1e-12
+    assert np.array_equal(oracle.rodrigues(np.zeros(3)), np.eye(3))
+    near_pi = np.array([np.pi - 1e-9, 0, 0])                                  # the s < 1e-5 branch of cvRodrigues2
+    assert np.abs(oracle.rodrigues(oracle.rodrigues(near_pi)) - near_pi).max() < 1e-6

@@ -58,6 +58,20 @@ def main():
     big = rng.integers(0, 256, (108, 192, 3), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "ingest_192x108.npz"), src=big, dst_57x32=O.resize_linear(big, 57, 32),
                         dst_96x54=O.resize_linear(big, 96, 54), dst_250x120=O.resize_linear(big, 250, 120))
+    # localisation: cv2.solvePnPRansac (visual_slam.py:231-235)
+    rng = np.random.default_rng(77)
+    Kp = np.array([[800., 0, 320], [0, 800, 240], [0, 0, 1]])
+    ax = np.array([0.3, -0.8, 0.5]); ax /= np.linalg.norm(ax)
+    kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rp = np.eye(3) + np.sin(0.35) * kx + (1 - np.cos(0.35)) * kx @ kx
+    tp = np.array([0.2, -0.1, 5.5])
+    Xp = rng.uniform(-2, 2, (240, 3)); Xc = Xp @ Rp.T + tp
+    uvp = ((Xc / Xc[:, 2:]) @ Kp.T)[:, :2] + rng.normal(0, 0.4, (240, 2))
+    badp = rng.random(240) < 0.35
+    uvp[badp] += rng.uniform(-80, 80, (int(badp.sum()), 2))
+    rc, rv, tv, mk, ni = O.solve_pnp_ransac(Xp, uvp, Kp)
+    np.savez_compressed(os.path.join(OUT, "pnp_240.npz"), K=Kp, obj=Xp, img=uvp, R_true=Rp, t_true=tp, rc=rc, rvec=rv, tvec=tv,
+                        mask=mk, n_inl=ni)
     print("wrote", os.listdir(OUT))
 
 

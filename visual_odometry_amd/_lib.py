@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
 
 VO_OK, VO_WARN_CAPACITY = 0, 1
 VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL, VO_ERR_NOT_CONFIGURED, VO_ERR_AMBIGUOUS = -1, -2, -3, -4, -5, -6
+VO_ERR_UNSUPPORTED = -7
 VO_STAGE_COUNT = 16
 
 
@@ -67,6 +68,9 @@ _SIGS = {
     "vo_detect_after": (C.c_int, [_P, _P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
+    "vo_solve_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_double, C.c_double, C.c_uint64, _P, _P, _P, _P]),
+    "vo_solve_pnp_ransac_batch": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_double, C.c_double, C.c_uint64, _P, _P, _P, _P, _P]),
+    "vo_rodrigues": (C.c_int, [_P, _P, C.c_int, _P]),
     "vo_resize_linear": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vo_frames_ingest": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _P]),
     "vo_feature_tracks": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),

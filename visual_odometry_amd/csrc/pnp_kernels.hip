@@ -1,0 +1,746 @@
+// pnp_kernels.hip — localisation after the pair path: cv2.solvePnPRansac(map_coords, image_coords, K, zeros(4))
+// (reference: src/visual_slam.py:231-235, then cv2.Rodrigues :243) on gfx950.
+//
+// One workgroup per PnP problem.  RANSAC as ptsetreg.cpp runs it (same generator, sampling and adaptive iteration
+// count as the essential-matrix kernel): 64 five-point samples per round are solved one per lane by EPnP
+// (epnp.cpp: control points, barycentric coordinates, null space of M^T M by one-sided Jacobi, three beta
+// approximations + Gauss-Newton, absolute orientation) with thread-private work arrays, the hypotheses are scored
+// one per wavefront (float32 reprojection error, ballot + popcount) and consumed in OpenCV's order; the final pose
+// is the reprojection-error minimum over the inliers: Levenberg-Marquardt whose normal equations are accumulated by
+// all 256 threads (interleaved partial sums, added in thread order — the order the CPU oracle uses, so the two agree
+// to the last bit up to libm's acos / cos / sin).  The arithmetic below is kept operation for operation equal to the
+// oracle's restatement.
+#include "vo_internal.h"
+#include <float.h>
+
+__device__ static inline double dp_hypot(double a, double b)
+{
+    a = fabs(a); b = fabs(b);
+    if (a < b) { double t = a; a = b; b = t; }
+    if (a == 0) return 0;
+    double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
+/* one-sided Jacobi SVD (lapack.cpp JacobiSVDImpl_): At = n rows of length m (row i = column i of A, m >= n).
+ * On return row i of At = sigma_i u_i, W descending, Vt rows = right singular vectors. */
+__device__ static void dp_jacobi_svd(double* At, int m, int n, double* W, double* Vt)
+{
+    const double eps = DBL_EPSILON * 10;
+    int max_iter = m > 30 ? m : 30;
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) sd += At[i * m + k] * At[i * m + k];
+        W[i] = sd;
+        for (int k = 0; k < n; k++) Vt[i * n + k] = 0;
+        Vt[i * n + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        int changed = 0;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                double *Ai = At + i * m, *Aj = At + j * m;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = dp_hypot(p, beta), c, s;
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (int k = 0; k < m; k++) {
+                    double t0 = c * Ai[k] + s * Aj[k];
+                    double t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = 1;
+                double *Vi = Vt + i * n, *Vj = Vt + j * n;
+                for (int k = 0; k < n; k++) {
+                    double t0 = c * Vi[k] + s * Vj[k];
+                    double t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+        for (int k = 0; k < m; k++) sd += At[i * m + k] * At[i * m + k];
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (int k = 0; k < m; k++) { t = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = t; }
+            for (int k = 0; k < n; k++) { t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t; }
+        }
+    }
+}
+
+/* cvSolve(A, b, x, CV_SVD) for an m x n system, m >= n <= 5, m <= 6: SVD::backSubst with OpenCV's threshold */
+__device__ static void dp_svd_solve(const double* A, int m, int n, const double* b, double* x)
+{
+    double At[5 * 6], W[5], Vt[25];
+    for (int j = 0; j < n; j++) for (int i = 0; i < m; i++) At[j * m + i] = A[i * n + j];
+    dp_jacobi_svd(At, m, n, W, Vt);
+    double thr = 0;
+    for (int j = 0; j < n; j++) thr += W[j];
+    thr *= DBL_EPSILON * 2;
+    for (int k = 0; k < n; k++) x[k] = 0;
+    for (int j = 0; j < n; j++) {
+        if (W[j] <= thr) continue;
+        double s = 0;                                     /* u_j . b / w_j, u_j = At row j / w_j */
+        for (int i = 0; i < m; i++) s += At[j * m + i] * b[i];
+        s /= W[j] * W[j];
+        for (int k = 0; k < n; k++) x[k] += s * Vt[j * n + k];
+    }
+}
+
+/* cvInvert(A, Ai, CV_SVD) for 3 x 3 */
+__device__ static void dp_inv3_svd(const double* A, double* Ai)
+{
+    double At[9], W[3], Vt[9];
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = A[i * 3 + j];
+    dp_jacobi_svd(At, 3, 3, W, Vt);
+    double thr = (W[0] + W[1] + W[2]) * DBL_EPSILON * 2;
+    for (int k = 0; k < 9; k++) Ai[k] = 0;
+    for (int j = 0; j < 3; j++) {
+        if (W[j] <= thr) continue;
+        const double iw2 = 1. / (W[j] * W[j]);           /* A^-1 = sum v_j u_j^T / w_j, u_j = At row j / w_j */
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ai[r * 3 + c] += Vt[j * 3 + r] * At[j * 3 + c] * iw2;
+    }
+}
+
+/* epnp.cpp qr_solve: Householder least squares for the 6 x 4 Gauss-Newton system (A is destroyed) */
+__device__ static void dp_qr_solve_6x4(double* A, double* b, double* X)
+{
+    const int nr = 6, nc = 4;
+    double A1[4], A2[4];
+    for (int k = 0; k < nc; k++) {
+        double eta = 0;
+        for (int i = k; i < nr; i++) { double e = fabs(A[i * nc + k]); if (e > eta) eta = e; }
+        if (eta == 0) { A1[k] = A2[k] = 0; continue; }   /* singular: epnp.cpp prints and returns; the step is then zero */
+        double sum = 0, inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) { A[i * nc + k] *= inv_eta; sum += A[i * nc + k] * A[i * nc + k]; }
+        double sigma = sqrt(sum);
+        if (A[k * nc + k] < 0) sigma = -sigma;
+        A[k * nc + k] += sigma;
+        A1[k] = sigma * A[k * nc + k];
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double s = 0;
+            for (int i = k; i < nr; i++) s += A[i * nc + k] * A[i * nc + j];
+            double tau = s / A1[k];
+            for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
+        }
+    }
+    for (int j = 0; j < nc; j++) {                        /* b <- Q^T b */
+        if (A1[j] == 0) continue;
+        double s = 0;
+        for (int i = j; i < nr; i++) s += A[i * nc + j] * b[i];
+        double tau = s / A1[j];
+        for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
+    }
+    for (int i = nc - 1; i >= 0; i--) {                   /* R x = b */
+        if (A2[i] == 0) { X[i] = 0; continue; }
+        double s = b[i];
+        for (int j = i + 1; j < nc; j++) s -= A[i * nc + j] * X[j];
+        X[i] = s / A2[i];
+    }
+}
+
+typedef struct { double fu, fv, uc, vc; } dp_cam;
+
+__device__ static double dp_dist2(const double* a, const double* b)
+{
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+__device__ static double dp_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+#define DP_MAXN 8        /* the minimal solver is called with 5 points (model_points) */
+
+/* epnp::compute_R_and_t: control points in the camera frame from the betas, sign, absolute orientation, error */
+__device__ static double dp_R_and_t(const double* v /*4 x 12, v[0] = smallest*/, const double* betas, const double* alphas,
+                         const double* pws, const double* us, int n, dp_cam K, double* R, double* t)
+{
+    double ccs[4][3], pcs[DP_MAXN][3];
+    for (int i = 0; i < 4; i++) ccs[i][0] = ccs[i][1] = ccs[i][2] = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++) ccs[j][k] += betas[i] * v[i * 12 + 3 * j + k];
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+            pcs[i][k] = alphas[4 * i] * ccs[0][k] + alphas[4 * i + 1] * ccs[1][k] + alphas[4 * i + 2] * ccs[2][k] + alphas[4 * i + 3] * ccs[3][k];
+    if (pcs[0][2] < 0) {                                  /* solve_for_sign */
+        for (int i = 0; i < 4; i++) for (int k = 0; k < 3; k++) ccs[i][k] = -ccs[i][k];
+        for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) pcs[i][k] = -pcs[i][k];
+    }
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};       /* estimate_R_and_t */
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) { pc0[k] += pcs[i][k]; pw0[k] += pws[3 * i + k]; }
+    for (int k = 0; k < 3; k++) { pc0[k] /= n; pw0[k] /= n; }
+    double abt[9] = {0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pcs[i][j] - pc0[j]) * (pws[3 * i] - pw0[0]);
+            abt[3 * j + 1] += (pcs[i][j] - pc0[j]) * (pws[3 * i + 1] - pw0[1]);
+            abt[3 * j + 2] += (pcs[i][j] - pc0[j]) * (pws[3 * i + 2] - pw0[2]);
+        }
+    double At[9], W[3], Vt[9], U[9];
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = abt[i * 3 + j];
+    dp_jacobi_svd(At, 3, 3, W, Vt);
+    for (int j = 0; j < 3; j++) {                          /* U column j = At row j / w_j */
+        double iw = W[j] > 0 ? 1. / W[j] : 0;
+        for (int i = 0; i < 3; i++) U[i * 3 + j] = At[j * 3 + i] * iw;
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = U[i * 3] * Vt[j] + U[i * 3 + 1] * Vt[3 + j] + U[i * 3 + 2] * Vt[6 + j];
+    const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    for (int k = 0; k < 3; k++) t[k] = pc0[k] - dp_dot3(R + 3 * k, pw0);
+    double sum2 = 0;                                       /* reprojection_error */
+    for (int i = 0; i < n; i++) {
+        const double* pw = pws + 3 * i;
+        double Xc = dp_dot3(R, pw) + t[0], Yc = dp_dot3(R + 3, pw) + t[1], inv_Zc = 1.0 / (dp_dot3(R + 6, pw) + t[2]);
+        double ue = K.uc + K.fu * Xc * inv_Zc, ve = K.vc + K.fv * Yc * inv_Zc;
+        double u = us[2 * i], vv = us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (vv - ve) * (vv - ve));
+    }
+    return sum2 / n;
+}
+
+/* epnp::compute_pose for n <= DP_MAXN points: pws world points, us pixel coordinates */
+__device__ static void dp_epnp(const double* pws, const double* us, int n, dp_cam K, double* Rbest, double* tbest)
+{
+    double cws[4][3];
+    /* choose_control_points */
+    cws[0][0] = cws[0][1] = cws[0][2] = 0;
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) cws[0][k] += pws[3 * i + k];
+    for (int k = 0; k < 3; k++) cws[0][k] /= n;
+    {
+        double ptp[9] = {0};                              /* PW0^T PW0 */
+        for (int i = 0; i < n; i++)
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+                ptp[r * 3 + c] += (pws[3 * i + r] - cws[0][r]) * (pws[3 * i + c] - cws[0][c]);
+        double At[9], dc[3], Vt[9];
+        for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = ptp[i * 3 + j];
+        dp_jacobi_svd(At, 3, 3, dc, Vt);
+        for (int i = 1; i < 4; i++) {
+            double k = sqrt(dc[i - 1] / n);
+            for (int j = 0; j < 3; j++) cws[i][j] = cws[0][j] + k * Vt[3 * (i - 1) + j];      /* symmetric: u_i = v_i */
+        }
+    }
+    /* compute_barycentric_coordinates */
+    double alphas[4 * DP_MAXN];
+    {
+        double cc[9], ci[9];
+        for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
+        dp_inv3_svd(cc, ci);
+        for (int i = 0; i < n; i++) {
+            const double* pi = pws + 3 * i;
+            double* a = alphas + 4 * i;
+            for (int j = 0; j < 3; j++)
+                a[1 + j] = ci[3 * j] * (pi[0] - cws[0][0]) + ci[3 * j + 1] * (pi[1] - cws[0][1]) + ci[3 * j + 2] * (pi[2] - cws[0][2]);
+            a[0] = 1.0 - a[1] - a[2] - a[3];
+        }
+    }
+    /* M (2n x 12), M^T M, its eigenvectors (rows of Vt; the four smallest are the null-space candidates) */
+    double M[2 * DP_MAXN * 12];
+    for (int i = 0; i < n; i++) {
+        double* M1 = M + (2 * i) * 12; double* M2 = M1 + 12;
+        const double* as = alphas + 4 * i;
+        for (int j = 0; j < 4; j++) {
+            M1[3 * j] = as[j] * K.fu; M1[3 * j + 1] = 0.0; M1[3 * j + 2] = as[j] * (K.uc - us[2 * i]);
+            M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * K.fv; M2[3 * j + 2] = as[j] * (K.vc - us[2 * i + 1]);
+        }
+    }
+    double mtm[144], At[144], D[12], Vt[144];
+    for (int r = 0; r < 12; r++)
+        for (int c = 0; c < 12; c++) {
+            double s = 0;
+            for (int i = 0; i < 2 * n; i++) s += M[i * 12 + r] * M[i * 12 + c];
+            mtm[r * 12 + c] = s;
+        }
+    for (int j = 0; j < 12; j++) for (int i = 0; i < 12; i++) At[j * 12 + i] = mtm[i * 12 + j];
+    dp_jacobi_svd(At, 12, 12, D, Vt);
+    double v[4 * 12];                                      /* v[0] = smallest singular value's vector (ut + 12*11) ... */
+    for (int i = 0; i < 4; i++) memcpy(v + 12 * i, Vt + 12 * (11 - i), sizeof(double) * 12);
+    /* compute_L_6x10, compute_rho */
+    double l[60], rho[6];
+    {
+        double dv[4][6][3];
+        for (int i = 0; i < 4; i++) {
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; j++) {
+                for (int k = 0; k < 3; k++) dv[i][j][k] = v[12 * i + 3 * a + k] - v[12 * i + 3 * b + k];
+                b++;
+                if (b > 3) { a++; b = a + 1; }
+            }
+        }
+        for (int i = 0; i < 6; i++) {
+            double* row = l + 10 * i;
+            row[0] = dp_dot3(dv[0][i], dv[0][i]);
+            row[1] = 2.0 * dp_dot3(dv[0][i], dv[1][i]);
+            row[2] = dp_dot3(dv[1][i], dv[1][i]);
+            row[3] = 2.0 * dp_dot3(dv[0][i], dv[2][i]);
+            row[4] = 2.0 * dp_dot3(dv[1][i], dv[2][i]);
+            row[5] = dp_dot3(dv[2][i], dv[2][i]);
+            row[6] = 2.0 * dp_dot3(dv[0][i], dv[3][i]);
+            row[7] = 2.0 * dp_dot3(dv[1][i], dv[3][i]);
+            row[8] = 2.0 * dp_dot3(dv[2][i], dv[3][i]);
+            row[9] = dp_dot3(dv[3][i], dv[3][i]);
+        }
+        rho[0] = dp_dist2(cws[0], cws[1]); rho[1] = dp_dist2(cws[0], cws[2]); rho[2] = dp_dist2(cws[0], cws[3]);
+        rho[3] = dp_dist2(cws[1], cws[2]); rho[4] = dp_dist2(cws[1], cws[3]); rho[5] = dp_dist2(cws[2], cws[3]);
+    }
+    double betas[4][4], rep[4], Rs[4][9], ts[4][3];
+    for (int N = 1; N <= 3; N++) {
+        double* be = betas[N];
+        if (N == 1) {                                      /* find_betas_approx_1: [B11 B12 B13 B14] */
+            double L4[24], b4[4];
+            for (int i = 0; i < 6; i++) { L4[4 * i] = l[10 * i]; L4[4 * i + 1] = l[10 * i + 1]; L4[4 * i + 2] = l[10 * i + 3]; L4[4 * i + 3] = l[10 * i + 6]; }
+            dp_svd_solve(L4, 6, 4, rho, b4);
+            if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
+            else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
+        } else if (N == 2) {                               /* find_betas_approx_2: [B11 B12 B22] */
+            double L3[18], b3[3];
+            for (int i = 0; i < 6; i++) { L3[3 * i] = l[10 * i]; L3[3 * i + 1] = l[10 * i + 1]; L3[3 * i + 2] = l[10 * i + 2]; }
+            dp_svd_solve(L3, 6, 3, rho, b3);
+            if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+            else { be[0] = sqrt(b3[0]); be[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+            if (b3[1] < 0) be[0] = -be[0];
+            be[2] = 0.0; be[3] = 0.0;
+        } else {                                           /* find_betas_approx_3: [B11 B12 B22 B13 B23] */
+            double L5[30], b5[5];
+            for (int i = 0; i < 6; i++) for (int k = 0; k < 5; k++) L5[5 * i + k] = l[10 * i + k];
+            dp_svd_solve(L5, 6, 5, rho, b5);
+            if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+            else { be[0] = sqrt(b5[0]); be[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+            if (b5[1] < 0) be[0] = -be[0];
+            be[2] = b5[3] / be[0]; be[3] = 0.0;
+        }
+        for (int it = 0; it < 5; it++) {                   /* gauss_newton */
+            double A[24], b[6], x[4];
+            for (int i = 0; i < 6; i++) {
+                const double* rl = l + 10 * i; double* ra = A + 4 * i;
+                ra[0] = 2 * rl[0] * be[0] + rl[1] * be[1] + rl[3] * be[2] + rl[6] * be[3];
+                ra[1] = rl[1] * be[0] + 2 * rl[2] * be[1] + rl[4] * be[2] + rl[7] * be[3];
+                ra[2] = rl[3] * be[0] + rl[4] * be[1] + 2 * rl[5] * be[2] + rl[8] * be[3];
+                ra[3] = rl[6] * be[0] + rl[7] * be[1] + rl[8] * be[2] + 2 * rl[9] * be[3];
+                b[i] = rho[i] - (rl[0] * be[0] * be[0] + rl[1] * be[0] * be[1] + rl[2] * be[1] * be[1] + rl[3] * be[0] * be[2] +
+                                 rl[4] * be[1] * be[2] + rl[5] * be[2] * be[2] + rl[6] * be[0] * be[3] + rl[7] * be[1] * be[3] +
+                                 rl[8] * be[2] * be[3] + rl[9] * be[3] * be[3]);
+            }
+            dp_qr_solve_6x4(A, b, x);
+            for (int i = 0; i < 4; i++) be[i] += x[i];
+        }
+        rep[N] = dp_R_and_t(v, be, alphas, pws, us, n, K, Rs[N], ts[N]);
+    }
+    int N = 1;
+    if (rep[2] < rep[1]) N = 2;
+    if (rep[3] < rep[N]) N = 3;
+    memcpy(Rbest, Rs[N], sizeof(double) * 9); memcpy(tbest, ts[N], sizeof(double) * 3);
+}
+
+/* cv::Rodrigues, matrix -> vector (calibration.cpp cvRodrigues2) */
+__device__ static void dp_rodrigues_to_vec(const double* R, double* r)
+{
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
+        double t;
+        t = (R[0] + 1) * 0.5; rx = sqrt(t > 0 ? t : 0);
+        t = (R[4] + 1) * 0.5; ry = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+        t = (R[8] + 1) * 0.5; rz = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+        if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+        theta /= sqrt(rx * rx + ry * ry + rz * rz);
+        r[0] = rx * theta; r[1] = ry * theta; r[2] = rz * theta;
+        return;
+    }
+    double vth = 1 / (2 * s);
+    vth *= theta;
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+/* cv::Rodrigues, vector -> matrix */
+__device__ static void dp_rodrigues_to_mat(const double* r, double* R)
+{
+    double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (theta < DBL_EPSILON) { memset(R, 0, sizeof(double) * 9); R[0] = R[4] = R[8] = 1; return; }
+    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
+    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+
+__device__ static inline uint32_t dp_rng_next(uint64_t* state)
+{
+    *state = (uint64_t)(uint32_t)*state * 4164903690U + (uint32_t)(*state >> 32);
+    return (uint32_t)*state;
+}
+
+__device__ static int dp_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p < 0 ? 0 : p; p = p > 1 ? 1 : p;
+    ep = ep < 0 ? 0 : ep; ep = ep > 1 ? 1 : ep;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+
+/* solvePnP(SOLVEPNP_EPNP) on the float32 sample: undistortPoints gives float32 normalised coordinates, which
+ * epnp::init_points maps back to pixels in double */
+__device__ static void dp_minimal(const double* obj, const double* img, const int* idx, int n, dp_cam K, double* R, double* t)
+{
+    double pws[3 * DP_MAXN], us[2 * DP_MAXN];
+    const double ifx = 1. / K.fu, ify = 1. / K.fv;
+    for (int i = 0; i < n; i++) {
+        const int j = idx ? idx[i] : i;
+        pws[3 * i] = (double)(float)obj[3 * j]; pws[3 * i + 1] = (double)(float)obj[3 * j + 1]; pws[3 * i + 2] = (double)(float)obj[3 * j + 2];
+        const float xn = (float)(((double)(float)img[2 * j] - K.uc) * ifx), yn = (float)(((double)(float)img[2 * j + 1] - K.vc) * ify);
+        us[2 * i] = (double)xn * K.fu + K.uc; us[2 * i + 1] = (double)yn * K.fv + K.vc;
+    }
+    dp_epnp(pws, us, n, K, R, t);
+}
+
+/* 3 x 3 rotation from an so(3) increment w: exp([w]x) (Rodrigues' formula) */
+__device__ static void dp_exp_so3(const double* w, double* E)
+{
+    dp_rodrigues_to_mat(w, E);
+}
+
+__device__ static void dp_mat3mul(const double* a, const double* b, double* r)
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+/* cost and normal equations of the pixel reprojection error at (R, t), increment (w, dt): x = exp(w) R X + t + dt.
+ * Summation order (any order restates the same sums; this one is what a 256-thread workgroup does, so that the HIP
+ * kernel can reproduce it bit for bit): partial sums over the points k, k + 256, k + 512, ... for k = 0..255, then the
+ * 256 partials added in increasing k.  acc = [cost, Jte (6), upper triangle of JtJ (21)]. */
+#define DP_LANES 256
+__device__ static void dp_point_terms(const double* Xw, const double* uv, const double* R, const double* t, dp_cam K, int want_j, double* acc)
+{
+    const double a = dp_dot3(R, Xw), b = dp_dot3(R + 3, Xw), c = dp_dot3(R + 6, Xw);      /* R X */
+    const double x = a + t[0], y = b + t[1], z = c + t[2];
+    const double iz = 1. / z;
+    const double eu = K.fu * x * iz + K.uc - uv[0], ev = K.fv * y * iz + K.vc - uv[1];
+    acc[0] += eu * eu + ev * ev;
+    if (!want_j) return;
+    /* d(u)/d(x,y,z), then d(x,y,z)/d(w) = -[R X]x, d/d(dt) = I */
+    const double ux = K.fu * iz, uz = -K.fu * x * iz * iz, vy = K.fv * iz, vz = -K.fv * y * iz * iz;
+    double Ju[6], Jv[6];
+    Ju[0] = uz * b;            Ju[1] = ux * c - uz * a;   Ju[2] = -ux * b;          /* row (ux, 0, uz) * -[RX]x */
+    Jv[0] = -vy * c + vz * b;  Jv[1] = -vz * a;           Jv[2] = vy * a;           /* row (0, vy, vz) * -[RX]x */
+    Ju[3] = ux; Ju[4] = 0;  Ju[5] = uz;
+    Jv[3] = 0;  Jv[4] = vy; Jv[5] = vz;
+    int q = 7;
+    for (int r = 0; r < 6; r++) {
+        acc[1 + r] += Ju[r] * eu + Jv[r] * ev;
+        for (int s = r; s < 6; s++) acc[q++] += Ju[r] * Ju[s] + Jv[r] * Jv[s];
+    }
+}
+
+/* symmetric positive definite 6 x 6 solve by Cholesky; returns 0 if not positive definite */
+__device__ static int dp_chol6(const double* A, const double* b, double* x)
+{
+    double L[36];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) { if (s <= 0) return 0; L[i * 6 + i] = sqrt(s); }
+            else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k]; x[i] = s / L[i * 6 + i]; }
+    return 1;
+}
+
+
+// ------------------------------------------------------------------ the kernel
+// inliers of one hypothesis counted by one wavefront: projectPoints in double, float32 output, squared float32 distance
+__device__ static int dp_count_inliers(const double* obj, const double* img, int n, const double* R, const double* t, dp_cam K,
+                                       float thr, int lane, int stride, uint8_t* mask_out)
+{
+    int good = 0;
+    for (int base = 0; base < n; base += stride) {
+        const int i = base + lane;
+        bool f = false;
+        if (i < n) {
+            const double X = (double)(float)obj[3 * i], Y = (double)(float)obj[3 * i + 1], Z = (double)(float)obj[3 * i + 2];
+            double x = R[0] * X + R[1] * Y + R[2] * Z + t[0], y = R[3] * X + R[4] * Y + R[5] * Z + t[1], z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+            z = z ? 1. / z : 1;
+            x *= z; y *= z;
+            const float pu = (float)(x * K.fu + K.uc), pv = (float)(y * K.fv + K.vc);
+            const float du = (float)img[2 * i] - pu, dv = (float)img[2 * i + 1] - pv;
+            f = du * du + dv * dv <= thr;
+            if (mask_out) mask_out[i] = f ? 1 : 0;
+        }
+        good += __popcll(__ballot(f));
+    }
+    return good;
+}
+
+#define PNP_STREAM 448
+struct PnpShared {
+    double Rt[64][12];                  // hypotheses of the round
+    double red[DP_LANES][28];           // per-thread partial sums of the normal equations
+    double cand[12];                    // candidate (R, t) of the Levenberg-Marquardt step
+    uint32_t stream[PNP_STREAM];
+    int sub[64][5];
+    int cnt[2][4];
+    int used, ctrl;
+};
+
+// sum of the 256 partials in thread order (the oracle's order); called by thread 0 after a barrier
+__device__ static void dp_reduce(const PnpShared& sh, double* tot)
+{
+    for (int q = 0; q < 28; q++) tot[q] = 0;
+    for (int k = 0; k < DP_LANES; k++)
+        for (int q = 0; q < 28; q++) tot[q] += sh.red[k][q];
+}
+
+__global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const double* img_all, const int* offsets, const double* Kd,
+                                                    int iterations, double reproj_err, double confidence, uint64_t seed,
+                                                    const uint32_t* rng_tab, int rng_n,
+                                                    double* rvec_out, double* tvec_out, uint8_t* mask_all, int* ninl_out, int* status_out)
+{
+    __shared__ PnpShared sh;
+    const int pb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o0 = offsets[pb], n = offsets[pb + 1] - o0;
+    const double* obj = obj_all + (size_t)o0 * 3; const double* img = img_all + (size_t)o0 * 2;
+    uint8_t* mask = mask_all + o0;
+    const dp_cam K = {Kd[0], Kd[4], Kd[2], Kd[5]};
+    if (n < 4 || n == 4 || !(confidence > 0 && confidence < 1)) {
+        if (tid == 0) { status_out[pb] = n < 4 ? VO_ERR_TOO_FEW : n == 4 ? VO_ERR_UNSUPPORTED : VO_ERR_INVALID; ninl_out[pb] = 0; }
+        for (int i = tid; i < n; i += 256) mask[i] = 0;
+        return;
+    }
+    if (n == 5) {                       // model_points == npoints: one EPnP, every point an inlier
+        if (tid == 0) {
+            double R[9], t[3], r[3];
+            dp_minimal(obj, img, nullptr, 5, K, R, t);
+            dp_rodrigues_to_vec(R, r);
+            for (int k = 0; k < 3; k++) { rvec_out[3 * pb + k] = r[k]; tvec_out[3 * pb + k] = t[k]; }
+            status_out[pb] = VO_OK; ninl_out[pb] = 5;
+        }
+        if (tid < 5) mask[tid] = 1;
+        return;
+    }
+    const float thr = (float)(reproj_err * reproj_err);
+    // every thread carries the same copy of the sequential state
+    int niters = iterations > 1 ? iterations : 1, max_good = 0, pos = 0;
+    double bestRt[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) bestRt[k] = 0;
+    for (int r0 = 0; r0 < niters; r0 += 64) {
+        const int nh = min(64, niters - r0);
+        for (int i = tid; i < PNP_STREAM; i += 256) sh.stream[i] = pos + i < rng_n ? rng_tab[pos + i] % (uint32_t)n : 0u;
+        __syncthreads();
+        if (tid == 0) {
+            int used = 0;
+            for (int h = 0; h < nh; h++) {
+                int idx[5];
+                for (int i = 0; i < 5; i++) {
+                    int v; bool dup;
+                    do {
+                        if (used < PNP_STREAM && pos + used < rng_n) v = (int)sh.stream[used];
+                        else {                              // beyond the staged window / table: recompute directly
+                            uint64_t st = seed ? seed : 0xffffffffULL;
+                            uint32_t x = 0;
+                            if (pos + used < rng_n) x = rng_tab[pos + used];
+                            else { for (int q = 0; q <= pos + used; q++) x = dp_rng_next(&st); }
+                            v = (int)(x % (uint32_t)n);
+                        }
+                        used++;
+                        dup = false;
+                        for (int k = 0; k < i; k++) dup |= idx[k] == v;
+                    } while (dup);
+                    idx[i] = v;
+                    sh.sub[h][i] = v;
+                }
+            }
+            sh.used = used;
+        }
+        __syncthreads();
+        pos += sh.used;
+        if (wave == 0 && lane < nh) {                       // one EPnP per lane
+            int idx[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) idx[i] = sh.sub[lane][i];
+            double R[9], t[3];
+            dp_minimal(obj, img, idx, 5, K, R, t);
+#pragma unroll
+            for (int k = 0; k < 9; k++) sh.Rt[lane][k] = R[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) sh.Rt[lane][9 + k] = t[k];
+        }
+        __syncthreads();
+        bool done = false;
+        for (int b = 0; b * 4 < nh && !done; b++) {         // four hypotheses at a time, consumed in order
+            const int h = b * 4 + wave;
+            if (h < nh) {
+                double Rt[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) Rt[k] = sh.Rt[h][k];
+                const int good = dp_count_inliers(obj, img, n, Rt, Rt + 9, K, thr, lane, 64, nullptr);
+                if (lane == 0) sh.cnt[b & 1][wave] = good;
+            }
+            __syncthreads();
+            for (int w = 0; w < 4; w++) {
+                const int h2 = b * 4 + w;
+                if (h2 >= nh) break;
+                if (r0 + h2 >= niters) { done = true; break; }
+                const int good = sh.cnt[b & 1][w];
+                if (good > max(max_good, 4)) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) bestRt[k] = sh.Rt[h2][k];
+                    max_good = good;
+                    niters = dp_update_num_iters(confidence, (double)(n - good) / n, 5, niters);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (max_good <= 0) {
+        for (int i = tid; i < n; i += 256) mask[i] = 0;
+        if (tid == 0) { status_out[pb] = VO_ERR_NO_MODEL; ninl_out[pb] = 0; }
+        return;
+    }
+    dp_count_inliers(obj, img, n, bestRt, bestRt + 9, K, thr, tid, 256, mask);
+    __syncthreads();                                        // the mask bytes are read back below (global, same workgroup)
+
+    // solvePnP(SOLVEPNP_ITERATIVE) on the inliers: Levenberg-Marquardt on the pixel reprojection error
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = bestRt[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = bestRt[9 + k];
+    auto partials = [&](const double* Rc, const double* tc, int want_j) {
+        double acc[28];
+#pragma unroll
+        for (int q = 0; q < 28; q++) acc[q] = 0;
+        for (int i = tid; i < n; i += DP_LANES)
+            if (mask[i]) dp_point_terms(obj + 3 * i, img + 2 * i, Rc, tc, K, want_j, acc);
+        __syncthreads();                                    // the previous reduction has been read
+#pragma unroll
+        for (int q = 0; q < 28; q++) sh.red[tid][q] = acc[q];
+        __syncthreads();
+    };
+    double lambda = 1e-3, JtJ[36], Jte[6], cost = 0, tot[28];
+    partials(R, t, 1);
+    if (tid == 0) {
+        dp_reduce(sh, tot);
+        cost = tot[0];
+        int q = 7;
+        for (int r = 0; r < 6; r++) { Jte[r] = tot[1 + r]; for (int s2 = r; s2 < 6; s2++) { JtJ[r * 6 + s2] = tot[q]; JtJ[s2 * 6 + r] = tot[q]; q++; } }
+    }
+    for (int it = 0; it < 100; it++) {
+        // thread 0 proposes a step (ctrl: 0 = evaluate the candidate, 1 = retry with more damping, 2 = stop)
+        double d[6];
+        if (tid == 0) {
+            double A[36], rhs[6];
+            for (int k = 0; k < 36; k++) A[k] = JtJ[k];
+            for (int k = 0; k < 6; k++) { A[k * 6 + k] *= 1. + lambda; rhs[k] = -Jte[k]; }
+            if (!dp_chol6(A, rhs, d)) { lambda *= 10; sh.ctrl = lambda > 1e12 ? 2 : 1; }
+            else {
+                double E[9], Rn[9];
+                dp_exp_so3(d, E);
+                dp_mat3mul(E, R, Rn);
+                for (int k = 0; k < 9; k++) sh.cand[k] = Rn[k];
+                for (int k = 0; k < 3; k++) sh.cand[9 + k] = t[k] + d[3 + k];
+                sh.ctrl = 0;
+            }
+        }
+        __syncthreads();
+        const int ctrl = sh.ctrl;
+        if (ctrl == 2) break;
+        if (ctrl == 1) { __syncthreads(); continue; }
+        double Rn[9], tn[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rn[k] = sh.cand[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) tn[k] = sh.cand[9 + k];
+        partials(Rn, tn, 0);
+        if (tid == 0) {
+            dp_reduce(sh, tot);
+            sh.ctrl = tot[0] < cost ? 3 : 4;                // 3 = accepted
+        }
+        __syncthreads();
+        const bool accepted = sh.ctrl == 3;
+        __syncthreads();                                    // everyone has read the verdict before thread 0 reuses ctrl
+        if (accepted) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = Rn[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) t[k] = tn[k];
+            partials(R, t, 1);
+            if (tid == 0) {
+                const double step = fabs(d[0]) + fabs(d[1]) + fabs(d[2]) + fabs(d[3]) + fabs(d[4]) + fabs(d[5]);
+                dp_reduce(sh, tot);
+                cost = tot[0];
+                int q = 7;
+                for (int r = 0; r < 6; r++) { Jte[r] = tot[1 + r]; for (int s2 = r; s2 < 6; s2++) { JtJ[r * 6 + s2] = tot[q]; JtJ[s2 * 6 + r] = tot[q]; q++; } }
+                lambda = lambda > 1e-12 ? lambda * 0.1 : lambda;
+                sh.ctrl = step < 1e-13 * (1. + fabs(t[0]) + fabs(t[1]) + fabs(t[2])) ? 2 : 0;
+            }
+        } else if (tid == 0) {
+            lambda *= 10;
+            sh.ctrl = lambda > 1e12 ? 2 : 0;
+        }
+        __syncthreads();
+        const int stop = sh.ctrl == 2;
+        __syncthreads();
+        if (stop) break;
+    }
+    if (tid == 0) {
+        double r[3];
+        dp_rodrigues_to_vec(R, r);
+        for (int k = 0; k < 3; k++) { rvec_out[3 * pb + k] = r[k]; tvec_out[3 * pb + k] = t[k]; }
+        status_out[pb] = VO_OK; ninl_out[pb] = max_good;
+    }
+}
+
+void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, const int* offsets, int B, const double* Kd,
+                       int iterations, double reproj_err, double confidence, uint64_t seed, const uint32_t* rng_tab, int rng_n,
+                       double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status)
+{
+    if (B <= 0) return;
+    hipLaunchKernelGGL(k_pnp_ransac, dim3(B), dim3(256), 0, s, obj, img, offsets, Kd, iterations, reproj_err, confidence, seed,
+                       rng_tab, rng_n, rvec, tvec, mask, ninl, status);
+}
+
+// cv2.Rodrigues for the Python shim (a 3-vector or a 3x3 matrix in, the other out): one thread
+__global__ void k_rodrigues(const double* in, int in_is_matrix, double* out)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    double a[9], b[9];
+    for (int k = 0; k < (in_is_matrix ? 9 : 3); k++) a[k] = in[k];
+    if (in_is_matrix) dp_rodrigues_to_vec(a, b); else dp_rodrigues_to_mat(a, b);
+    for (int k = 0; k < (in_is_matrix ? 3 : 9); k++) out[k] = b[k];
+}
+
+void launch_rodrigues(hipStream_t s, const double* in, int in_is_matrix, double* out)
+{
+    hipLaunchKernelGGL(k_rodrigues, dim3(1), dim3(64), 0, s, in, in_is_matrix, out);
+}

@@ -1045,6 +1045,84 @@ extern "C" int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam
     return VO_OK;
 }
 
+// ------------------------------------------------------------------ "next" row: PnP-RANSAC localisation
+extern "C" int vo_solve_pnp_ransac_batch(vo_ctx* ctx, const double* obj, const double* img, const int32_t* offsets, int B,
+                                         const double* K, int iterations, double reproj_err, double confidence, uint64_t seed,
+                                         double* rvec, double* tvec, uint8_t* mask, int32_t* n_inl, int32_t* status)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (B < 0 || !offsets || !K || (B > 0 && (!rvec || !tvec || !n_inl || !status))) FAIL(VO_ERR_INVALID, "bad arguments");
+    if (B == 0) return VO_OK;
+    for (int b = 0; b < B; b++) if (offsets[b + 1] < offsets[b]) FAIL(VO_ERR_INVALID, "offsets must not decrease");
+    const int total = offsets[B] - offsets[0];
+    if (total > 0 && (!obj || !img || !mask)) FAIL(VO_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_rng(ctx, seed); if (rc) return rc;
+    // doubles: obj 3T, img 2T, K 9, rvec 3B, tvec 3B; then ints: offsets B+1, ninl B, status B; then mask T bytes
+    const size_t nd = (size_t)5 * total + 9 + (size_t)6 * B, ni = (size_t)3 * B + 1;
+    rc = ensure_raw_d(ctx, nd + (ni + 1) / 2 + (size_t)(total + 7) / 8 + 8); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    double* dobj = ctx->raw_d; double* dimg = dobj + (size_t)3 * total; double* dK = dimg + (size_t)2 * total;
+    double* drv = dK + 9; double* dtv = drv + (size_t)3 * B;
+    int* doff = (int*)(dtv + (size_t)3 * B); int* dninl = doff + B + 1; int* dst = dninl + B;
+    uint8_t* dmask = (uint8_t*)(dst + B + ((3 * B + 1) & 1));
+    std::vector<int> off(B + 1);
+    for (int b = 0; b <= B; b++) off[b] = offsets[b] - offsets[0];
+    if (total > 0) {
+        HIPCHK(hipMemcpyAsync(dobj, obj + (size_t)3 * offsets[0], (size_t)3 * total * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dimg, img + (size_t)2 * offsets[0], (size_t)2 * total * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(doff, off.data(), (size_t)(B + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                                 // `off` is a stack vector
+    { StageTimer t(ctx, ST_MISC); launch_pnp_ransac(s, dobj, dimg, doff, B, dK, iterations, reproj_err, confidence, seed, ctx->rng_tab, RNG_TAB_N,
+                                                   drv, dtv, dmask, dninl, dst); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rvec, drv, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(tvec, dtv, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(n_inl, dninl, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(status, dst, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (total > 0) HIPCHK(hipMemcpyAsync(mask + offsets[0], dmask, (size_t)total, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+extern "C" int vo_solve_pnp_ransac(vo_ctx* ctx, const double* obj, const double* img, int n, const double* K, int iterations,
+                                   double reproj_err, double confidence, uint64_t seed, double* rvec, double* tvec,
+                                   uint8_t* mask, int32_t* n_inl)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (n < 0 || !rvec || !tvec || !n_inl || (n > 0 && (!obj || !img || !mask))) FAIL(VO_ERR_INVALID, "bad arguments");
+    const int32_t offsets[2] = {0, n};
+    int32_t status = 0;
+    uint8_t dummy = 0;
+    *n_inl = 0;
+    int rc = vo_solve_pnp_ransac_batch(ctx, obj, img, offsets, 1, K, iterations, reproj_err, confidence, seed, rvec, tvec,
+                                       n > 0 ? mask : &dummy, n_inl, &status);
+    if (rc) return rc;
+    if (status == VO_ERR_TOO_FEW) FAIL(VO_ERR_TOO_FEW, "solvePnPRansac needs at least 4 correspondences, got %d", n);
+    if (status == VO_ERR_UNSUPPORTED) FAIL(VO_ERR_UNSUPPORTED, "solvePnPRansac with exactly 4 points (P3P) is not built");
+    if (status == VO_ERR_NO_MODEL) FAIL(VO_ERR_NO_MODEL, "no pose with more than 4 inliers");
+    if (status < 0) FAIL(status, "solvePnPRansac failed");
+    return VO_OK;
+}
+
+extern "C" int vo_rodrigues(vo_ctx* ctx, const double* in, int in_is_matrix, double* out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!in || !out) FAIL(VO_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_raw_d(ctx, 32); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemcpyAsync(ctx->raw_d, in, (in_is_matrix ? 9 : 3) * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_rodrigues(s, ctx->raw_d, in_is_matrix, ctx->raw_d + 16);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, ctx->raw_d + 16, (in_is_matrix ? 3 : 9) * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return VO_OK;
+}
+
 // ------------------------------------------------------------------ "next" row: frame ingest (cv2.resize INTER_LINEAR)
 // resize.cpp resize(): fx = (float)((dx + 0.5) * scale_x - 0.5), scale_x = 1. / ((double)dw / sw); columns force
 // (offset, weight) at the borders, rows keep the weight and clamp the row index; coefficients are

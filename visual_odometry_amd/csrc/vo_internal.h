@@ -124,6 +124,10 @@ void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat
 void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, int cn, int sstride, int64_t sframe,
                           uint8_t* dst, int dw, int dh, int dstride, int64_t dframe,
                           const int* xofs, const void* xa, const int* yofs, const void* yb, int area2, int F);
+void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, const int* offsets, int B, const double* Kd,
+                       int iterations, double reproj_err, double confidence, uint64_t seed, const uint32_t* rng_tab, int rng_n,
+                       double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status);
+void launch_rodrigues(hipStream_t s, const double* in, int in_is_matrix, double* out);
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F);
 void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x);
 

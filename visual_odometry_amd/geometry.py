@@ -85,3 +85,67 @@ def five_point(x1, x2, ctx=None):
     ctx = ctx or _lib.default_context()
     ctx.check(ctx.lib.vo_stage_five_point(ctx.handle, x1.ctypes.data, x2.ctypes.data, E.ctypes.data, C.addressof(n)))
     return E[:n.value].reshape(-1, 3, 3).copy()
+
+
+SOLVEPNP_ITERATIVE = 0
+
+
+def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, useExtrinsicGuess=False, iterationsCount=100,
+                   reprojectionError=8.0, confidence=0.99, flags=SOLVEPNP_ITERATIVE, seed=OPENCV_RNG_SEED, ctx=None):
+    """cv2.solvePnPRansac as the reference calls it (src/visual_slam.py:231-235: positional objectPoints, imagePoints,
+    cameraMatrix, zeros(4)) -> (retval, rvec 3x1, tvec 3x1, inliers n_inl x 1 int32 indices or None).
+    Only the reference's configuration is built: zero distortion, no extrinsic guess, SOLVEPNP_ITERATIVE."""
+    if distCoeffs is not None and np.any(np.asarray(distCoeffs, np.float64) != 0):
+        raise NotImplementedError("only zero distortion coefficients are built (the reference passes np.zeros(4))")
+    if useExtrinsicGuess or flags != SOLVEPNP_ITERATIVE:
+        raise NotImplementedError("only cv2.solvePnPRansac's defaults (no extrinsic guess, SOLVEPNP_ITERATIVE) are built")
+    obj = np.ascontiguousarray(np.asarray(objectPoints, np.float64).reshape(-1, 3))
+    img = np.ascontiguousarray(np.asarray(imagePoints, np.float64).reshape(-1, 2))
+    if len(obj) != len(img):
+        raise ValueError("objectPoints and imagePoints differ in length")
+    K = np.ascontiguousarray(cameraMatrix, np.float64).reshape(3, 3)
+    n = len(obj)
+    rvec = np.zeros((3, 1)); tvec = np.zeros((3, 1)); mask = np.zeros(max(n, 1), np.uint8); ninl = C.c_int32(0)
+    ctx = ctx or _lib.default_context()
+    rc = ctx.lib.vo_solve_pnp_ransac(ctx.handle, obj.ctypes.data, img.ctypes.data, n, K.ctypes.data, int(iterationsCount),
+                                     float(reprojectionError), float(confidence), int(seed), rvec.ctypes.data, tvec.ctypes.data,
+                                     mask.ctypes.data, C.addressof(ninl))
+    if rc == _lib.VO_ERR_NO_MODEL:
+        return False, rvec, tvec, None                     # cv2: retval False
+    ctx.check(rc)                                          # n < 4 raises, as cv2's assertion does
+    return True, rvec, tvec, np.nonzero(mask[:n])[0].astype(np.int32).reshape(-1, 1)
+
+
+def solve_pnp_ransac_batch(objectPoints, imagePoints, offsets, cameraMatrix, iterationsCount=100, reprojectionError=8.0,
+                           confidence=0.99, seed=OPENCV_RNG_SEED, ctx=None):
+    """B independent solvePnPRansac problems in one launch; problem b owns rows offsets[b]:offsets[b+1].
+    Returns (status [B], rvec [B, 3], tvec [B, 3], mask [total] uint8, n_inliers [B])."""
+    obj = np.ascontiguousarray(np.asarray(objectPoints, np.float64).reshape(-1, 3))
+    img = np.ascontiguousarray(np.asarray(imagePoints, np.float64).reshape(-1, 2))
+    off = np.ascontiguousarray(offsets, np.int32)
+    B = len(off) - 1
+    K = np.ascontiguousarray(cameraMatrix, np.float64).reshape(3, 3)
+    rvec = np.zeros((B, 3)); tvec = np.zeros((B, 3)); mask = np.zeros(max(len(obj), 1), np.uint8)
+    ninl = np.zeros(B, np.int32); status = np.zeros(B, np.int32)
+    ctx = ctx or _lib.default_context()
+    ctx.check(ctx.lib.vo_solve_pnp_ransac_batch(ctx.handle, obj.ctypes.data, img.ctypes.data, off.ctypes.data, B, K.ctypes.data,
+                                                int(iterationsCount), float(reprojectionError), float(confidence), int(seed),
+                                                rvec.ctypes.data, tvec.ctypes.data, mask.ctypes.data, ninl.ctypes.data,
+                                                status.ctypes.data))
+    return status, rvec, tvec, mask[:len(obj)], ninl
+
+
+def Rodrigues(src, ctx=None):
+    """cv2.Rodrigues(src) -> (dst, None): 3-vector (3, 3x1 or 1x3) -> 3x3 matrix, 3x3 matrix -> 3x1 vector
+    (src/visual_slam.py:243; the Jacobian cv2 also returns is not computed)."""
+    a = np.ascontiguousarray(src, np.float64)
+    ctx = ctx or _lib.default_context()
+    if a.size == 9:
+        out = np.zeros((3, 1))
+        ctx.check(ctx.lib.vo_rodrigues(ctx.handle, a.ctypes.data, 1, out.ctypes.data))
+    elif a.size == 3:
+        out = np.zeros((3, 3))
+        ctx.check(ctx.lib.vo_rodrigues(ctx.handle, a.ctypes.data, 0, out.ctypes.data))
+    else:
+        raise ValueError("Rodrigues takes a 3-vector or a 3x3 matrix")
+    return out, None
