@@ -77,3 +77,28 @@ def test_rodrigues_and_error_paths(oracle, ctx):
     assert ok in (True, False)                                          # garbage correspondences: a verdict, no crash
     with pytest.raises(NotImplementedError):
         geometry.solvePnPRansac(X, uv, K, np.array([0.1, 0, 0, 0]))
+
+
+def test_degenerate_configurations_terminate_and_agree(oracle, ctx):
+    """Coincident, collinear and coplanar object points, points behind the camera: no hang, and the same verdict and
+    inlier set as the oracle (NaN hypotheses simply collect no inliers)."""
+    from visual_odometry_amd import geometry
+    rng = np.random.default_rng(4)
+    uv = rng.uniform(0, 600, (60, 2))
+    same = np.tile(np.array([[0.5, -0.2, 4.0]]), (60, 1))
+    line = np.outer(np.linspace(-1, 1, 60), [1.0, 0.5, 0.2]) + [0, 0, 5]
+    X, uvp, R, t, _ = problem(31, 60, 0.2)
+    plane = X.copy(); plane[:, 2] = 0.0
+    Xc = plane @ R.T + t
+    uv_plane = ((Xc / Xc[:, 2:]) @ K.T)[:, :2]
+    behind = X.copy(); behind[:, 2] -= 20.0
+    for obj, img in ((same, uv), (line, uv), (plane, uv_plane), (behind, uvp)):
+        rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(obj, img, K)
+        st, rvec, tvec, m, n_in = geometry.solve_pnp_ransac_batch(obj, img, np.array([0, len(obj)], np.int32), K)
+        assert st[0] == rc
+        if rc == 0:
+            assert n_in[0] == ninl and np.array_equal(m, mask)
+            ok = np.isfinite(rv).all() and np.isfinite(tv).all()
+            assert np.isfinite(rvec[0]).all() == ok
+            if ok:
+                assert np.abs(rvec[0] - rv).max() < 1e-6 and np.abs(tvec[0] - tv).max() < 1e-6
