@@ -455,14 +455,23 @@ __device__ __noinline__ int five_point_solve(const double* x1, const double* x2,
     if (n == 10) dk_iterate<true>(c, 10, rr, ri);
     else dk_iterate<false>(c, n, rr, ri);
 
+    // real roots, in ascending index (OpenCV's order).  Lanes hold their real roots at different indices, so instead
+    // of ten wave-wide passes each lane walks the set bits of its own mask: the wave makes max-popcount passes.
+    uint32_t real_mask = 0;
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+        double zi = ri[q];
+        if (fabs(zi) < 1e-100) zi = 0;
+        if (q < n && !(fabs(zi) > 1e-10)) real_mask |= 1u << q;
+    }
     int count = 0;
 #pragma unroll 1
-    for (int i = 0; i < n; i++) {
-        double zr = 0, zi = 0;
+    while (real_mask) {
+        const int i = __ffs((int)real_mask) - 1;
+        real_mask &= real_mask - 1;
+        double zr = 0;
 #pragma unroll
-        for (int q = 0; q < 10; q++) if (q == i) { zr = rr[q]; zi = ri[q]; }
-        if (fabs(zi) < 1e-100) zi = 0;
-        if (fabs(zi) > 1e-10) continue;
+        for (int q = 0; q < 10; q++) if (q == i) zr = rr[q];
         double z1 = zr, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[9], xy1[3];
 #pragma unroll
