@@ -16,7 +16,7 @@ opts = fes[0].make_opts(want_points=True)
 ref = None; bad = 0
 inflight = [None, None]
 def key(r): return np.concatenate([r[k].astype(np.float64).ravel() for k in ("status","n_match","n_inl","n_good","ransac_iters","R","t")])
-for it in range(12):
+for it in range(int(os.environ.get("VO_DET_ITERS", "12"))):
     k = it % 2
     f = fes[k]
     if inflight[k] is not None:
