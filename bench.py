@@ -97,8 +97,8 @@ def cpu_baseline(frames, K, nfeatures, nlevels, match_mode, ratio, budget_s=12.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--pairs-per-step", type=int, default=256)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
