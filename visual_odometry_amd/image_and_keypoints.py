@@ -27,8 +27,8 @@ class ImageAndKeypoints:
         width = int(image.shape[1] * self.scale_factor)
         height = int(image.shape[0] * self.scale_factor)
         if (height, width) != tuple(image.shape[:2]):
-            raise NotImplementedError("rescaling (cv2.INTER_AREA) belongs to frame ingest, which is out of scope; "
-                                      "the reference runs with scale_factor = 1")
+            raise NotImplementedError("cv2.INTER_AREA rescaling is not built (visual_odometry_amd.ingest.resize offers "
+                                      "cv2.resize's default INTER_LINEAR); the reference runs with scale_factor = 1")
         self.image = np.array(image, copy=True)                       # INTER_AREA at scale 1 is a copy
 
     def detect_keypoints(self):
