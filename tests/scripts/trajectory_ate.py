@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O  # noqa: E402
 from visual_odometry_amd import synth  # noqa: E402
 from visual_odometry_amd.frontend import FrontEnd, chain_poses  # noqa: E402

@@ -1,7 +1,7 @@
 """CPU: the oracle against the committed vectors and the only numeric known-answer the reference holds.
 
 PARITY UNPINNED (see oracle/voo.h): tests/golden/*.npz were produced by the oracle itself
-(tools/make_golden.py); they freeze its behaviour, they do not prove agreement with cv2."""
+(tests/scripts/make_golden.py); they freeze its behaviour, they do not prove agreement with cv2."""
 import os
 
 import numpy as np
