@@ -405,10 +405,19 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     }
     if (gc >= FT_GROUPS_X) colmask = 0;
     const uint32_t* colp = (const uint32_t*)s_px + 3 + gc + hp * (FT_PXW / 4);   // dword of the group in pixel-tile row hp
+    uint32_t rowmask = 0xffffffffu;                    // bit st: this lane's row of step st can hold a corner
+    if (edge_tile) {
+        rowmask = 0;
+#pragma unroll
+        for (int st = 0; st < FT_SCH / 2; st++) {
+            const int gy = y0 - 1 + 2 * st + hp;
+            rowmask |= (gy >= 3 && gy < lv.h - 3) ? 1u << st : 0u;
+        }
+    }
+    const uint32_t entry0 = ((uint32_t)hp << 10) | ((uint32_t)gc << 4);
     int gn = 0;                                        // wave-uniform group-queue length
 #pragma unroll
     for (int st = 0; st < FT_SCH / 2; st++) {
-        const int gr = 2 * st + hp, gy = y0 - 1 + gr;  // score-tile row of this lane
         const uint32_t* rowp = colp + (2 * st + 3) * (FT_PXW / 4);
         const uint32_t c = rowp[0], wl = rowp[-1], wr = rowp[1];
         const uint32_t up = rowp[-3 * (FT_PXW / 4)], dn = rowp[3 * (FT_PXW / 4)];
@@ -429,12 +438,11 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         const uint32_t dk_o = pk_sub16(pk_max16(pk_min16(r0_o, r8_o), pk_min16(r4_o, r12_o)), lo_o);
         // candidate bits: pixel 0 / 2 = bits 15 / 31 of the even word, pixel 1 / 3 of the odd word
         const uint32_t tt = (((br_e | dk_e) & 0x80008000u) >> 15) | (((br_o | dk_o) & 0x80008000u) >> 14);
-        uint32_t bits = (tt | (tt >> 14)) & colmask;
-        if (edge_tile && !(gy >= 3 && gy < lv.h - 3)) bits = 0;
+        uint32_t bits = (tt | (tt >> 14)) & colmask & (uint32_t)((int32_t)(rowmask << (31 - st)) >> 31);
         const unsigned long long m = __ballot(bits != 0);
         if (m) {                                                             // wave-uniform
             const int slot = gn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (bits) s_g[slot] = (uint16_t)((gr << 10) | (gc << 4) | bits);
+            if (bits) s_g[slot] = (uint16_t)(entry0 + ((uint32_t)(2 * st) << 10) + bits);       // (row 2 st + hp) << 10 | gc << 4 | bits
             gn += (int)__popcll(m);
         }
     }
