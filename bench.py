@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--contexts", type=int, default=2, help="contexts (streams) per GPU alternating over the chunks")
     ap.add_argument("--chain-detect", type=int, default=1,
                     help="1: a context's detection starts after the previous context's detection (software pipeline)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the trajectory gather even with one rank (exercises RCCL on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the multi-process path on a box with fewer GPUs than ranks (all ranks share GPU 0)")
     args = ap.parse_args()
@@ -131,7 +133,8 @@ def main():
         args.gpus = world
     dist = torch = None
     device = local_rank
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch
         import torch.distributed as dist
         if args.dist_backend == "nccl":
@@ -140,7 +143,7 @@ def main():
         else:
             device = 0
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    on_gpu = world > 1 and args.dist_backend == "nccl"
+    on_gpu = use_dist and args.dist_backend == "nccl"
 
     from visual_odometry_amd import synth
     from visual_odometry_amd.frontend import FrontEnd, MATCH_CROSSCHECK, MATCH_RATIO, chain_poses
@@ -175,20 +178,32 @@ def main():
     fe = fes[0]
     opts = fe.make_opts(match_mode=match_mode, ratio=args.ratio, want_points=True)
 
-    rec = np.zeros((C, 16), np.float64)                   # per pair: R (9) t (3) n_kp1 n_match n_inl n_good
+    # per pair: R (9) t (3) n_kp1 n_match n_inl n_good.  Page-locked staging + preallocated device tensors: the gather
+    # costs one asynchronous 32 KB copy and one collective per step, nothing that waits for the GPU.
     gathered = None
+    if use_dist:
+        rec_t = torch.zeros((C, 16), dtype=torch.float64, pin_memory=on_gpu)
+        rec = rec_t.numpy()
+        mine_d = torch.empty((C, 16), dtype=torch.float64, device="cuda") if on_gpu else None
+        out_d = torch.empty((world * C, 16), dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        copied = torch.cuda.Event() if on_gpu else None   # the staging buffer is free again once this has fired
     in_flight = [None] * n_ctx
     counter = [0]
 
     def consume(res):
         nonlocal gathered
-        if world > 1:                                     # trajectory gather over RCCL / xGMI: 128 B per pair
+        if use_dist:                                      # trajectory gather over RCCL / xGMI: 128 B per pair
+            if on_gpu and gathered is not None:
+                copied.synchronize()
             rec[:, :9] = res["R"]; rec[:, 9:12] = res["t"]
             rec[:, 12] = res["n_kp1"]; rec[:, 13] = res["n_match"]; rec[:, 14] = res["n_inl"]; rec[:, 15] = res["n_good"]
-            mine = torch.from_numpy(rec).cuda() if on_gpu else torch.from_numpy(rec)
-            out = torch.empty((world * C, 16), dtype=torch.float64, device=mine.device)
-            dist.all_gather_into_tensor(out, mine)
-            gathered = out
+            if on_gpu:
+                mine_d.copy_(rec_t, non_blocking=True)
+                copied.record()
+                dist.all_gather_into_tensor(out_d, mine_d)
+            else:
+                dist.all_gather_into_tensor(out_d, rec_t)
+            gathered = out_d
 
     staged = [None] * n_ctx                               # page-locked copies of the chunk (streamed-from-host pass)
 
@@ -217,7 +232,7 @@ def main():
         return last
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             if on_gpu:
                 torch.cuda.synchronize()
@@ -232,7 +247,7 @@ def main():
     res = drain()                                         # every enqueued chunk finished, results on the host
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -328,7 +343,7 @@ def main():
             traj = chain_poses(gathered[:, :9].reshape(-1, 3, 3).cpu().numpy(), gathered[:, 9:12].cpu().numpy())
             line["config"]["trajectory_poses_gathered"] = int(traj.shape[0])
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

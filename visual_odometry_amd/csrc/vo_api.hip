@@ -11,7 +11,7 @@
 
 struct vo_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // non-blocking: no implicit ordering with the NULL stream (PyTorch / RCCL use it)
     char err[512] = {0};
 
     bool configured = false;
@@ -237,7 +237,7 @@ extern "C" int vo_create(int device_id, vo_ctx** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return VO_ERR_HIP;
     vo_ctx* ctx = new vo_ctx();
     ctx->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         dmalloc(&ctx->dK, 16) != hipSuccess) {
         delete ctx;
         return VO_ERR_HIP;
@@ -350,6 +350,7 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     HIPCHK(hipMemset(ff.flags, 0, F * sizeof(int)));
     HIPCHK(alloc_pairbuf(ctx->pb, max_pairs, g.kp_cap, false));
     ctx->pb_pairs = max_pairs; ctx->pb_cap = g.kp_cap;
+    HIPCHK(hipDeviceSynchronize());                         // the initialising memsets ran on the NULL stream
     ctx->configured = true;
     return VO_OK;
 }
@@ -537,6 +538,7 @@ extern "C" int vo_frame_features(vo_ctx* ctx, int slot, float* kp_xy, float* kp_
     HIPCHK(hipSetDevice(ctx->device));
     const PyrGeom& g = ctx->g;
     int n = 0, flags = 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));              // an asynchronous detection may still be running
     HIPCHK(hipMemcpy(&n, ctx->ff.kp_count + slot, sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&flags, ctx->ff.flags + slot, sizeof(int), hipMemcpyDeviceToHost));
     int warn = (flags & 1) ? VO_WARN_CAPACITY : VO_OK;
@@ -597,6 +599,7 @@ static int download_packed(vo_ctx* ctx, const uint8_t* dev_base, uint8_t* out)
 {
     const PyrGeom& g = ctx->g;
     std::vector<uint8_t> tmp((size_t)g.frame_bytes);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(tmp.data(), dev_base, (size_t)g.frame_bytes, hipMemcpyDeviceToHost));
     size_t o = 0;
     for (int l = 0; l < g.nlevels; l++) {
@@ -774,6 +777,7 @@ extern "C" int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* ti
     if (pair < 0 || pair >= ctx->last_pairs || !n_out) FAIL(VO_ERR_INVALID, "bad pair index");
     HIPCHK(hipSetDevice(ctx->device));
     int n = 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));              // an asynchronous batch may still be running
     HIPCHK(hipMemcpy(&n, ctx->pb.m_count + pair, sizeof(int), hipMemcpyDeviceToHost));
     if (n > cap) n = cap;
     *n_out = n;
@@ -801,7 +805,7 @@ static int ensure_raw(vo_ctx* ctx, int cap)
     HIPCHK(dmalloc(&ctx->raw_desc_x, (size_t)2 * desc_x_rows(cap) * 256));
     HIPCHK(dmalloc(&ctx->raw_xy, (size_t)2 * cap * 2));
     HIPCHK(dmalloc(&ctx->raw_count, 2));
-    HIPCHK(hipMemset(ctx->raw_xy, 0, (size_t)2 * cap * 2 * sizeof(float)));
+    HIPCHK(hipMemsetAsync(ctx->raw_xy, 0, (size_t)2 * cap * 2 * sizeof(float), ctx->stream));
     HIPCHK(alloc_pairbuf(ctx->raw_pb, 1, cap, true));
     ctx->raw_cap = cap;
     return VO_OK;
