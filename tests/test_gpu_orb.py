@@ -185,3 +185,52 @@ def test_contexts_can_be_created_reconfigured_and_destroyed(oracle):
         ref2 = oracle.orb_detect_and_compute(img2, oracle.orb_params(nfeatures=nf))
         assert np.array_equal(fe2.features(0)["desc"], ref2["desc"])
         c.close()
+
+
+def _fuzz_image(rng, h, w):
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w))
+    elif kind == 1:                                    # checkerboard with random cell size and contrast: many equal scores
+        c = int(rng.integers(3, 12)); lo, hi = sorted(rng.integers(0, 256, 2))
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.where(((yy // c) + (xx // c)) % 2 == 0, lo, hi)
+    elif kind == 2:                                    # smooth gradient + sparse salt
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = (xx * 255 // max(w - 1, 1) + yy * 255 // max(h - 1, 1)) // 2
+        m = rng.random((h, w)) < 0.01
+        img = np.where(m, 255 - img, img)
+    elif kind == 3:                                    # blocks of random grey + noise (the conftest generator, other scale)
+        b = int(rng.integers(2, 9))
+        img = np.kron(rng.integers(0, 256, (h // b + 1, w // b + 1)), np.ones((b, b)))[:h, :w] + rng.normal(0, 8, (h, w))
+    elif kind == 4:                                    # saturated: only 0 and 255
+        img = np.where(rng.random((h, w)) < 0.5, 0, 255)
+    else:                                              # flat with a few rectangles
+        img = np.full((h, w), int(rng.integers(0, 256)))
+        for _ in range(int(rng.integers(1, 12))):
+            y, x = int(rng.integers(0, h - 8)), int(rng.integers(0, w - 8))
+            img[y:y + int(rng.integers(4, 40)), x:x + int(rng.integers(4, 40))] = int(rng.integers(0, 256))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_images_and_parameters(oracle, ctx, seed):
+    """Differential fuzz: 8 x 8 random (image class, size, feature count, pyramid depth, FAST threshold, score type)
+    combinations through the whole detector against the oracle — checkerboards and saturated images produce thousands
+    of equal scores (ties at every retainBest threshold, capacity warnings), flat images produce nothing."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(8):
+        h, w = int(rng.integers(70, 330)), int(rng.integers(70, 420))
+        nfeatures = int(rng.choice([30, 100, 500, 1500])); nlevels = int(rng.integers(1, 9))
+        thr = int(rng.choice([5, 10, 20, 40])); score = int(rng.integers(0, 2))
+        img = _fuzz_image(rng, h, w)
+        p = oracle.orb_params(nfeatures=nfeatures, nlevels=nlevels, fast_threshold=thr, score_type=score)
+        ref = oracle.orb_detect_and_compute(img, p)
+        got = _det(nfeatures, nlevels, fastThreshold=thr, scoreType=score).detect_arrays(img)
+        tag = f"seed {seed} {h}x{w} nf {nfeatures} L {nlevels} t {thr} score {score}"
+        if got["truncated"]:                           # a capacity of DESIGN.md section 7 was exceeded (flagged, never silent):
+            assert ref["overflow"] or len(ref["xy"]) >= len(got["xy"]), tag     # ties really did outnumber the capacity
+            continue
+        assert not ref["overflow"], tag
+        for k in ("xy", "octave", "response", "angle", "size", "desc"):
+            assert np.array_equal(got[k], ref[k]), f"{tag}: {k}"
