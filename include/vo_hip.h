@@ -70,9 +70,18 @@ int vo_orb_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int
  * BASELINE.json's north_star names). */
 int vo_set_matcher_kernel(vo_ctx* ctx, int kind);
 
+/* How the five-point solver inside findEssentialMat finds the roots of its degree-10 polynomial (cv::solvePoly,
+ * Durand-Kerner): 1 = OpenCV's fixed 300 sweeps, operation for operation; 0 (default) = the same sweeps, stopped per
+ * sample once every correction is rounding noise (~20 sweeps; identical inlier masks, [R|t] equal to ~1e-12 on the
+ * test sets, 10x less RANSAC time).  Applies to vo_find_essential_ransac, vo_stage_five_point and vo_pairs_run. */
+int vo_set_poly_solver(vo_ctx* ctx, int kind);
+
 /* self.matcher.match(d1, d2) for cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=...) —
  * src/image_pair.py:234-236, matcher built at src/visual_slam.py:18 / src/image_and_keypoints.py:9.
- * cross_check: 0 = nearest neighbour, 1 = cv2 crossCheck=True semantics, 2 = strict mutual NN.
+ * cross_check: 0 = nearest neighbour (crossCheck=False); 2 = crossCheck=True as OpenCV 4.x computes it: strict
+ * mutual nearest neighbours, lowest index winning ties in both directions (core/batch_distance.cpp keeps train i
+ * for its nearest query idx only if `sidx[idx] == i`); 1 = the older rule without that forward test (every train
+ * row votes for its nearest query, a query keeps its closest voter) — [unverified] which releases used it.
  * Outputs (capacity nq) are ordered by ascending queryIdx. */
 int vo_match_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int cross_check,
                      int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
@@ -99,6 +108,8 @@ int vo_triangulate(vo_ctx* ctx, const double* P1, const double* P2, const double
                    int M, double* X);
 
 /* ------------------------------------------------------------------ stage outputs (parity tests) */
+/* size in bytes of the packed outputs below (sum over levels of w_l * h_l); < 0 for invalid parameters */
+int64_t vo_packed_pyramid_bytes(int h, int w, const vo_orb_params* params);
 /* gray + INTER_LINEAR_EXACT pyramid, levels packed tightly one after the other */
 int vo_stage_pyramid(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
                      const vo_orb_params* params, uint8_t* out_packed);
@@ -116,7 +127,8 @@ int vo_stage_five_point(vo_ctx* ctx, const double* x1, const double* x2, double*
  * src/visual_slam.py:294-298 (match_features -> determine_essential_matrix ->
  * estimate_camera_movement -> reconstruct_3d_points). */
 typedef struct {
-    int32_t match_mode;     /* 0 = BFMatcher(crossCheck=True).match, 1 = knnMatch(k=2) + ratio */
+    int32_t match_mode;     /* 0 = BFMatcher(crossCheck=True).match (strict mutual NN), 1 = knnMatch(k=2) + ratio,
+                               2 = the legacy cross-check rule (vo_match_hamming cross_check = 1) */
     double  ratio;          /* ratio for match_mode 1 */
     double  ransac_prob;    /* 0.99  src/image_pair.py:278 */
     double  ransac_thresh;  /* 1.0   src/image_pair.py:279 */

@@ -139,7 +139,7 @@ def orb_detect_and_compute(img, params, cap=None):
                 octave=octv[:n].copy(), desc=desc[:n].copy(), overflow=(rc == 1))
 
 
-def match_hamming(q, t, cross_check=1):
+def match_hamming(q, t, cross_check=2):
     q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
     nq, nt = len(q), len(t)
     qi = np.zeros(max(nq, 1), np.int32); ti = np.zeros(max(nq, 1), np.int32); d = np.zeros(max(nq, 1), np.float32)
@@ -161,6 +161,15 @@ def knn2_ratio_hamming(q, t, ratio):
                                       qi.ctypes.data, ti.ctypes.data, d.ctypes.data, C.addressof(n))
     assert rc == 0
     return qi[:n.value].copy(), ti[:n.value].copy(), d[:n.value].copy()
+
+
+def set_dk_early_exit(on):
+    """False (default): cv::solvePoly's fixed 300 sweeps; True: the noise-floor exit of the kernel's throughput mode."""
+    lib().voo_set_dk_early_exit(int(bool(on)))
+
+
+def get_dk_early_exit():
+    return bool(lib().voo_get_dk_early_exit())
 
 
 def five_point(x1, x2):

@@ -52,14 +52,19 @@ int voo_orb_detect_and_compute(const uint8_t* img, int h, int w, int channels, i
                                int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);
 
 /* --- matcher ----------------------------------------------------------------- */
-/* cross_check: 0 = plain nearest neighbour, 1 = cv2 BFMatcher(crossCheck=True) semantics
- * (batchDistance reverse-NN update), 2 = strict mutual nearest neighbour */
+/* cross_check: 0 = plain nearest neighbour; 2 = cv2 BFMatcher(crossCheck=True) as OpenCV 4.x's batchDistance
+ * computes it (strict mutual nearest neighbours: `d < d0 && sidx[idx] == i`); 1 = the older reverse-NN update
+ * without the forward test.  [unverified] against a cv2 4.7 build: tests/test_cv2_crosscheck.py probes it. */
 int voo_match_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int cross_check,
                       int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
 int voo_knn2_ratio_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
                            int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
 
 /* --- two-view geometry (float64) --------------------------------------------- */
+/* cv::solvePoly inside the five-point solver: 0 (default) = OpenCV's fixed 300 Durand-Kerner sweeps, 1 = stop at the
+ * rounding-noise floor exactly as the HIP kernel's throughput mode does (process-wide switch, not thread safe) */
+void voo_set_dk_early_exit(int on);
+int  voo_get_dk_early_exit(void);
 int voo_find_essential_ransac(const double* p1, const double* p2, int M, const double* K,
                               double prob, double thresh_px, int max_iters, uint64_t seed,
                               double* E /*9, or 9*n_models when M==5*/, uint8_t* mask,
@@ -76,7 +81,7 @@ typedef struct {
     int32_t n_kp1, n_kp2, n_match, n_inl_E, n_good_pose;
     double  R[9], t[3], E[9];
 } voo_pair_result;
-/* match_mode: 0 = BFMatcher(crossCheck=True).match, 1 = knnMatch(k=2)+ratio */
+/* match_mode: 0 = BFMatcher(crossCheck=True).match (strict mutual), 1 = knnMatch(k=2)+ratio, 2 = legacy cross-check */
 int voo_pair(const uint8_t* img1, const uint8_t* img2, int h, int w, const voo_orb_params* p,
              const double* K, int match_mode, double ratio, voo_pair_result* out,
              double* X /*4 x cap, w=1*/, int32_t x_cap);

@@ -216,11 +216,17 @@ static inline cplx cdiv(cplx a, cplx b)
     return r;
 }
 
-/* OpenCV runs a fixed 300 sweeps (its exit test is maxDiff <= 0).  Compiled with -DVOO_DK_FULL_300 this does the
- * same.  By default a sample stops as soon as further sweeps can only move rounding noise: every correction below
- * 4 ulp of its root, or the largest correction has been small (< 1e-7 relative) and has stopped shrinking for two
- * sweeps (the noise floor of an ill-conditioned / multiple root).  The roots agree with the 300-sweep result to
- * that noise floor, and the HIP kernel applies the identical rule, operation for operation. */
+/* OpenCV runs a fixed 300 sweeps (its exit test is maxDiff <= 0), and so does the oracle by default: that is the
+ * faithful algorithm.  voo_set_dk_early_exit(1) selects the rule the HIP kernel uses in its throughput mode: a sample
+ * stops as soon as further sweeps can only move rounding noise (every correction below 4 ulp of its root, or the
+ * largest correction has been small (< 1e-7 relative) and has stopped shrinking for two sweeps: the noise floor of
+ * an ill-conditioned / multiple root).  The roots agree with the 300-sweep result to that noise floor
+ * (tests/test_oracle_dk_modes.py); the kernel applies the identical rule, operation for operation, and has the
+ * 300-sweep mode as well (vo_set_poly_solver). */
+static int g_dk_early_exit = 0;
+void voo_set_dk_early_exit(int on) { g_dk_early_exit = on != 0; }
+int voo_get_dk_early_exit(void) { return g_dk_early_exit; }
+
 static int solve_poly(const double* c, int n0, cplx* roots, int max_iters)
 {
     int n = n0;
@@ -254,16 +260,14 @@ static int solve_poly(const double* c, int n0, cplx* roots, int max_iters)
             conv_all &= ab <= 4 * DBL_EPSILON * mag;
         }
         if (max_diff <= 0) break;
-#ifndef VOO_DK_FULL_300
-        if (conv_all) break;
-        if (max_diff < 1e-7 * (1.0 + max_mag)) {
-            if (max_diff > 0.5 * prev) { if (++stall >= 2) break; }
-            else stall = 0;
+        if (g_dk_early_exit) {
+            if (conv_all) break;
+            if (max_diff < 1e-7 * (1.0 + max_mag)) {
+                if (max_diff > 0.5 * prev) { if (++stall >= 2) break; }
+                else stall = 0;
+            }
+            prev = max_diff;
         }
-        prev = max_diff;
-#else
-        (void)conv_all; (void)prev; (void)stall;
-#endif
     }
     for (int i = 0; i < n; i++) if (fabs(roots[i].im) < 1e-100) roots[i].im = 0;
     return n;

@@ -43,9 +43,10 @@ int voo_match_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int cr
     int32_t* fd = fi + nq;
     int n = 0;
     if (cross_check == 1) {
-        /* batchDistance(..., crosscheck=true): the forward pass is NOT run; for every train row
-         * i (ascending) its nearest query idx gets the candidate (i, d) and keeps it iff d is
-         * strictly smaller than what it holds. */
+        /* the older batchDistance(..., crosscheck=true): the forward pass is NOT run; for every train
+         * row i (ascending) its nearest query idx gets the candidate (i, d) and keeps it iff d is
+         * strictly smaller than what it holds.  OpenCV 4.x adds `&& sidx[idx] == i` (idx's own nearest
+         * train row must be i), which is cross_check == 2 below. */
         int32_t* ri = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nt);
         int32_t* rd = ri + nt;
         nn1(t, nt, q, nq, ri, rd);

@@ -29,8 +29,8 @@ int voo_pair(const uint8_t* img1, const uint8_t* img2, int h, int w, const voo_o
     int32_t* ti = qi + n1 + 1;
     float* md = (float*)malloc(sizeof(float) * (size_t)(n1 + 1));
     if (rc >= 0) {
-        rc = match_mode == 0 ? voo_match_hamming(d1, n1, d2, n2, 1, qi, ti, md, &nm)
-                             : voo_knn2_ratio_hamming(d1, n1, d2, n2, ratio, qi, ti, md, &nm);
+        rc = match_mode == 1 ? voo_knn2_ratio_hamming(d1, n1, d2, n2, ratio, qi, ti, md, &nm)
+                             : voo_match_hamming(d1, n1, d2, n2, match_mode == 0 ? 2 : 1, qi, ti, md, &nm);
     }
     out->n_match = nm;
     double* pts = (double*)malloc(sizeof(double) * 8 * (size_t)(nm + 1));

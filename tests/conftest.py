@@ -11,9 +11,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # the in-tree libraries are git-ignored build products: build them if a fresh checkout lacks them
-    if not (os.path.exists(os.path.join(ROOT, "visual_odometry_amd", "libvo_hip.so")) and
-            os.path.exists(os.path.join(ROOT, "oracle", "libvoo.so"))):
+    # the in-tree libraries are git-ignored build products: always run make (a no-op when they are up to date), so a
+    # stale binary is never what gets tested.  The GPU box has the same toolchain; without one, use what travelled.
+    import shutil
+    have = os.path.exists(os.path.join(ROOT, "visual_odometry_amd", "libvo_hip.so")) and \
+        os.path.exists(os.path.join(ROOT, "oracle", "libvoo.so"))
+    if shutil.which("hipcc") and shutil.which("make") or not have:
         import __graft_entry__
         __graft_entry__.build()
 
@@ -23,6 +26,16 @@ def oracle():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+@pytest.fixture
+def kernel_dk_rule(oracle):
+    """The oracle's five-point root finder switched to the HIP kernel's throughput rule (Durand-Kerner sweeps stop at
+    the rounding-noise floor) for the duration of a test, so that E / masks / [R|t] can be compared bit for bit with
+    the product's default mode.  Without it the oracle runs cv::solvePoly's fixed 300 sweeps."""
+    oracle.set_dk_early_exit(True)
+    yield oracle
+    oracle.set_dk_early_exit(False)
 
 
 @pytest.fixture(scope="session")

@@ -21,12 +21,14 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    assert not O.get_dk_early_exit()                       # vectors come from the faithful 300-sweep root finder
     seq = synth.sequence(2, 320, 240)
     frames, K = seq["frames"], seq["K"]
     p = O.orb_params(nfeatures=300, nlevels=6)
     d = [O.orb_detect_and_compute(f, p) for f in frames]
     lv = O.pyramid(frames[0], p)
-    qi, ti, md = O.match_hamming(d[0]["desc"], d[1]["desc"], 1)
+    qi, ti, md = O.match_hamming(d[0]["desc"], d[1]["desc"], 2)        # BFMatcher(crossCheck=True), OpenCV 4.x rule
+    lq, lt, ld = O.match_hamming(d[0]["desc"], d[1]["desc"], 1)        # the legacy rule
     rq, rt, rd = O.knn2_ratio_hamming(d[0]["desc"], d[1]["desc"], 0.8)
     pr = O.pair(frames[0], frames[1], p, K)
     np.savez_compressed(
@@ -34,7 +36,7 @@ def main():
         level1=lv[1], fast0=O.fast_score_nms(lv[0], 20), blur0=O.gaussian_blur7(lv[0]),
         xy0=d[0]["xy"], angle0=d[0]["angle"], response0=d[0]["response"], octave0=d[0]["octave"], desc0=d[0]["desc"],
         xy1=d[1]["xy"], desc1=d[1]["desc"],
-        cc_q=qi, cc_t=ti, cc_d=md, ratio_q=rq, ratio_t=rt, ratio_d=rd,
+        cc_q=qi, cc_t=ti, cc_d=md, legacy_q=lq, legacy_t=lt, legacy_d=ld, ratio_q=rq, ratio_t=rt, ratio_d=rd,
         n_match=pr["n_match"], n_inl=pr["n_inl"], n_good=pr["n_good"], R=pr["R"], t=pr["t"], E=pr["E"], X=pr["X"])
     # geometry-only vector: exact synthetic correspondences with outliers
     rng = np.random.default_rng(99)

@@ -46,10 +46,24 @@ def test_ingest_resize_matches_cv2_resize(oracle, shape, dsize):
     assert np.array_equal(cv2.resize(img, dsize), got)
 
 
-def test_blur_matches_gaussianblur(oracle):
+def test_blur_matches_orbs_gaussianblur_path(oracle):
+    """orb.cpp blurs every level as a SUB-MATRIX of the bordered pyramid buffer: GaussianBlur(workingMat, workingMat,
+    Size(7, 7), 2, 2, BORDER_REFLECT_101) with workingMat = imagePyramid(layerInfo[level]).  For an 8-bit sub-matrix
+    without BORDER_ISOLATED GaussianBlur skips its bit-exact fixed-point branch and runs sepFilter2D, whose 8-bit path
+    quantises the float kernel to cvRound(256 g) = {18, 34, 49, 55, 49, 34, 18} and rounds (sum + 2^15) >> 16 — what
+    the oracle restates.  A numpy view never carries cv::Mat's SUBMATRIX flag, so that branch cannot be reached through
+    GaussianBlur from Python: the same arithmetic is called directly (sepFilter2D with GaussianBlur's own CV_32F
+    kernel).  The pixels sepFilter2D reads beyond the ROI are the pyramid's REFLECT_101 border, i.e. the reflection."""
     img = random_image(12, 240, 320)
-    ref = cv2.GaussianBlur(img, (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
+    g = cv2.getGaussianKernel(7, 2, cv2.CV_32F)
+    ref = cv2.sepFilter2D(img, -1, g, g, borderType=cv2.BORDER_REFLECT_101)
     assert np.array_equal(oracle.gaussian_blur7(img), ref)
+    # the same blur on a whole (non-sub-matrix) image takes the fixed-point branch with a different tap table: it is
+    # expected to DIFFER from the oracle in a few grey levels, and must never be used to "pin" the ORB blur
+    whole = cv2.GaussianBlur(img, (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
+    diff = np.abs(whole.astype(int) - ref.astype(int))
+    print(f"whole-image GaussianBlur vs sepFilter2D path: {int((diff > 0).sum())} pixels differ, max {int(diff.max())}")
+    assert diff.max() <= 1
 
 
 def test_fast_matches_fastfeaturedetector(oracle):
@@ -87,7 +101,31 @@ def _descs(oracle, frames):
 def test_bfmatcher_crosscheck(oracle, frames):
     a, b = _descs(oracle, frames)
     ms = cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(a["desc"], b["desc"])
-    qi, ti, d = oracle.match_hamming(a["desc"], b["desc"], 1)
+    qi, ti, d = oracle.match_hamming(a["desc"], b["desc"], 2)
+    assert [(m.queryIdx, m.trainIdx, m.distance) for m in ms] == list(zip(qi.tolist(), ti.tolist(), d.tolist()))
+
+
+def test_crosscheck_rule_probe(oracle):
+    """Which cross-check rule does this cv2 implement?  The oracle's default (2) is OpenCV 4.x's batchDistance: train i
+    is kept for its nearest query idx only if idx's own nearest train row is i (mutual nearest neighbours).  Rule 1 is
+    the older update without that forward test.  The two differ on a NON-mutual configuration without any tie."""
+    q = np.zeros((2, 32), np.uint8); t = np.zeros((2, 32), np.uint8)
+    q[1, 0] = 0b1111; t[0, 0] = 0b1; t[1, 0] = 0xff; t[1, 1] = 0b1
+    # distances: q0-t0 1, q0-t1 9, q1-t0 3, q1-t1 5.  Reverse NN: t0 -> q0, t1 -> q1.  Forward NN: q0 -> t0, q1 -> t0.
+    # rule 1 keeps (q0, t0) and (q1, t1); the mutual rule keeps only (q0, t0).
+    got = [(m.queryIdx, m.trainIdx) for m in cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(q, t)]
+    r1 = list(zip(*[a.tolist() for a in oracle.match_hamming(q, t, 1)[:2]]))
+    r2 = list(zip(*[a.tolist() for a in oracle.match_hamming(q, t, 2)[:2]]))
+    assert r1 == [(0, 0), (1, 1)] and r2 == [(0, 0)]
+    assert got in (r1, r2), got
+    assert got == r2, "this cv2 build uses the LEGACY cross-check rule (oracle mode 1): switch the default (vo_pair_opts.match_mode 2)"
+    # ties: equal distances resolve to the lowest index in both directions
+    rng = np.random.default_rng(3)
+    tt = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    qq = np.repeat(tt[:10], 2, axis=0)                      # every query twice, every matching train row once
+    tt[20:30] = tt[:10]                                     # and every matching train row twice
+    ms = cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True).match(qq, tt)
+    qi, ti, d = oracle.match_hamming(qq, tt, 2)
     assert [(m.queryIdx, m.trainIdx, m.distance) for m in ms] == list(zip(qi.tolist(), ti.tolist(), d.tolist()))
 
 
@@ -101,7 +139,7 @@ def test_knn_ratio(oracle, frames):
 
 def _matched_points(oracle, frames):
     a, b = _descs(oracle, frames)
-    qi, ti, _ = oracle.match_hamming(a["desc"], b["desc"], 1)
+    qi, ti, _ = oracle.match_hamming(a["desc"], b["desc"], 2)
     return a["xy"][qi].astype(np.float64), b["xy"][ti].astype(np.float64)
 
 

@@ -27,7 +27,7 @@ def _matcher(**kw):
 def test_match_modes_bit_exact(oracle, ctx, nq, nt, seed, mode):
     t = _descs(seed, nt)
     q = _descs(seed + 100, nq, dup_from=t, flip_bits=40)
-    m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+    m = _matcher(crossCheck=mode > 0, legacy_crosscheck=mode == 1)
     gq, gt, gd = m.match_arrays(q, t)
     rq, rt, rd = oracle.match_hamming(q, t, mode)
     assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
@@ -40,7 +40,7 @@ def test_ties_prefer_lowest_index(oracle, ctx):
     q = base[rng.integers(0, 16, 300)]
     t = base[rng.integers(0, 16, 280)]
     for mode in (0, 1, 2):
-        m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+        m = _matcher(crossCheck=mode > 0, legacy_crosscheck=mode == 1)
         gq, gt, gd = m.match_arrays(q, t)
         rq, rt, rd = oracle.match_hamming(q, t, mode)
         assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
@@ -71,7 +71,7 @@ def test_real_descriptors(oracle, ctx, seq_small):
     d1 = det.detect_arrays(seq_small["frames"][0])["desc"]
     d2 = det.detect_arrays(seq_small["frames"][1])["desc"]
     gq, gt, gd = _matcher(crossCheck=True).match_arrays(d1, d2)
-    rq, rt, rd = oracle.match_hamming(d1, d2, 1)
+    rq, rt, rd = oracle.match_hamming(d1, d2, 2)
     assert len(gq) > 100
     assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd)
     assert np.all(np.diff(gq) > 0)       # ascending queryIdx, as BFMatcher.match returns them
@@ -85,7 +85,7 @@ def test_sizes_around_the_mfma_tiles(oracle, ctx, nq, nt):
     t = _descs(nq * 7 + nt, nt)
     q = _descs(nq + nt * 3, nq, dup_from=t, flip_bits=30)
     for mode in (0, 1, 2):
-        m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+        m = _matcher(crossCheck=mode > 0, legacy_crosscheck=mode == 1)
         assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode)))
     for ratio in (0.6, 1.0):
         assert all(np.array_equal(a, b) for a, b in zip(_matcher().ratio_match_arrays(q, t, ratio),
@@ -98,7 +98,7 @@ def test_extreme_descriptors(oracle, ctx):
     mix = np.concatenate([z[:5], o[:5], _descs(3, 20)])
     for q, t in ((z, o), (o, z), (mix, o), (z, mix), (mix, mix[::-1].copy())):
         for mode in (0, 1, 2):
-            m = _matcher(crossCheck=mode > 0, strict_mutual=mode == 2)
+            m = _matcher(crossCheck=mode > 0, legacy_crosscheck=mode == 1)
             assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode)))
         assert all(np.array_equal(a, b) for a, b in zip(_matcher().ratio_match_arrays(q, t, 0.9),
                                                         oracle.knn2_ratio_hamming(q, t, 0.9)))
@@ -115,7 +115,7 @@ def test_popcount_kernel_gives_the_same_matches(oracle):
             t = _descs(nq + 5, nt)
             q = _descs(nt + 9, nq, dup_from=t, flip_bits=40)
             for mode in (0, 1, 2):
-                m = HammingMatcher(crossCheck=mode > 0, strict_mutual=mode == 2, ctx=c)
+                m = HammingMatcher(crossCheck=mode > 0, legacy_crosscheck=mode == 1, ctx=c)
                 assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode)))
             m = HammingMatcher(ctx=c)
             assert all(np.array_equal(a, b) for a, b in zip(m.ratio_match_arrays(q, t, 0.8), oracle.knn2_ratio_hamming(q, t, 0.8)))

@@ -6,6 +6,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _same_root_finder_rule(kernel_dk_rule):
+    """Every test of this module compares the product's DEFAULT mode with the oracle bit for bit, so the oracle runs the
+    kernel's Durand-Kerner exit rule; tests/test_gpu_faithful.py covers OpenCV's fixed 300 sweeps on both sides."""
+    yield
+
+
 def _check_pair(res, X, ref):
     assert res["status"] == 0 and ref["rc"] == 0
     assert (res["n_kp1"], res["n_kp2"], res["n_match"], res["n_inl"], res["n_good"]) == \
@@ -27,7 +34,7 @@ def _check_pair(res, X, ref):
     assert np.allclose(X[3, :n], 1.0)
 
 
-@pytest.mark.parametrize("match_mode", [0, 1])
+@pytest.mark.parametrize("match_mode", [0, 1, 2])
 def test_batched_pairs_match_oracle(oracle, seq_small, match_mode):
     from visual_odometry_amd.frontend import FrontEnd
     frames, K = seq_small["frames"], seq_small["K"]
@@ -43,7 +50,7 @@ def test_batched_pairs_match_oracle(oracle, seq_small, match_mode):
         _check_pair(res[i], X[i], ref)
         qi, ti, d, m = fe.pair_matches(i)
         d1 = oracle.orb_detect_and_compute(frames[a], p)["desc"]; d2 = oracle.orb_detect_and_compute(frames[b], p)["desc"]
-        rq, rt, rd = oracle.match_hamming(d1, d2, 1) if match_mode == 0 else oracle.knn2_ratio_hamming(d1, d2, 0.8)
+        rq, rt, rd = oracle.match_hamming(d1, d2, 2 if match_mode == 0 else 1) if match_mode != 1 else oracle.knn2_ratio_hamming(d1, d2, 0.8)
         assert np.array_equal(qi, rq) and np.array_equal(ti, rt) and np.array_equal(d, rd)   # bit-exact match pairs
 
 
@@ -220,3 +227,29 @@ def test_overlapped_contexts_are_deterministic():
     for k in range(2):
         fes[k].wait()
         assert np.array_equal(key(inflight[k]), ref)
+
+
+def test_reconfigure_recycles_memory_safely(oracle, seq_small):
+    """vo_batch_configure frees and reallocates every device buffer.  The MFMA matcher multiplies the unwritten rows
+    of the last 16-row group of the expanded descriptors (it masks them with a bias), so those rows must never hold
+    arbitrary recycled bytes: configure small -> large (fill the heap with image noise) -> small again on ONE context
+    and compare the match lists with the oracle."""
+    from conftest import random_image
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    frames, K = seq_small["frames"], seq_small["K"]
+    c = _lib.Context(0)
+    p = oracle.orb_params(nfeatures=500)
+    d = [oracle.orb_detect_and_compute(frames[i], p)["desc"] for i in range(3)]
+    want = [oracle.match_hamming(d[i], d[i + 1], 2) for i in range(2)]
+    for round_ in range(3):
+        fe = FrontEnd(480, 640, max_frames=3, max_pairs=2, nfeatures=500, ctx=c)
+        fe.upload(frames[:3]); fe.detect(0, 3)
+        fe.run_pairs([[0, 1], [1, 2]], K)
+        for i in range(2):
+            qi, ti, dd, _ = fe.pair_matches(i)
+            assert np.array_equal(qi, want[i][0]) and np.array_equal(ti, want[i][1]) and np.array_equal(dd, want[i][2]), (round_, i)
+        big = FrontEnd(1080, 1920, max_frames=6, max_pairs=2, nfeatures=4000, nlevels=4, ctx=c)
+        noise = np.stack([random_image(40 + round_ * 7 + k, 1080, 1920) | 0x80 for k in range(6)])
+        big.upload(noise); big.detect(0, 6)
+    c.close()

@@ -55,8 +55,11 @@ def test_pair_golden(oracle):
     for k in ("xy", "angle", "response", "octave", "desc"):
         assert np.array_equal(d0[k], g[k + "0"]), k
     assert np.array_equal(d1["xy"], g["xy1"]) and np.array_equal(d1["desc"], g["desc1"])
-    q, t, d = oracle.match_hamming(d0["desc"], d1["desc"], 1)
+    q, t, d = oracle.match_hamming(d0["desc"], d1["desc"], 2)
     assert np.array_equal(q, g["cc_q"]) and np.array_equal(t, g["cc_t"]) and np.array_equal(d, g["cc_d"])
+    q, t, d = oracle.match_hamming(d0["desc"], d1["desc"], 1)
+    assert np.array_equal(q, g["legacy_q"]) and np.array_equal(t, g["legacy_t"]) and np.array_equal(d, g["legacy_d"])
+    assert set(zip(g["cc_q"].tolist(), g["cc_t"].tolist())) <= set(zip(q.tolist(), t.tolist()))   # mutual pairs survive both rules
     q, t, d = oracle.knn2_ratio_hamming(d0["desc"], d1["desc"], 0.8)
     assert np.array_equal(q, g["ratio_q"]) and np.array_equal(t, g["ratio_t"]) and np.array_equal(d, g["ratio_d"])
     pr = oracle.pair(f[0], f[1], p, g["K"])

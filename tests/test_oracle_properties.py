@@ -97,9 +97,9 @@ def test_matcher_semantics(oracle):
     assert np.array_equal(qi, np.arange(40)) and np.all(d == 0) and np.all((t[ti] == q).all(axis=1))
     q1, t1, d1 = oracle.match_hamming(q, t, 1); q2, t2, d2 = oracle.match_hamming(q, t, 2)
     assert np.array_equal(q1, q2) and np.array_equal(t1, t2)   # distinct exact matches: both cross-check rules agree
-    # cv2 crossCheck keeps a query as soon as SOME train row chose it; strict mutual NN can drop it
+    # the legacy rule (1) keeps a query as soon as SOME train row chose it; OpenCV 4.x's mutual rule (2) can drop it
     q = np.zeros((2, 32), np.uint8); t = np.zeros((2, 32), np.uint8)
-    q[1, 0] = 0b111; t[0, 0] = 0b1; t[1, 0] = 0b11111
+    q[1, 0] = 0b1111; t[0, 0] = 0b1; t[1, 0] = 0xff; t[1, 1] = 0b1          # no ties: q1 -> t0 forward, t1 -> q1 backward
     a = oracle.match_hamming(q, t, 1); b = oracle.match_hamming(q, t, 2)
     assert a[0].tolist() == [0, 1] and a[1].tolist() == [0, 1] and b[0].tolist() == [0] and b[1].tolist() == [0]
     # ratio rule is strict

@@ -132,7 +132,12 @@ def test_matcher_against_numpy_popcount(oracle):
     D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
     qi, ti, d = oracle.match_hamming(q, t, 0)
     assert np.array_equal(ti, D.argmin(axis=1)) and np.array_equal(d, D.min(axis=1))
-    # cv2 crossCheck: every train row votes for its nearest query; a query keeps the closest voter (lowest index)
+    # OpenCV 4.x crossCheck: mutual nearest neighbours, first minimum in both directions
+    fwd, rev = D.argmin(axis=1), D.argmin(axis=0)
+    mutual = [i for i in range(70) if rev[fwd[i]] == i]
+    qi, ti, d = oracle.match_hamming(q, t, 2)
+    assert qi.tolist() == mutual and np.array_equal(ti, fwd[mutual]) and np.array_equal(d, D[mutual, fwd[mutual]])
+    # legacy crossCheck: every train row votes for its nearest query; a query keeps the closest voter (lowest index)
     best = {}
     for j in range(90):
         qq = int(D[:, j].argmin()); dd = int(D[qq, j])

@@ -47,6 +47,7 @@ _SIGS = {
     "vo_find_essential_ransac": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_double, C.c_double, C.c_int, C.c_uint64, _P, _P, _P, _P]),
     "vo_recover_pose": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P]),
     "vo_triangulate": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
+    "vo_packed_pyramid_bytes": (C.c_int64, [C.c_int, C.c_int, _P]),
     "vo_stage_pyramid": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "vo_stage_fast_scores": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "vo_stage_blur": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
@@ -65,6 +66,7 @@ _SIGS = {
     "vo_pairs_run_async": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int32]),
     "vo_sync": (C.c_int, [_P]),
     "vo_set_matcher_kernel": (C.c_int, [_P, C.c_int]),
+    "vo_set_poly_solver": (C.c_int, [_P, C.c_int]),
     "vo_detect_after": (C.c_int, [_P, _P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
@@ -138,6 +140,11 @@ class Context:
     def set_matcher_kernel(self, kind):
         """'mfma' (default) or 'popcount': which kernel computes the Hamming nearest neighbours (same results)."""
         self.check(self.lib.vo_set_matcher_kernel(self.handle, {"mfma": 0, "popcount": 1}[kind]))
+
+    def set_poly_solver(self, kind):
+        """'fast' (default): Durand-Kerner sweeps stop at the rounding-noise floor; 'opencv300': cv::solvePoly's fixed
+        300 sweeps (the faithful, 10x slower form of the five-point solver's root finder)."""
+        self.check(self.lib.vo_set_poly_solver(self.handle, {"fast": 0, "opencv300": 1}[kind]))
 
     def check(self, rc):
         if rc < 0:

@@ -196,12 +196,12 @@ __device__ __forceinline__ void conv(const double* a, const double* b, double* r
 
 // cv::solvePoly's Durand-Kerner sweeps (Gauss-Seidel updates from the starting points (1+i)^k).
 // FULL: degree 10 (the normal case, static indices).  OpenCV always runs its 300 sweeps (its exit test is
-// maxDiff <= 0).  Here a lane stops as soon as further sweeps can only move rounding noise: every correction
+// maxDiff <= 0); early == false does the same (vo_set_poly_solver(ctx, 1)).  With early == true a lane stops as soon as further sweeps can only move rounding noise: every correction
 // below 4 ulp of its root, or the largest correction has been small and has stopped shrinking for two sweeps
 // (the noise floor of an ill-conditioned / multiple root).  The roots agree with the full iteration to
 // that noise floor; the exit is per lane, so a sample's result does not depend on its wave mates.
 template <bool FULL>
-__device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, double* ri)
+__device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, double* ri, bool early)
 {
     double prev = 1e300;
     int stall = 0;
@@ -244,8 +244,8 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
                 conv_all &= ab <= 4 * DBL_EPSILON * mag;
             }
         }
-        if (max_diff <= 0 || conv_all) break;
-        if (max_diff < 1e-7 * (1.0 + max_mag)) {
+        if (max_diff <= 0 || (early && conv_all)) break;
+        if (early && max_diff < 1e-7 * (1.0 + max_mag)) {
             if (max_diff > 0.5 * prev) { if (++stall >= 2) break; }
             else stall = 0;
         }
@@ -261,7 +261,7 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
 #define FP_LANES 32
 #define CM(r, k) cm[((r) * 20 + (k)) * FP_LANES]
 typedef __attribute__((address_space(3))) double lds_double;
-__device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout, lds_double* cm)
+__device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout, lds_double* cm, bool dk_early)
 {
     double basis[36];
     {
@@ -452,8 +452,8 @@ __device__ __noinline__ int five_point_solve(const double* x1, const double* x2,
 #pragma unroll
         for (int i = 0; i < 10; i++) { rr[i] = p.re; ri[i] = p.im; p = cmul(p, r); }
     }
-    if (n == 10) dk_iterate<true>(c, 10, rr, ri);
-    else dk_iterate<false>(c, n, rr, ri);
+    if (n == 10) dk_iterate<true>(c, 10, rr, ri, dk_early);
+    else dk_iterate<false>(c, n, rr, ri, dk_early);
 
     // real roots, in ascending index (OpenCV's order).  Lanes hold their real roots at different indices, so instead
     // of ten wave-wide passes each lane walks the set bits of its own mask: the wave makes max-popcount passes.
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
     if (M == 5) {       // ptsetreg.cpp: count == modelPoints -> all solutions, every point an inlier
         if (tid == 0) {
             double* models = pb.models + (size_t)p * 64 * 90;
-            int nm = five_point_solve(x1, x2, models, (lds_double*)sh.cm);
+            int nm = five_point_solve(x1, x2, models, (lds_double*)sh.cm, rp.dk_early != 0);
             for (int k = 0; k < 9; k++) res->E[k] = nm > 0 ? models[k] : 0.0;
             res->status = nm > 0 ? VO_OK : VO_ERR_NO_MODEL;
             res->n_inl = nm > 0 ? 5 : 0;
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                     s1[2 * i] = x1[2 * v]; s1[2 * i + 1] = x1[2 * v + 1];
                     s2[2 * i] = x2[2 * v]; s2[2 * i + 1] = x2[2 * v + 1];
                 }
-                nm = five_point_solve(s1, s2, gmodels + lane * 90, (lds_double*)sh.cm + lane);
+                nm = five_point_solve(s1, s2, gmodels + lane * 90, (lds_double*)sh.cm + lane, rp.dk_early != 0);
             }
             sh.nm[lane] = nm;
             // exclusive prefix of the model counts + flattened (sample, model) list
@@ -980,15 +980,15 @@ void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
 }
 
 // ------------------------------------------------------------------ single five-point sample (stage test)
-__global__ __launch_bounds__(64) void k_five_point_raw(const double* x1, const double* x2, double* E, int* nm)
+__global__ __launch_bounds__(64) void k_five_point_raw(const double* x1, const double* x2, double* E, int* nm, int dk_early)
 {
     __shared__ double s_cm[200 * FP_LANES];
-    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E, (lds_double*)s_cm);
+    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E, (lds_double*)s_cm, dk_early != 0);
 }
 
-void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm)
+void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm, int dk_early)
 {
-    hipLaunchKernelGGL(k_five_point_raw, dim3(1), dim3(64), 0, s, x1, x2, E, nm);
+    hipLaunchKernelGGL(k_five_point_raw, dim3(1), dim3(64), 0, s, x1, x2, E, nm, dk_early);
 }
 
 // ------------------------------------------------------------------ reprojection-error filter

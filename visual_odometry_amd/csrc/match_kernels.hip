@@ -4,7 +4,7 @@
 // (reference: src/image_pair.py:234-236, matcher built at src/visual_slam.py:18 and
 // src/image_and_keypoints.py:9) and knnMatch(k=2) + ratio test (src/feature_detection.py:20-26).
 // Semantics follow OpenCV's batchDistance: ascending scan, strict `<`, so the lowest index wins ties;
-// crossCheck=True keeps, for every query, the closest of the train rows whose own nearest query it is.
+// crossCheck=True keeps the mutual nearest neighbours (mode 2); the older reverse-NN-only rule is mode 1.
 #include "vo_internal.h"
 #include <limits.h>
 
@@ -268,8 +268,9 @@ void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, 
 }
 
 // ------------------------------------------------------------------ match selection + ordered compaction, one workgroup per pair
-// mode 0: nearest neighbour; 1: cv2 crossCheck=True (batchDistance reverse-NN update, strict <, ascending
-// train index == 64-bit atomic min of (dist << 32 | train)); 2: strict mutual NN; 3: knn2 + ratio.
+// mode 0: nearest neighbour; 1: legacy cross-check (batchDistance reverse-NN update without the forward test,
+// strict <, ascending train index == 64-bit atomic min of (dist << 32 | train)); 2: cv2 4.x crossCheck=True =
+// strict mutual NN; 3: knn2 + ratio.
 // Also gathers the matched keypoint coordinates as float64 pixels (ImagePair.get_image_points,
 // image_pair.py:294-299) and their K-normalised form (findEssentialMat / recoverPose prologue).
 __device__ __forceinline__ int excl_scan_256(int v, int* s_w, int* total)
@@ -350,5 +351,7 @@ void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count,
 {
     if (P <= 0) return;
     size_t shmem = mode == 1 ? (size_t)kp_cap * 8 : 8;
+    // above the 64 KB default a workgroup must opt in to its dynamic LDS (the API layer bounds kp_cap * 8 by 160 KB)
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_match_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k_match_select, dim3(P), dim3(256), shmem, s, kp_xy, kp_count, kp_cap, pb, mode, ratio, K);
 }

@@ -38,7 +38,7 @@ struct vo_ctx {
     uint8_t* raw_desc = nullptr; float* raw_xy = nullptr; int* raw_count = nullptr; uint8_t* raw_desc_x = nullptr;
     PairBuf raw_pb{};
     double* raw_d = nullptr; size_t raw_d_n = 0;     // generic double scratch
-    uint32_t* rng_tab = nullptr; uint64_t rng_seed = 0; bool rng_valid = false;   // OpenCV RNG stream for the RANSAC seed
+    uint32_t* rng_tab = nullptr; uint32_t* rng_host = nullptr; uint64_t rng_seed = 0; bool rng_valid = false;   // OpenCV RNG stream for the RANSAC seed
     int* raw_i = nullptr;
 
     bool prof = false;
@@ -51,6 +51,7 @@ struct vo_ctx {
     hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
     bool ev_det_set = false;
     int matcher_kernel = 0;               // 0: int8 MFMA on +1/-1 bytes (default), 1: XOR + popcount
+    int dk_early = 1;                     // five-point polynomial roots: 1 = noise-floor exit (default), 0 = fixed 300 sweeps
 };
 
 static const char* k_stage_names[VO_STAGE_COUNT] = {
@@ -261,6 +262,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
     if (ctx->ev_det) (void)hipEventDestroy(ctx->ev_det);
+    if (ctx->rng_host) (void)hipHostFree(ctx->rng_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -270,6 +272,14 @@ extern "C" int vo_set_matcher_kernel(vo_ctx* ctx, int kind)
     if (!ctx) return VO_ERR_INVALID;
     if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "matcher kernel must be 0 (MFMA) or 1 (XOR + popcount)");
     ctx->matcher_kernel = kind;
+    return VO_OK;
+}
+
+extern "C" int vo_set_poly_solver(vo_ctx* ctx, int kind)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "poly solver must be 0 (noise-floor exit) or 1 (OpenCV's fixed 300 sweeps)");
+    ctx->dk_early = kind == 0;
     return VO_OK;
 }
 
@@ -338,6 +348,9 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     HIPCHK(dmalloc(&ff.kp_xy, F * g.kp_cap * 2)); HIPCHK(dmalloc(&ff.kp_size, F * g.kp_cap));
     HIPCHK(dmalloc(&ff.desc, F * g.kp_cap * 32));
     HIPCHK(dmalloc(&ctx->desc_x, F * (size_t)desc_x_rows(g.kp_cap) * 256));
+    // k_brief writes only the rows below kp_count; k_nn_mfma still multiplies the rest of the last 16-row group and
+    // relies on |dot| <= 16384, which holds for +1 / -1 bytes but not for whatever a recycled allocation held
+    HIPCHK(hipMemset(ctx->desc_x, 0xFF, F * (size_t)desc_x_rows(g.kp_cap) * 256));
     HIPCHK(dmalloc(&ff.kp_count, F)); HIPCHK(dmalloc(&ff.flags, F));
     HIPCHK(dmalloc(&ff.hist, F * VO_MAX_LEVELS * 256));
     HIPCHK(dmalloc(&ff.tile_list, F * (size_t)g.ftiles_total * FAST_LISTCAP));
@@ -625,6 +638,20 @@ static int stage_common(vo_ctx* ctx, const uint8_t* img, int h, int w, int chann
     return VO_OK;
 }
 
+// bytes vo_stage_pyramid / vo_stage_fast_scores / vo_stage_blur write (levels packed tightly): sum of w_l * h_l
+extern "C" int64_t vo_packed_pyramid_bytes(int h, int w, const vo_orb_params* params)
+{
+    if (!params || h < 1 || w < 1 || params->nlevels < 1 || params->nlevels > VO_MAX_LEVELS || !(params->scale_factor > 1.0f)) return VO_ERR_INVALID;
+    int64_t total = 0;
+    for (int l = 0; l < params->nlevels; l++) {
+        const float scale = (float)pow((double)params->scale_factor, (double)l);
+        const int lw = cv_round_f((float)w / scale), lh = cv_round_f((float)h / scale);
+        if (lw < 1 || lh < 1) return VO_ERR_INVALID;
+        total += (int64_t)lw * lh;
+    }
+    return total;
+}
+
 extern "C" int vo_stage_pyramid(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
                                 const vo_orb_params* params, uint8_t* out_packed)
 {
@@ -654,18 +681,25 @@ static int ensure_rng(vo_ctx* ctx, uint64_t seed)
 {
     if (ctx->rng_valid && ctx->rng_seed == seed) return VO_OK;
     if (!ctx->rng_tab) HIPCHK(dmalloc(&ctx->rng_tab, RNG_TAB_N));
-    std::vector<uint32_t> tab(RNG_TAB_N);
+    if (!ctx->rng_host) HIPCHK(hipHostMalloc((void**)&ctx->rng_host, RNG_TAB_N * sizeof(uint32_t), hipHostMallocDefault));
+    // an earlier asynchronous batch may still be reading the table (and the host buffer may still be feeding the
+    // previous copy): the rewrite is ordered on the ctx stream, behind both
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint32_t* tab = ctx->rng_host;
     uint64_t st = seed ? seed : 0xffffffffULL;
     for (int i = 0; i < RNG_TAB_N; i++) {
         st = (uint64_t)(uint32_t)st * 4164903690ULL + (uint32_t)(st >> 32);
         tab[i] = (uint32_t)st;
     }
-    HIPCHK(hipMemcpy(ctx->rng_tab, tab.data(), RNG_TAB_N * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(ctx->rng_tab, tab, RNG_TAB_N * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     ctx->rng_seed = seed; ctx->rng_valid = true;
     return VO_OK;
 }
 
-static int map_select_mode(int match_mode) { return match_mode == 0 ? 1 : 3; }
+// vo_pair_opts.match_mode -> k_match_select mode.  BFMatcher(crossCheck=True) of OpenCV 4.x is the strict mutual
+// nearest neighbour (batchDistance compares the forward result too: `d < d0 && sidx[idx] == i`); the older
+// reverse-NN-only update rule stays selectable as match_mode 2.
+static int map_select_mode(int match_mode) { return match_mode == 0 ? 2 : match_mode == 2 ? 1 : 3; }
 
 static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t* desc_x, const float* kp_xy, const int* kp_count, int cap,
                      int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points)
@@ -696,7 +730,7 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
 {
     if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (!pair_slots || !K || !opts || !results || B < 0 || B > ctx->max_pairs) FAIL(VO_ERR_INVALID, "bad pair batch arguments");
-    if (opts->match_mode != 0 && opts->match_mode != 1) FAIL(VO_ERR_INVALID, "match_mode must be 0 or 1");
+    if (opts->match_mode < 0 || opts->match_mode > 2) FAIL(VO_ERR_INVALID, "match_mode must be 0, 1 or 2");
     if (!(opts->ransac_prob > 0 && opts->ransac_prob < 1)) FAIL(VO_ERR_INVALID, "ransac_prob must be in (0, 1)");
     for (int i = 0; i < 2 * B; i++)
         if (pair_slots[i] < 0 || pair_slots[i] >= ctx->max_frames) FAIL(VO_ERR_INVALID, "pair slot %d out of range", pair_slots[i]);
@@ -709,7 +743,7 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
     HIPCHK(hipMemcpyAsync(ctx->dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
     RansacParams rp{};
     rp.prob = opts->ransac_prob; rp.thresh_px = opts->ransac_thresh; rp.max_iters = opts->ransac_max_iters;
-    rp.seed = opts->ransac_seed; rp.dist_thresh = opts->pose_dist_thresh;
+    rp.seed = opts->ransac_seed; rp.dist_thresh = opts->pose_dist_thresh; rp.dk_early = ctx->dk_early;
     memcpy(rp.K, K, sizeof(rp.K));
     const bool wp = opts->want_points != 0;
     int rc = run_pairs(ctx, ctx->pb, ctx->ff.desc, ctx->desc_x, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
@@ -819,6 +853,9 @@ static int match_raw(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, in
     *n_out = 0;
     if (nq == 0 || nt == 0) return VO_OK;
     if (nq > 65535 || nt > 65535) FAIL(VO_ERR_INVALID, "at most 65535 descriptors per set");
+    // the legacy cross-check rule keeps an 8-byte (distance, train) slot per query in LDS: 160 KB per workgroup
+    if (select_mode == 1 && (size_t)align_up((nq > nt ? nq : nt) + (nq > nt ? nq : nt) / 4 + 64, 64) * 8 > 160 * 1024)
+        FAIL(VO_ERR_INVALID, "cross_check = 1 (legacy rule) supports at most 16000 descriptors per set (LDS), got %d / %d", nq, nt);
     HIPCHK(hipSetDevice(ctx->device));
     int rc = ensure_raw(ctx, nq > nt ? nq : nt);
     if (rc) return rc;
@@ -903,7 +940,7 @@ extern "C" int vo_find_essential_ransac(vo_ctx* ctx, const double* p1, const dou
     int rc = upload_points(ctx, p1, p2, M, K, 0);
     if (rc) return rc;
     RansacParams rp{};
-    rp.prob = prob; rp.thresh_px = thresh_px; rp.max_iters = max_iters; rp.seed = seed; rp.dist_thresh = 50;
+    rp.prob = prob; rp.thresh_px = thresh_px; rp.max_iters = max_iters; rp.seed = seed; rp.dist_thresh = 50; rp.dk_early = ctx->dk_early;
     memcpy(rp.K, K, sizeof(rp.K));
     rc = ensure_rng(ctx, rp.seed);
     if (rc) return rc;
@@ -1000,7 +1037,7 @@ extern "C" int vo_stage_five_point(vo_ctx* ctx, const double* x1, const double* 
     double* d = ctx->raw_d;
     HIPCHK(hipMemcpyAsync(d, x1, 10 * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d + 10, x2, 10 * sizeof(double), hipMemcpyHostToDevice, s));
-    launch_five_point_raw(s, d, d + 10, d + 20, ctx->raw_i);
+    launch_five_point_raw(s, d, d + 10, d + 20, ctx->raw_i, ctx->dk_early);
     HIPCHK(hipGetLastError());
     int nm = 0;
     HIPCHK(hipMemcpyAsync(&nm, ctx->raw_i, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -108,6 +108,7 @@ struct RansacParams {
     uint64_t seed;
     double K[9];
     double dist_thresh;
+    int dk_early;                // five-point root finder: 1 = stop at the noise floor, 0 = OpenCV's fixed 300 sweeps
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------------------------
@@ -156,7 +157,7 @@ void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
 void launch_triangulate_pairs(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);
 void launch_triangulate_raw(hipStream_t s, const double* P1, const double* P2, const double* x1, const double* x2,
                             int M, double* X);
-void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm);
+void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm, int dk_early);
 void launch_reprojection(hipStream_t s, const double* poses, int ncam, const double* points, int npt, const int* obs_cam,
                          const int* obs_pt, const double* obs_xy, int nobs, const double* Kd, double threshold,
                          double* sqerr, uint8_t* keep, int* bad);

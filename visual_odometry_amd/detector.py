@@ -6,6 +6,7 @@ src/frame_generator.py:25-26, src/image_and_keypoints.py:8,46).
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 
 import numpy as np
 
@@ -27,6 +28,7 @@ class OrbDetector:
         self.params = make_params(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType,
                                   patchSize, fastThreshold)
         self._ctx = ctx
+        self.truncated = False            # set by detectAndCompute: the last call hit a list capacity
 
     @property
     def ctx(self):
@@ -62,6 +64,11 @@ class OrbDetector:
         if mask is not None:
             raise NotImplementedError("detection masks are not supported (the reference always passes None)")
         a = self.detect_arrays(image)
+        # cv2 keeps every tie with the n-th response; this build's lists have a fixed capacity
+        self.truncated = a["truncated"]
+        if a["truncated"]:
+            warnings.warn("ORB candidate / keypoint capacity reached: the keypoint list was truncated in canonical order "
+                          "(cv2 would have kept every tie)", RuntimeWarning, stacklevel=2)
         kps = tuple(KeyPoint(x, y, s, an, r, o) for (x, y), s, an, r, o in
                     zip(a["xy"].tolist(), a["size"].tolist(), a["angle"].tolist(), a["response"].tolist(),
                         a["octave"].tolist()))
@@ -72,8 +79,11 @@ class OrbDetector:
         img = np.ascontiguousarray(image)
         h, w = img.shape[:2]
         ch = 1 if img.ndim == 2 else img.shape[2]
-        out = np.empty(int(h) * int(w) * 4, np.uint8)      # the pyramid is < 3.3x the base level for scale 1.2
         ctx = self.ctx
+        nbytes = int(ctx.lib.vo_packed_pyramid_bytes(int(h), int(w), C.addressof(self.params)))
+        if nbytes < 0:
+            raise ValueError("invalid ORB parameters for this image size")
+        out = np.empty(nbytes, np.uint8)
         ctx.check(getattr(ctx.lib, fn_name)(ctx.handle, img.ctypes.data, h, w, ch, img.strides[0],
                                             C.addressof(self.params), out.ctypes.data))
         return out

@@ -11,7 +11,7 @@ from . import _lib
 from .detector import make_params
 from .geometry import OPENCV_RNG_SEED
 
-MATCH_CROSSCHECK, MATCH_RATIO = 0, 1
+MATCH_CROSSCHECK, MATCH_RATIO, MATCH_CROSSCHECK_LEGACY = 0, 1, 2
 
 
 class FrontEnd:

@@ -24,9 +24,11 @@ def _desc(a):
 
 
 class HammingMatcher:
-    def __init__(self, crossCheck: bool = False, strict_mutual: bool = False, ctx: _lib.Context | None = None):
+    def __init__(self, crossCheck: bool = False, legacy_crosscheck: bool = False, ctx: _lib.Context | None = None):
+        # crossCheck=True is OpenCV 4.x's rule (opencv-python 4.7.0.72 is what the reference locks): mutual nearest
+        # neighbours.  legacy_crosscheck=True selects the older batchDistance rule without the forward test.
         self.crossCheck = bool(crossCheck)
-        self.strict_mutual = bool(strict_mutual)
+        self.legacy_crosscheck = bool(legacy_crosscheck)
         self._ctx = ctx
 
     @property
@@ -40,7 +42,7 @@ class HammingMatcher:
         nq = len(q)
         qi = np.empty(max(nq, 1), np.int32); ti = np.empty(max(nq, 1), np.int32); d = np.empty(max(nq, 1), np.float32)
         n = C.c_int32(0)
-        mode = 0 if not self.crossCheck else (2 if self.strict_mutual else 1)
+        mode = 0 if not self.crossCheck else (1 if self.legacy_crosscheck else 2)
         ctx = self.ctx
         ctx.check(ctx.lib.vo_match_hamming(ctx.handle, q.ctypes.data, nq, t.ctypes.data, len(t), mode,
                                            qi.ctypes.data, ti.ctypes.data, d.ctypes.data, C.addressof(n)))
