@@ -70,6 +70,13 @@ int vo_orb_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int
  * BASELINE.json's north_star names). */
 int vo_set_matcher_kernel(vo_ctx* ctx, int kind);
 
+/* Order of the keypoint list (and therefore of every keypoint / match index): 0 (default) = canonical (octave, y, x);
+ * 1 = cv2's — the permutation cv::KeyPointsFilter::retainBest's std::nth_element + std::partition leave behind, which
+ * is what makes `Feature.feature_id = (frame.id, idx)` (src/frame_generator.py:34-36) and DMatch.queryIdx / trainIdx
+ * (src/image_pair.py:243-252) the same numbers cv2 produces.  Same keypoint set, responses and descriptors either way;
+ * mode 1 costs an extra pass over every FAST corner of the frame.  Takes effect at the next detection. */
+int vo_set_keypoint_order(vo_ctx* ctx, int kind);
+
 /* How the five-point solver inside findEssentialMat finds the roots of its degree-10 polynomial (cv::solvePoly,
  * Durand-Kerner): 1 = OpenCV's fixed 300 sweeps, operation for operation; 0 (default) = the same sweeps, stopped per
  * sample once every correction is rounding noise (~20 sweeps; identical inlier masks, [R|t] equal to ~1e-12 on the
@@ -118,6 +125,9 @@ int vo_stage_fast_scores(vo_ctx* ctx, const uint8_t* img, int h, int w, int chan
                          const vo_orb_params* params, uint8_t* out_packed);
 int vo_stage_blur(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride,
                   const vo_orb_params* params, uint8_t* out_packed);
+/* cv::KeyPointsFilter::retainBest(keypoints, n_points) on a list of n responses: order (capacity n) receives the kept
+ * ORIGINAL indices in the order cv2 leaves them in */
+int vo_stage_retain_best(vo_ctx* ctx, const float* response, int n, int n_points, int32_t* order, int32_t* n_out);
 /* EMEstimatorCallback::runKernel on one 5-point sample of normalised coordinates */
 int vo_stage_five_point(vo_ctx* ctx, const double* x1, const double* x2, double* E /*10x9*/, int32_t* n_models);
 

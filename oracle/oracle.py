@@ -35,7 +35,7 @@ def orb_params(nfeatures=500, scale_factor=1.2, nlevels=8, edge_threshold=31, fi
 
 def build(force=False):
     so = os.path.join(_HERE, "libvoo.so")
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".cpp", ".h", ".inc"))]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libvoo.so"], stdout=subprocess.DEVNULL)
     return so
@@ -137,6 +137,19 @@ def orb_detect_and_compute(img, params, cap=None):
     n = n.value
     return dict(xy=xy[:n].copy(), size=size[:n].copy(), angle=ang[:n].copy(), response=resp[:n].copy(),
                 octave=octv[:n].copy(), desc=desc[:n].copy(), overflow=(rc == 1))
+
+
+def set_keypoint_order(order):
+    """'canonical' (default): keypoints in (octave, y, x) order; 'cv2': KeyPointsFilter::retainBest's libstdc++ order."""
+    lib().voo_set_keypoint_order({"canonical": 0, "cv2": 1}[order])
+
+
+def retain_best_cv2(response, n_points):
+    """cv::KeyPointsFilter::retainBest on a response list: the kept original indices in cv2's order."""
+    r = np.ascontiguousarray(response, np.float32)
+    out = np.zeros(max(len(r), 1), np.int32)
+    m = lib().voo_retain_best_cv2(_p(r, C.c_float), len(r), int(n_points), _p(out, C.c_int32))
+    return out[:m].copy()
 
 
 def match_hamming(q, t, cross_check=2):

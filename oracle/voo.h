@@ -51,6 +51,14 @@ int voo_orb_detect_and_compute(const uint8_t* img, int h, int w, int channels, i
                                float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
                                int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);
 
+/* Keypoint list order of voo_orb_detect_and_compute: 0 (default) = canonical (octave, y, x); 1 = cv2's, i.e. the
+ * permutation KeyPointsFilter::retainBest's std::nth_element + std::partition leave behind (voo_cv2order.cpp).  The
+ * keypoint SET, responses, angles and descriptors are the same in both orders.  Process-wide switch. */
+void voo_set_keypoint_order(int cv2_order);
+int  voo_get_keypoint_order(void);
+/* KeyPointsFilter::retainBest on a response list: writes the kept ORIGINAL indices in cv2's order, returns their count */
+int voo_retain_best_cv2(const float* response, int n, int n_points, int32_t* order);
+
 /* --- matcher ----------------------------------------------------------------- */
 /* cross_check: 0 = plain nearest neighbour; 2 = cv2 BFMatcher(crossCheck=True) as OpenCV 4.x's batchDistance
  * computes it (strict mutual nearest neighbours: `d < d0 && sidx[idx] == i`); 1 = the older reverse-NN update

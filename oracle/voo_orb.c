@@ -337,10 +337,24 @@ static int cmp_desc_f(const void* a, const void* b)
     return fa > fb ? -1 : (fa < fb ? 1 : 0);
 }
 
+static int g_cv2_order = 0;
+void voo_set_keypoint_order(int cv2_order) { g_cv2_order = cv2_order != 0; }
+int voo_get_keypoint_order(void) { return g_cv2_order; }
+
 static int retain_best(cand_t* c, int n, int n_points)
 {
     if (n_points < 0 || n <= n_points) return n;
     if (n_points == 0) return 0;
+    if (g_cv2_order) {                       /* the literal std::nth_element + std::partition permutation */
+        float* r = (float*)malloc(sizeof(float) * (size_t)n);
+        int32_t* ord = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+        cand_t* tmp = (cand_t*)malloc(sizeof(cand_t) * (size_t)n);
+        for (int i = 0; i < n; i++) { r[i] = c[i].resp; tmp[i] = c[i]; }
+        int m = voo_retain_best_cv2(r, n, n_points, ord);
+        for (int i = 0; i < m; i++) c[i] = tmp[ord[i]];
+        free(r); free(ord); free(tmp);
+        return m;
+    }
     float* r = (float*)malloc(sizeof(float) * (size_t)n);
     for (int i = 0; i < n; i++) r[i] = c[i].resp;
     qsort(r, (size_t)n, sizeof(float), cmp_desc_f);

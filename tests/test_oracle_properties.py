@@ -164,3 +164,93 @@ def test_unsupported_params_are_rejected(oracle, bad):
     kw = {bad: {"first_level": 1, "wta_k": 3, "patch_size": 21}[bad]}
     with pytest.raises(RuntimeError):
         oracle.orb_detect_and_compute(random_image(11, 100, 100), oracle.orb_params(**kw))
+
+
+def _introselect_py(a, nth):
+    """libstdc++'s std::nth_element(first, nth, last, greater) on a list of (response, id), restated sequentially in
+    Python from the algorithm's published description — a structurally independent check of the C++ oracle unit."""
+    def gt(x, y): return x[0] > y[0]
+
+    def adjust_heap(f0, hole, ln, v):
+        top, sc = hole, hole
+        while sc < (ln - 1) // 2:
+            sc = 2 * (sc + 1)
+            if gt(a[f0 + sc], a[f0 + sc - 1]): sc -= 1
+            a[f0 + hole] = a[f0 + sc]; hole = sc
+        if ln % 2 == 0 and sc == (ln - 2) // 2:
+            sc = 2 * (sc + 1); a[f0 + hole] = a[f0 + sc - 1]; hole = sc - 1
+        parent = (hole - 1) // 2
+        while hole > top and gt(a[f0 + parent], v):
+            a[f0 + hole] = a[f0 + parent]; hole = parent; parent = (hole - 1) // 2
+        a[f0 + hole] = v
+
+    first, last = 0, len(a)
+    if first == last or nth == last: return
+    depth = 2 * ((last - first).bit_length() - 1)
+    while last - first > 3:
+        if depth == 0:
+            ln = nth + 1 - first
+            if ln >= 2:
+                parent = (ln - 2) // 2
+                while True:
+                    adjust_heap(first, parent, ln, a[first + parent])
+                    if parent == 0: break
+                    parent -= 1
+            for i in range(nth + 1, last):
+                if gt(a[i], a[first]):
+                    v = a[i]; a[i] = a[first]; adjust_heap(first, 0, ln, v)
+            a[first], a[nth] = a[nth], a[first]
+            return
+        depth -= 1
+        A, B, C = first + 1, first + (last - first) // 2, last - 1
+        if gt(a[A], a[B]): m = B if gt(a[B], a[C]) else C if gt(a[A], a[C]) else A
+        else: m = A if gt(a[A], a[C]) else C if gt(a[B], a[C]) else B
+        a[first], a[m] = a[m], a[first]
+        f, l, p = first + 1, last, a[first]
+        while True:
+            while gt(a[f], p): f += 1
+            l -= 1
+            while gt(p, a[l]): l -= 1
+            if not f < l: break
+            a[f], a[l] = a[l], a[f]; f += 1
+        if f <= nth: first = f
+        else: last = f
+    for i in range(first + 1, last):
+        v = a[i]
+        if gt(v, a[first]):
+            a[first + 1:i + 1] = a[first:i]; a[first] = v
+        else:
+            nx = i - 1
+            while gt(v, a[nx]): a[nx + 1] = a[nx]; nx -= 1
+            a[nx + 1] = v
+
+
+def test_cv2_order_unit_is_libstdcxx_retain_best(oracle):
+    """oracle.retain_best_cv2 = cv::KeyPointsFilter::retainBest: nth_element, then partition of the tail by
+    `response >= n-th response` (every tie kept); compared with the Python restatement above and with the defining
+    properties of the result."""
+    rng = np.random.default_rng(11)
+    for it in range(400):
+        n = int(rng.integers(1, 400)); n_points = int(rng.integers(0, n + 3))
+        kind = it % 4
+        r = (rng.integers(0, 12, n) if kind == 0 else np.arange(n) if kind == 1 else
+             np.where(np.arange(n) < n // 2, np.arange(n), n - np.arange(n)) if kind == 2 else rng.normal(0, 1, n)).astype(np.float32)
+        got = oracle.retain_best_cv2(r, n_points)
+        if n <= n_points:
+            assert got.tolist() == list(range(n)); continue            # untouched
+        if n_points == 0:
+            assert len(got) == 0; continue
+        thr = np.sort(r)[::-1][n_points - 1]
+        assert sorted(got.tolist()) == np.nonzero(r >= thr)[0].tolist()    # the kept SET: everything at or above the n-th response
+        a = [(float(v), i) for i, v in enumerate(r)]
+        _introselect_py(a, n_points - 1)
+        amb = a[n_points - 1][0]
+        f, l = n_points, n                                              # std::partition(begin + n, end, response >= amb)
+        while True:
+            while f != l and a[f][0] >= amb: f += 1
+            if f == l: break
+            l -= 1
+            while f != l and not a[l][0] >= amb: l -= 1
+            if f == l: break
+            a[f], a[l] = a[l], a[f]; f += 1
+        assert got.tolist() == [i for _, i in a[:f]], (it, n, n_points)

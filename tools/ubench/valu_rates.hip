@@ -1,78 +1,147 @@
-// Micro-benchmark: wave64 issue rate of the VALU instructions the front-end kernels lean on (gfx950).
-// Each kernel runs a long unrolled chain of ONE instruction kind on independent registers; cycles per
-// wave-instruction = clock delta / count, measured with 1 and with 8 waves per SIMD.
+// Micro-benchmark: issue cost of the instructions the front-end kernels lean on (gfx950, wave64).
+//
+// Every measured instruction is an `asm volatile` statement, so the compiler can neither fold, fuse, hoist nor
+// re-select it (the round-1 version used C expressions; several of its rows were partly folded and one exceeded the
+// chip's physical rate).  A wave runs ITERS x 32 copies of ONE instruction on 16 independent destination registers
+// (dependent-issue latency is hidden: a register is rewritten every 16th instruction) between two s_memtime stamps.
+// With W waves resident per SIMD (256 CUs x 4 SIMDs x W waves, all co-resident) the SIMD's issue interval for that
+// instruction is  cycles(one wave) / (ITERS x 32) / W ... reported both ways, together with the wall-clock rate in
+// T lane-ops/s (64 lanes per wave-instruction; a packed instruction still counts as ONE instruction).
+// The physical ceiling if every wave64 instruction issued in 2 cycles: 256 x 4 x 32 x 2.4 GHz = 78.6 T lane-ops/s.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
-#define N_ITERS 512
-#define UNROLL 16
-typedef short s16x2 __attribute__((ext_vector_type(2)));
+#include <algorithm>
+
+#define ITERS 256
+#define PER_ITER 32
+
+#define R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int OP>
-__global__ void k(uint32_t* out, uint32_t seed, long long* cyc)
+__global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* cyc, uint32_t seed)
 {
-    uint32_t r[UNROLL];
+    __shared__ uint32_t lds[4096];
+    uint32_t r[16];
 #pragma unroll
-    for (int i = 0; i < UNROLL; i++) r[i] = seed * (i + 1) + threadIdx.x;
+    for (int i = 0; i < 16; i++) r[i] = seed * (i + 1) + threadIdx.x * 2654435761u;
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = seed + i;
+    __syncthreads();
     uint32_t a = seed ^ 0x9e3779b9u, b = seed * 7u + 1u;
-    long long t0 = clock64();
-    for (int it = 0; it < N_ITERS; it++) {
-#pragma unroll
-        for (int i = 0; i < UNROLL; i++) {
-            if (OP == 0) r[i] = r[i] ^ r[(i + 5) & 15];                          // v_xor_b32 (register operands)
-            if (OP == 1) r[i] = __popc(r[i]) + b;                                // v_bcnt_u32_b32 (accumulate form)
-            if (OP == 2) r[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, r[i]) - __builtin_bit_cast(s16x2, a));  // v_pk_sub_i16
-            if (OP == 3) r[i] = __builtin_amdgcn_perm(r[i], a, 0x0c050c03u);     // v_perm_b32
-            if (OP == 4) r[i] = __builtin_amdgcn_udot4(r[i], a, b, false);       // v_dot4_u32_u8
-            if (OP == 5) r[i] = __builtin_amdgcn_alignbyte(r[i], a, 1);          // v_alignbyte_b32
-            if (OP == 6) r[i] = min(r[i], a) + 1;                                // v_min_u32 + v_add (2 instrs)
-            if (OP == 7) r[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, r[i]), __builtin_bit_cast(s16x2, a)));  // v_pk_min_i16
-            if (OP == 8) r[i] = r[i] * 18u + b;                                  // v_mad_u32_u24 / mul_lo
-            if (OP == 9) r[i] = (r[i] >> 3) + r[(i + 3) & 15];                   // v_lshrrev + v_add (or v_lshl_add)
-            if (OP == 10) r[i] = (r[i] & a) | r[(i + 7) & 15];                   // v_and_or_b32 (1 instr)
-            if (OP == 11) r[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, r[i]), __builtin_bit_cast(s16x2, r[(i + 1) & 15])));  // v_pk_max_i16
-            if (OP == 12) { typedef unsigned short u16x2 __attribute__((ext_vector_type(2))); r[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, r[i]) >> (unsigned short)3) + 1u; }  // v_pk_lshrrev_b16 + add
-            if (OP == 13) r[i] = r[i] > a ? r[(i + 1) & 15] : b;                  // v_cmp + v_cndmask
-            if (OP == 14) r[i] = __builtin_amdgcn_sad_u8(r[i], a, b);            // v_sad_u8
-            if (OP == 15) r[i] = __builtin_amdgcn_ubfe(r[i], 8, 8) + b;          // v_bfe_u32 + add
-        }
+    uint32_t addr = (threadIdx.x * 4u) & 0x3ffcu;                       // conflict-free dword address
+    uint32_t baddr = (threadIdx.x * 37u + (threadIdx.x >> 3)) & 0x3fffu; // scattered byte address (FAST ring reads)
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    for (int it = 0; it < ITERS; it++) {
+#define ONE(i, str) asm volatile(str : "+v"(r[i]) : "v"(a), "v"(b), "v"(r[(i + 5) & 15]), "v"(addr), "v"(baddr));
+#define BODY(str) ONE(0, str) ONE(1, str) ONE(2, str) ONE(3, str) ONE(4, str) ONE(5, str) ONE(6, str) ONE(7, str) \
+                  ONE(8, str) ONE(9, str) ONE(10, str) ONE(11, str) ONE(12, str) ONE(13, str) ONE(14, str) ONE(15, str)
+        if (OP == 0)  { BODY("v_xor_b32 %0, %0, %1") BODY("v_xor_b32 %0, %0, %2") }
+        if (OP == 1)  { BODY("v_add_u32 %0, %0, %1") BODY("v_add_u32 %0, %0, %2") }
+        if (OP == 2)  { BODY("v_pk_sub_i16 %0, %0, %1") BODY("v_pk_sub_i16 %0, %0, %2") }
+        if (OP == 3)  { BODY("v_pk_min_i16 %0, %0, %3") BODY("v_pk_min_i16 %0, %0, %3") }
+        if (OP == 4)  { BODY("v_pk_max_i16 %0, %0, %3") BODY("v_pk_max_i16 %0, %0, %3") }
+        if (OP == 5)  { BODY("v_perm_b32 %0, %0, %1, %2") BODY("v_perm_b32 %0, %0, %3, %2") }
+        if (OP == 6)  { BODY("v_alignbit_b32 %0, %0, %3, 16") BODY("v_alignbit_b32 %0, %0, %3, 16") }
+        if (OP == 7)  { BODY("v_alignbyte_b32 %0, %0, %3, 1") BODY("v_alignbyte_b32 %0, %0, %3, 1") }
+        if (OP == 8)  { BODY("v_dot4_u32_u8 %0, %3, %1, %0") BODY("v_dot4_u32_u8 %0, %3, %2, %0") }
+        if (OP == 9)  { BODY("v_dot2_u32_u16 %0, %3, %1, %0") BODY("v_dot2_u32_u16 %0, %3, %2, %0") }
+        if (OP == 10) { BODY("v_lshl_or_b32 %0, %0, 16, %3") BODY("v_lshl_or_b32 %0, %0, 16, %3") }
+        if (OP == 11) { BODY("v_and_or_b32 %0, %0, %1, %3") BODY("v_and_or_b32 %0, %0, %1, %3") }
+        if (OP == 12) { BODY("v_bcnt_u32_b32 %0, %3, %0") BODY("v_bcnt_u32_b32 %0, %3, %0") }
+        if (OP == 13) { BODY("v_min_u32 %0, %0, %3") BODY("v_max_u32 %0, %0, %3") }
+        if (OP == 14) { BODY("v_mad_u32_u24 %0, %0, %1, %3") BODY("v_mad_u32_u24 %0, %0, %1, %3") }
+        if (OP == 15) { BODY("v_mbcnt_lo_u32_b32 %0, %1, %0") BODY("v_mbcnt_hi_u32_b32 %0, %2, %0") }
+        if (OP == 16) { BODY("v_cndmask_b32 %0, %0, %3, vcc") BODY("v_cndmask_b32 %0, %0, %3, vcc") }
+        if (OP == 17) { BODY("v_pk_mul_lo_u16 %0, %0, %3") BODY("v_pk_mul_lo_u16 %0, %0, %3") }
+        if (OP == 18) { BODY("v_pk_add_u16 %0, %0, %3") BODY("v_pk_add_u16 %0, %0, %3") }
+        if (OP == 19) { BODY("v_bfe_u32 %0, %3, 8, 8") BODY("v_bfe_u32 %0, %3, 16, 8") }
+        if (OP == 20) { BODY("v_mov_b32 %0, %3") BODY("v_mov_b32 %0, %3") }
+        if (OP == 21) { BODY("v_add_f32 %0, %0, %3") BODY("v_add_f32 %0, %0, %3") }
+        if (OP == 22) { BODY("v_fma_f32 %0, %0, %1, %3") BODY("v_fma_f32 %0, %0, %1, %3") }
+        if (OP == 23) { BODY("v_pk_fma_f32 %0, %0, %1, %3") }              // 64-bit operands: handled below
+        if (OP == 24) { BODY("ds_read_b32 %0, %4") BODY("ds_read_b32 %0, %4 offset:256") asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        if (OP == 25) { BODY("ds_read_u8 %0, %5") BODY("ds_read_u8 %0, %5 offset:160") asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        if (OP == 26) { BODY("v_max3_i32 %0, %0, %1, %3") BODY("v_min3_i32 %0, %0, %1, %3") }
+        if (OP == 27) { BODY("v_sad_u8 %0, %0, %1, %3") BODY("v_sad_u8 %0, %0, %1, %3") }
+        if (OP == 28) { BODY("v_cmp_gt_u32 vcc, %0, %3") BODY("v_cmp_gt_i32 vcc, %0, %3") }
+        if (OP == 29) { BODY("v_pk_lshrrev_b16 %0, 3, %0") BODY("v_pk_ashrrev_i16 %0, 3, %0") }
+        if (OP == 30) { BODY("v_add3_u32 %0, %0, %1, %3") BODY("v_or3_b32 %0, %0, %1, %3") }
+        if (OP == 31) { BODY("v_cmp_gt_u16_sdwa vcc, %0, %3 src0_sel:BYTE_0 src1_sel:BYTE_1") BODY("v_and_b32_sdwa %0, %0, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD") }
+#undef BODY
+#undef ONE
     }
-    long long t1 = clock64();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
     uint32_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < UNROLL; i++) acc ^= r[i];
+    for (int i = 0; i < 16; i++) acc ^= r[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
-    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int OP>
-void run(const char* name, int instrs_per_op)
+// v_pk_fma_f32 needs 64-bit register pairs: its own kernel
+__global__ __launch_bounds__(256) void k_pkfma(float* out, unsigned long long* cyc, float seed)
 {
-    uint32_t* out; long long* cyc;
-    hipMalloc(&out, 256 * 2048 * 4 * sizeof(uint32_t)); hipMalloc(&cyc, 8);
-    for (int waves_per_simd : {1, 8}) {
-        // 256 CUs x 4 SIMDs: blocks of 256 threads (1 wave per SIMD each); `waves_per_simd` blocks per CU
-        int blocks = 256 * waves_per_simd;
-        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 12345u, cyc);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 r[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) r[i] = (f2){seed * (i + 1), seed + threadIdx.x};
+    f2 a = {1.0001f, 0.9999f}, b = {1e-3f, -1e-3f};
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    f2 acc = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += r[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x + acc.y;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+static uint32_t* g_out; static unsigned long long* g_cyc;
+
+template <typename L>
+static void measure(const char* name, L launch)
+{
+    for (int w : {1, 2, 4, 8}) {
+        const int blocks = 256 * w;                                    // 256-thread blocks: one wave per SIMD each
+        launch(blocks);
         hipDeviceSynchronize();
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 12345u, cyc);
+        launch(blocks);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-        double n = (double)N_ITERS * UNROLL * instrs_per_op;
-        printf("%-28s waves/SIMD %d: %6.2f clk per wave-instr (in-kernel), %7.3f ms, %6.2f Tlane-op/s\n", name, waves_per_simd,
-               c / n, ms, n * 64.0 * blocks * 4 / (ms * 1e-3) / 1e12);
+        std::vector<unsigned long long> c(blocks * 4);
+        hipMemcpy(c.data(), g_cyc, c.size() * 8, hipMemcpyDeviceToHost);
+        std::sort(c.begin(), c.end());
+        const double n = (double)ITERS * PER_ITER;
+        const double med = (double)c[c.size() / 2];
+        printf("%-34s W=%d  %6.2f clk/instr seen by a wave  %5.2f clk SIMD issue interval  %7.3f ms  %6.2f Tlane-op/s\n",
+               name, w, med / n, med / n / w, ms, n * 64.0 * blocks * 4 / (ms * 1e-3) / 1e12);
+        hipEventDestroy(e0); hipEventDestroy(e1);
     }
 }
 
+#define RUN(op, name) measure(name, [](int blocks) { hipLaunchKernelGGL(k<op>, dim3(blocks), dim3(256), 0, 0, g_out, g_cyc, 12345u); })
+
 int main()
 {
-    run<0>("v_xor_b32", 1); run<1>("v_bcnt_u32_b32 (+acc)", 1); run<2>("v_pk_sub_i16", 1); run<3>("v_perm_b32", 1);
-    run<4>("v_dot4_u32_u8", 1); run<5>("v_alignbyte_b32", 1); run<6>("v_min_u32 + v_add", 2); run<7>("v_pk_min_i16", 1);
-    run<8>("v_mad_u32_u24 / mul+add", 1); run<9>("v_lshrrev + v_add", 2); run<10>("v_and_or_b32", 1);
-    run<11>("v_pk_max_i16", 1); run<12>("v_pk_lshrrev_b16 + v_add", 2); run<13>("v_cmp + v_cndmask", 2);
-    run<14>("v_sad_u8", 1); run<15>("v_bfe_u32 + v_add", 2);
+    hipMalloc(&g_out, 256 * 8 * 256 * sizeof(uint32_t)); hipMalloc(&g_cyc, 256 * 8 * 4 * 8);
+    RUN(0, "v_xor_b32"); RUN(1, "v_add_u32"); RUN(20, "v_mov_b32"); RUN(13, "v_min_u32 / v_max_u32"); RUN(26, "v_max3_i32 / v_min3_i32");
+    RUN(30, "v_add3_u32 / v_or3_b32"); RUN(10, "v_lshl_or_b32"); RUN(11, "v_and_or_b32"); RUN(19, "v_bfe_u32");
+    RUN(5, "v_perm_b32"); RUN(6, "v_alignbit_b32"); RUN(7, "v_alignbyte_b32"); RUN(12, "v_bcnt_u32_b32"); RUN(15, "v_mbcnt_lo / v_mbcnt_hi");
+    RUN(14, "v_mad_u32_u24"); RUN(27, "v_sad_u8"); RUN(8, "v_dot4_u32_u8"); RUN(9, "v_dot2_u32_u16");
+    RUN(2, "v_pk_sub_i16"); RUN(18, "v_pk_add_u16"); RUN(3, "v_pk_min_i16"); RUN(4, "v_pk_max_i16"); RUN(17, "v_pk_mul_lo_u16"); RUN(29, "v_pk_lshrrev_b16 / v_pk_ashrrev_i16");
+    RUN(16, "v_cndmask_b32 (vcc)"); RUN(28, "v_cmp_gt_u32 / v_cmp_gt_i32 -> vcc"); RUN(31, "v_cmp_gt_u16_sdwa / v_and_b32_sdwa");
+    RUN(21, "v_add_f32"); RUN(22, "v_fma_f32");
+    measure("v_pk_fma_f32", [](int blocks) { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(256), 0, 0, (float*)g_out, g_cyc, 1.5f); });
+    RUN(24, "ds_read_b32 (conflict-free)"); RUN(25, "ds_read_u8 (scattered bytes)");
     return 0;
 }

@@ -67,6 +67,8 @@ _SIGS = {
     "vo_sync": (C.c_int, [_P]),
     "vo_set_matcher_kernel": (C.c_int, [_P, C.c_int]),
     "vo_set_poly_solver": (C.c_int, [_P, C.c_int]),
+    "vo_set_keypoint_order": (C.c_int, [_P, C.c_int]),
+    "vo_stage_retain_best": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vo_detect_after": (C.c_int, [_P, _P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
@@ -140,6 +142,19 @@ class Context:
     def set_matcher_kernel(self, kind):
         """'mfma' (default) or 'popcount': which kernel computes the Hamming nearest neighbours (same results)."""
         self.check(self.lib.vo_set_matcher_kernel(self.handle, {"mfma": 0, "popcount": 1}[kind]))
+
+    def set_keypoint_order(self, kind):
+        """'canonical' (default): keypoints in (octave, y, x) order; 'cv2': the order cv2.ORB returns them in
+        (KeyPointsFilter::retainBest's libstdc++ permutation), so keypoint and match indices equal cv2's."""
+        self.check(self.lib.vo_set_keypoint_order(self.handle, {"canonical": 0, "cv2": 1}[kind]))
+
+    def retain_best(self, response, n_points):
+        """cv::KeyPointsFilter::retainBest on a response list: the kept original indices in cv2's order."""
+        r = np.ascontiguousarray(response, np.float32)
+        out = np.zeros(max(len(r), 1), np.int32)
+        n = C.c_int32(0)
+        self.check(self.lib.vo_stage_retain_best(self.handle, r.ctypes.data, len(r), int(n_points), out.ctypes.data, C.addressof(n)))
+        return out[:n.value].copy()
 
     def set_poly_solver(self, kind):
         """'fast' (default): Durand-Kerner sweeps stop at the rounding-noise floor; 'opencv300': cv::solvePoly's fixed

@@ -699,6 +699,22 @@ void launch_select_fast(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, in
     hipLaunchKernelGGL(k_sel_rows<true>, dim3(g.sel_chunks_total, F), dim3(64), (size_t)cap * 8, s, tile_list, tile_count, g, ff, thr, chunk_count, cap);
 }
 
+// cv2-order mode: the same two kernels with threshold 1 and the all-winner list geometry give the raster-ordered list
+// of every NMS winner inside the border, which is what cv2's first retainBest permutes (cv2order_kernels.hip)
+void launch_all_winners(hipStream_t s, const PyrGeom& g, FrameFeat ff, const Cv2Buf& cb, int F, const uint32_t* tile_list, const int* tile_count)
+{
+    if (g.sel_chunks_total <= 0) return;
+    PyrGeom ga = g;
+    int cap = 0;
+    for (int l = 0; l < g.nlevels; l++) { ga.lv[l].cand_off = cb.all_off[l]; ga.lv[l].cand_cap = cb.all_cap[l]; cap = cb.all_cap[l] > cap ? cb.all_cap[l] : cap; }
+    ga.cand_total = cb.all_total;
+    FrameFeat fa = ff;
+    fa.cand_pos = cb.all_pos; fa.cand_resp = cb.all_resp; fa.cand_count = cb.all_count;
+    if (cap > 7680) cap = 7680;                       // a row of FAST tiles holding more winners is truncated and flagged
+    hipLaunchKernelGGL(k_sel_rows<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, tile_list, tile_count, ga, fa, cb.ones, cb.chunk_count, cap);
+    hipLaunchKernelGGL(k_sel_rows<true>, dim3(g.sel_chunks_total, F), dim3(64), (size_t)cap * 8, s, tile_list, tile_count, ga, fa, cb.ones, cb.chunk_count, cap);
+}
+
 // ------------------------------------------------------------------ Harris response (orb.cpp HarrisResponses)
 // One lane per candidate; the 9x9 neighbourhood is fetched as 9 rows x 3 unaligned dwords and kept in
 // registers, the 49 Sobel pairs are evaluated from there (no per-tap memory access).

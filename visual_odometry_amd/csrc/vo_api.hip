@@ -51,6 +51,9 @@ struct vo_ctx {
     hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
     bool ev_det_set = false;
     int matcher_kernel = 0;               // 0: int8 MFMA on +1/-1 bytes (default), 1: XOR + popcount
+    int kp_order = 0;                     // 0: canonical (octave, y, x) keypoint order, 1: cv2's retainBest order
+    Cv2Buf cv2{};
+    bool cv2_ready = false;
     int dk_early = 1;                     // five-point polynomial roots: 1 = noise-floor exit (default), 0 = fixed 300 sweeps
 };
 
@@ -215,8 +218,45 @@ static hipError_t alloc_pairbuf(PairBuf& pb, int P, int cap, bool with_pose_mask
     return hipSuccess;
 }
 
+static void free_cv2(vo_ctx* c)
+{
+    void* ptrs[] = {c->cv2.all_pos, c->cv2.all_resp, c->cv2.all_count, c->cv2.chunk_count, c->cv2.ones, c->cv2.work, c->cv2.lpos, c->cv2.rpos};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    memset(&c->cv2, 0, sizeof(c->cv2));
+    c->cv2_ready = false;
+}
+
+// all-winner lists + work arrays of the cv2 order mode for the current configuration.  Capacity per level: an eighth
+// of its pixels (natural images leave 1 - 4 % of the pixels as FAST corners; 3x3 NMS allows at most a quarter).
+static int alloc_cv2(vo_ctx* ctx)
+{
+    if (ctx->cv2_ready) return VO_OK;
+    const PyrGeom& g = ctx->g;
+    Cv2Buf& cb = ctx->cv2;
+    int off = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int px8 = g.lv[l].w * g.lv[l].h / 8 + 1024;
+        cb.all_off[l] = off;
+        cb.all_cap[l] = align_up(px8 > g.lv[l].cand_cap ? px8 : g.lv[l].cand_cap, 8);
+        off += cb.all_cap[l];
+    }
+    cb.all_total = off;
+    const size_t F = (size_t)ctx->max_frames, n = F * off;
+    HIPCHK(dmalloc(&cb.all_pos, n)); HIPCHK(dmalloc(&cb.all_resp, n)); HIPCHK(dmalloc(&cb.work, n));
+    HIPCHK(dmalloc(&cb.lpos, n)); HIPCHK(dmalloc(&cb.rpos, n));
+    HIPCHK(dmalloc(&cb.all_count, F * VO_MAX_LEVELS)); HIPCHK(dmalloc(&cb.ones, F * VO_MAX_LEVELS));
+    HIPCHK(dmalloc(&cb.chunk_count, F * (size_t)(g.sel_chunks_total + 1)));
+    std::vector<int> ones(F * VO_MAX_LEVELS, 1);
+    HIPCHK(hipMemcpy(cb.ones, ones.data(), ones.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(cb.all_count, 0, F * VO_MAX_LEVELS * sizeof(int)));
+    HIPCHK(hipDeviceSynchronize());
+    ctx->cv2_ready = true;
+    return VO_OK;
+}
+
 static void free_config(vo_ctx* c)
 {
+    free_cv2(c);
     void* ptrs[] = {c->tab_mem, c->pyr, c->blur, c->score, c->ff.cand_pos, c->ff.cand_resp, c->ff.cand_count,
                     c->ff.kp_pos, c->ff.kp_level, c->ff.kp_resp, c->ff.kp_angle, c->ff.kp_xy, c->ff.kp_size,
                     c->ff.desc, c->ff.kp_count, c->ff.flags, c->ff.hist, c->ff.tile_list, c->ff.tile_count, c->sel_thr, c->sel_chunk_count, c->har_kept, c->har_thr, c->desc_x};
@@ -272,6 +312,19 @@ extern "C" int vo_set_matcher_kernel(vo_ctx* ctx, int kind)
     if (!ctx) return VO_ERR_INVALID;
     if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "matcher kernel must be 0 (MFMA) or 1 (XOR + popcount)");
     ctx->matcher_kernel = kind;
+    return VO_OK;
+}
+
+extern "C" int vo_set_keypoint_order(vo_ctx* ctx, int kind)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "keypoint order must be 0 (canonical) or 1 (cv2)");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->kp_order = kind;
+    if (kind == 1 && ctx->configured && !ctx->cv2_ready) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return alloc_cv2(ctx);
+    }
     return VO_OK;
 }
 
@@ -365,6 +418,7 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     ctx->pb_pairs = max_pairs; ctx->pb_cap = g.kp_cap;
     HIPCHK(hipDeviceSynchronize());                         // the initialising memsets ran on the NULL stream
     ctx->configured = true;
+    if (ctx->kp_order == 1) { rc = alloc_cv2(ctx); if (rc) return rc; }
     return VO_OK;
 }
 
@@ -471,6 +525,17 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     { StageTimer t(ctx, ST_SELECT_FAST); launch_select_fast(s, g, ff, F, ctx->sel_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->sel_chunk_count + (size_t)first_slot * g.sel_chunks_total, ff.tile_list, ff.tile_count); }
     if (g.score_type == 0) { StageTimer t(ctx, ST_HARRIS); launch_harris(s, pyr, g, ff, F); }
     { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F, ctx->har_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->har_kept + (size_t)first_slot * VO_MAX_LEVELS); }
+    if (ctx->kp_order == 1 && ctx->cv2_ready) {
+        // cv2's list order: permute every level's keypoints the way retainBest's nth_element / partition leave them
+        StageTimer t(ctx, ST_MISC);
+        Cv2Buf cb = ctx->cv2;
+        const size_t fo = (size_t)first_slot;
+        cb.all_pos += fo * cb.all_total; cb.all_resp += fo * cb.all_total; cb.work += fo * cb.all_total;
+        cb.lpos += fo * cb.all_total; cb.rpos += fo * cb.all_total;
+        cb.all_count += fo * VO_MAX_LEVELS; cb.ones += fo * VO_MAX_LEVELS; cb.chunk_count += fo * g.sel_chunks_total;
+        launch_all_winners(s, g, ff, cb, F, ff.tile_list, ff.tile_count);
+        launch_cv2_order(s, g, ff, cb, F, ctx->har_kept + fo * VO_MAX_LEVELS);
+    }
     { StageTimer t(ctx, ST_ANGLE); launch_angle(s, pyr, g, ff, F); }
     { StageTimer t(ctx, ST_BLUR); launch_blur(s, pyr, blur, g, F); }
     {
@@ -1044,6 +1109,33 @@ extern "C" int vo_stage_five_point(vo_ctx* ctx, const double* x1, const double* 
     HIPCHK(hipStreamSynchronize(s));
     *n_models = nm;
     if (nm > 0) HIPCHK(hipMemcpy(E, d + 20, (size_t)nm * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    return VO_OK;
+}
+
+// KeyPointsFilter::retainBest on one response list (the stage the cv2 order mode is built from): order receives the
+// kept original indices in cv2's order
+extern "C" int vo_stage_retain_best(vo_ctx* ctx, const float* response, int n, int n_points, int32_t* order, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (n < 0 || !n_out || (n > 0 && (!response || !order))) FAIL(VO_ERR_INVALID, "bad arguments");
+    *n_out = 0;
+    if (n == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_raw_d(ctx, (size_t)3 * n + 64);                 // floats + uint2 work + lpos + rpos + order, in doubles
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    uint2* work = (uint2*)ctx->raw_d;
+    float* dresp = (float*)(work + n);
+    uint32_t* lpos = (uint32_t*)(dresp + n); uint32_t* rpos = lpos + n;
+    int* dorder = (int*)(rpos + n); int* dn = dorder + n;
+    HIPCHK(hipMemcpyAsync(dresp, response, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_retain_raw(s, dresp, n, n_points, work, lpos, rpos, dorder, dn);
+    HIPCHK(hipGetLastError());
+    int m = 0;
+    HIPCHK(hipMemcpyAsync(&m, dn, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_out = m;
+    if (m > 0) HIPCHK(hipMemcpy(order, dorder, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
     return VO_OK;
 }
 

@@ -76,6 +76,21 @@ struct FrameFeat {
     int*      tile_count; // [F][ftiles_total]
 };
 
+// cv2 keypoint order (vo_set_keypoint_order(ctx, 1)): per frame and level the raster-ordered list of ALL NMS winners
+// inside the border (cv2 runs retainBest on that list) and the work arrays of the re-enacted std::nth_element /
+// std::partition (cv2order_kernels.hip)
+struct Cv2Buf {
+    uint32_t* all_pos;    // [F][all_total]  (y << 16 | x)
+    float*    all_resp;   // [F][all_total]  FAST score
+    int*      all_count;  // [F][VO_MAX_LEVELS]
+    int*      chunk_count;// [F][sel_chunks_total + 1]
+    int*      ones;       // [F][VO_MAX_LEVELS] selection threshold 1 = keep every listed winner
+    uint2*    work;       // [F][all_total]  (response bits, index into the all-list)
+    uint32_t* lpos;       // [F][all_total]  positions where the left / right cursor of a partition pass stops
+    uint32_t* rpos;
+    int all_off[VO_MAX_LEVELS], all_cap[VO_MAX_LEVELS], all_total;
+};
+
 // per-pair arrays (device), P = number of pairs
 struct PairBuf {
     int*      slots;      // [P][2]
@@ -120,6 +135,11 @@ void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hi
 void launch_select_fast(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count,
                         const uint32_t* tile_list, const int* tile_count);
 void launch_harris(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
+// raster-ordered list of every NMS winner inside the border (the list cv2's first retainBest sees), per level
+void launch_all_winners(hipStream_t s, const PyrGeom& g, FrameFeat ff, const Cv2Buf& cb, int F, const uint32_t* tile_list, const int* tile_count);
+void launch_cv2_order(hipStream_t s, const PyrGeom& g, FrameFeat ff, Cv2Buf cb, int F, const int* kept);
+void launch_retain_raw(hipStream_t s, const float* resp, int n, int n_points, uint2* a, uint32_t* lpos, uint32_t* rpos,
+                       int* order, int* n_out);
 void launch_select_harris(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, float* thr, int* kept);
 void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat ff, int F);
 void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, int cn, int sstride, int64_t sframe,

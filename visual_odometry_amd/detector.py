@@ -24,10 +24,14 @@ def make_params(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, fir
 
 class OrbDetector:
     def __init__(self, nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, WTA_K=2,
-                 scoreType=HARRIS_SCORE, patchSize=31, fastThreshold=20, ctx: _lib.Context | None = None):
+                 scoreType=HARRIS_SCORE, patchSize=31, fastThreshold=20, ctx: _lib.Context | None = None,
+                 keypoint_order: str = "canonical"):
         self.params = make_params(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType,
                                   patchSize, fastThreshold)
         self._ctx = ctx
+        if keypoint_order not in ("canonical", "cv2"):
+            raise ValueError("keypoint_order must be 'canonical' or 'cv2'")
+        self.keypoint_order = keypoint_order   # 'cv2': the list order (hence every keypoint / match index) cv2.ORB returns
         self.truncated = False            # set by detectAndCompute: the last call hit a list capacity
 
     @property
@@ -52,6 +56,7 @@ class OrbDetector:
         resp = np.empty(cap, np.float32); octv = np.empty(cap, np.int32); desc = np.empty((cap, 32), np.uint8)
         n = C.c_int32(0)
         ctx = self.ctx
+        ctx.set_keypoint_order(self.keypoint_order)
         rc = ctx.check(ctx.lib.vo_orb_detect_and_compute(
             ctx.handle, img.ctypes.data, h, w, ch, img.strides[0], C.addressof(self.params),
             xy.ctypes.data, size.ctypes.data, ang.ctypes.data, resp.ctypes.data, octv.ctypes.data,
@@ -98,7 +103,7 @@ class OrbDetector:
 
 
 def ORB_create(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, WTA_K=2,
-               scoreType=HARRIS_SCORE, patchSize=31, fastThreshold=20) -> OrbDetector:
-    """cv2.ORB_create look-alike."""
+               scoreType=HARRIS_SCORE, patchSize=31, fastThreshold=20, keypoint_order="canonical") -> OrbDetector:
+    """cv2.ORB_create look-alike.  keypoint_order='cv2' returns the keypoints in cv2's own list order."""
     return OrbDetector(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize,
-                       fastThreshold)
+                       fastThreshold, keypoint_order=keypoint_order)

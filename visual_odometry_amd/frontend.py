@@ -15,8 +15,10 @@ MATCH_CROSSCHECK, MATCH_RATIO, MATCH_CROSSCHECK_LEGACY = 0, 1, 2
 
 
 class FrontEnd:
-    def __init__(self, height, width, max_frames, max_pairs, nfeatures=500, nlevels=8, device=0, ctx=None, **orb_kw):
+    def __init__(self, height, width, max_frames, max_pairs, nfeatures=500, nlevels=8, device=0, ctx=None,
+                 keypoint_order="canonical", **orb_kw):
         self.ctx = ctx or _lib.Context(device)
+        self.ctx.set_keypoint_order(keypoint_order)       # 'cv2': keypoint / match indices as cv2.ORB + BFMatcher number them
         self.h, self.w = int(height), int(width)
         self.max_frames, self.max_pairs = int(max_frames), int(max_pairs)
         self.params = make_params(nfeatures=nfeatures, nlevels=nlevels, **orb_kw)
