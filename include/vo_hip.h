@@ -194,6 +194,22 @@ int vo_detect_after(vo_ctx* ctx, vo_ctx* other);
 int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* dist, uint8_t* inlier_mask,
                     int cap, int32_t* n_out);
 
+/* ------------------------------------------------------------------ multi-GPU: the trajectory gather
+ * One process per GPU, every rank runs its own block of independent pairs (visual_odometry_amd/sharding.py); the only
+ * exchange is ONE all-gather of the per-pair records at the end of a batch: VO_RECORD_DOUBLES float64 per pair =
+ * R (9, row-major), t (3), n_kp1, n_match, n_inl (or the negative status of a failed pair), n_good.  RCCL is bound at
+ * run time.  vo_comm_unique_id on rank 0, hand the 128 bytes to every rank by any host channel, vo_comm_init on all. */
+#define VO_COMM_ID_BYTES 128
+#define VO_RECORD_DOUBLES 16
+int vo_comm_unique_id(uint8_t id[VO_COMM_ID_BYTES]);
+int vo_comm_init(vo_ctx* ctx, const uint8_t id[VO_COMM_ID_BYTES], int rank, int world);
+int vo_comm_destroy(vo_ctx* ctx);
+/* Packs the records of the first B pairs of the most recent vo_pairs_run[_async] on the device and all-gathers them
+ * over RCCL on the ctx stream (every rank must pass the same B; pad short blocks).  gathered (host, page-locked for
+ * the asynchronous form, world * B * VO_RECORD_DOUBLES doubles, rank-major) is valid after the call (wait != 0) or
+ * after the next vo_sync(ctx).  Without vo_comm_init (single process) it degenerates to the local records. */
+int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait);
+
 /* ------------------------------------------------------------------ "next" row
  * Map.remove_observations_with_reprojection_errors_above_threshold / calculate_reprojection_error —
  * src/map.py:46-94.  poses: ncam x 16 (row-major 4x4, TrackedCamera.pose()), points: npt x 3, observation i =

@@ -72,6 +72,7 @@ int voo_knn2_ratio_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, d
 /* cv::solvePoly inside the five-point solver: 0 (default) = OpenCV's fixed 300 Durand-Kerner sweeps, 1 = stop at the
  * rounding-noise floor exactly as the HIP kernel's throughput mode does (process-wide switch, not thread safe) */
 void voo_set_dk_early_exit(int on);
+void voo_dk_sweep_histogram(long long* out /*302*/, int reset);   /* diagnostic: sweeps per five-point sample */
 int  voo_get_dk_early_exit(void);
 int voo_find_essential_ransac(const double* p1, const double* p2, int M, const double* K,
                               double prob, double thresh_px, int max_iters, uint64_t seed,

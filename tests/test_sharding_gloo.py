@@ -53,3 +53,75 @@ def test_gather_world_size_2_gloo():
     assert outs[0].shape == (11, 16)
     assert np.array_equal(outs[0][:, 9], np.arange(11))  # in global pair order
     assert np.array_equal(outs[0][:, 12], 2000 + np.arange(11))
+
+
+def _driver_worker(rank, world, port, q, n_items, chunk):
+    """The N > 1 driver loop (sharding.run_sharded) with stand-in per-pair results: record k of the sequence encodes its
+    own global pair id and the two frame ids it was computed from, so halo handling and global order are checkable."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from visual_odometry_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames_touched = set()
+    calls = []
+
+    def process_chunk(lo, hi):                            # a sequence block: frames lo .. hi inclusive (hi = halo)
+        calls.append((lo, hi))
+        frames_touched.update(range(lo, hi + 1))
+        rec = np.zeros((hi - lo, sharding.RECORD_WIDTH))
+        for i, g in enumerate(range(lo, hi)):
+            rec[i, :9] = np.eye(3).ravel(); rec[i, 9:12] = [1.0, 0.0, 0.0]
+            rec[i, 12] = g; rec[i, 13] = g + 1; rec[i, 14] = 100 + g; rec[i, 15] = rank
+        return rec
+
+    def gather_chunk(rec):
+        out = torch.empty((world * chunk, sharding.RECORD_WIDTH), dtype=torch.float64)
+        dist.all_gather_into_tensor(out, torch.from_numpy(rec))
+        return out.numpy().reshape(world, chunk, sharding.RECORD_WIDTH)
+
+    allrec = sharding.run_sharded(n_items, rank, world, chunk, process_chunk, gather_chunk)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, allrec, sorted(frames_touched), calls))
+
+
+@pytest.mark.parametrize("n_frames,chunk", [(24, 4), (11, 8), (3, 4)])
+def test_sharded_sequence_driver_world_size_2_gloo(n_frames, chunk):
+    import torch.multiprocessing as mp
+    from visual_odometry_amd import sharding
+    n_items = n_frames - 1
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 2, port, q, n_items, chunk)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, rec, touched, calls = q.get(timeout=120)
+        got[r] = (rec, touched, calls)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0][0], got[1][0])                           # every rank ends with the whole record table
+    rec = got[0][0]
+    assert rec.shape == (n_items, 16) and np.array_equal(rec[:, 12], np.arange(n_items))    # global pair order
+    assert np.array_equal(rec[:, 13], np.arange(n_items) + 1)             # pair g was computed from frames (g, g + 1)
+    for r in range(2):
+        lo, hi, flo, fhi = sharding.sequence_shard(n_frames, r, 2)
+        assert np.all(rec[lo:hi, 15] == r)                                # ... by the rank that owns it
+        assert got[r][1] == list(range(flo, fhi))                         # its own frames plus exactly one halo frame
+        assert all(b - a <= chunk for a, b in got[r][2])
+    centres, bad = sharding.records_to_trajectory(rec)
+    assert bad == 0 and np.allclose(centres[-1], [-n_items, 0, 0])       # x_{k+1} = x_k + (1,0,0): the camera moves along -x
+
+
+def test_ate_alignment_removes_similarity():
+    from visual_odometry_amd.sharding import ate_after_alignment
+    rng = np.random.default_rng(0)
+    p = np.cumsum(rng.normal(size=(50, 3)), axis=0)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    assert ate_after_alignment(2.5 * p @ q.T + [3, -1, 2], p) < 1e-9
+    assert ate_after_alignment(p + rng.normal(0, 0.1, p.shape), p) > 0.05

@@ -17,6 +17,7 @@ VO_OK, VO_WARN_CAPACITY = 0, 1
 VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL, VO_ERR_NOT_CONFIGURED, VO_ERR_AMBIGUOUS = -1, -2, -3, -4, -5, -6
 VO_ERR_UNSUPPORTED = -7
 VO_STAGE_COUNT = 16
+VO_COMM_ID_BYTES, VO_RECORD_DOUBLES = 128, 16
 
 
 class OrbParams(C.Structure):
@@ -70,6 +71,10 @@ _SIGS = {
     "vo_set_keypoint_order": (C.c_int, [_P, C.c_int]),
     "vo_stage_retain_best": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vo_detect_after": (C.c_int, [_P, _P]),
+    "vo_comm_unique_id": (C.c_int, [_P]),
+    "vo_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "vo_comm_destroy": (C.c_int, [_P]),
+    "vo_pairs_gather": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
     "vo_solve_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_double, C.c_double, C.c_uint64, _P, _P, _P, _P]),
@@ -142,6 +147,20 @@ class Context:
     def set_matcher_kernel(self, kind):
         """'mfma' (default) or 'popcount': which kernel computes the Hamming nearest neighbours (same results)."""
         self.check(self.lib.vo_set_matcher_kernel(self.handle, {"mfma": 0, "popcount": 1}[kind]))
+
+    # ---- multi-GPU: the trajectory gather over RCCL (one communicator per context)
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * VO_COMM_ID_BYTES)()
+        if self.lib.vo_comm_unique_id(buf) != 0:
+            raise VoError(VO_ERR_HIP, "ncclGetUniqueId failed (is librccl.so.1 loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * VO_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self.check(self.lib.vo_comm_init(self.handle, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self.check(self.lib.vo_comm_destroy(self.handle))
 
     def set_keypoint_order(self, kind):
         """'canonical' (default): keypoints in (octave, y, x) order; 'cv2': the order cv2.ORB returns them in

@@ -15,6 +15,9 @@
 #include <float.h>
 
 #define WAVE 64
+// throughput mode gives up on a sample after this many sweeps (oracle/voo_geom.c VOO_DK_FAST_CAP: 0.07 % of the samples
+// never settle, and one such lane would hold its wavefront for all 300 sweeps)
+#define VO_DK_FAST_CAP 64
 #ifndef VO_DK_ITERS
 #define VO_DK_ITERS 300
 #endif
@@ -205,8 +208,9 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
 {
     double prev = 1e300;
     int stall = 0;
+    const int sweeps = early ? VO_DK_FAST_CAP : VO_DK_ITERS;
 #pragma unroll 1
-    for (int iter = 0; iter < VO_DK_ITERS; iter++) {
+    for (int iter = 0; iter < sweeps; iter++) {
         bool conv_all = true;
         double max_diff = 0, max_mag = 0;
 #pragma unroll

@@ -51,6 +51,8 @@ struct vo_ctx {
     hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
     bool ev_det_set = false;
     int matcher_kernel = 0;               // 0: int8 MFMA on +1/-1 bytes (default), 1: XOR + popcount
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;          // RCCL communicator of the trajectory gather
+    double *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0;
     int kp_order = 0;                     // 0: canonical (octave, y, x) keypoint order, 1: cv2's retainBest order
     Cv2Buf cv2{};
     bool cv2_ready = false;
@@ -302,6 +304,9 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
     if (ctx->ev_det) (void)hipEventDestroy(ctx->ev_det);
+    if (ctx->comm) rccl_comm_destroy(ctx->comm);
+    if (ctx->rec_send) (void)hipFree(ctx->rec_send);
+    if (ctx->rec_recv) (void)hipFree(ctx->rec_recv);
     if (ctx->rng_host) (void)hipHostFree(ctx->rng_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -887,6 +892,68 @@ extern "C" int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* ti
         if (dist) HIPCHK(hipMemcpy(dist, ctx->pb.m_d + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
         if (inlier_mask) HIPCHK(hipMemcpy(inlier_mask, ctx->pb.mask + o, (size_t)n, hipMemcpyDeviceToHost));
     }
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU: trajectory gather over RCCL
+extern "C" int vo_comm_unique_id(uint8_t* id)
+{
+    if (!id) return VO_ERR_INVALID;
+    return rccl_unique_id(id) ? VO_ERR_HIP : VO_OK;
+}
+
+extern "C" int vo_comm_init(vo_ctx* ctx, const uint8_t* id, int rank, int world)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!id || world < 1 || rank < 0 || rank >= world) FAIL(VO_ERR_INVALID, "bad communicator arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->comm) { rccl_comm_destroy(ctx->comm); ctx->comm = nullptr; }
+    const char* e = rccl_comm_init(&ctx->comm, id, rank, world);
+    if (e) FAIL(VO_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, e);
+    ctx->comm_rank = rank; ctx->comm_world = world;
+    return VO_OK;
+}
+
+extern "C" int vo_comm_destroy(vo_ctx* ctx)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm) rccl_comm_destroy(ctx->comm);
+    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_world = 1;
+    return VO_OK;
+}
+
+extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (B < 0 || B > ctx->max_pairs || !gathered) FAIL(VO_ERR_INVALID, "bad gather arguments");
+    if (B == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int world = ctx->comm ? ctx->comm_world : 1;
+    const size_t n = (size_t)B * VO_RECORD_DOUBLES;
+    if (n * world > ctx->rec_cap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->rec_send) (void)hipFree(ctx->rec_send);
+        if (ctx->rec_recv) (void)hipFree(ctx->rec_recv);
+        ctx->rec_send = ctx->rec_recv = nullptr; ctx->rec_cap = 0;
+        HIPCHK(dmalloc(&ctx->rec_send, (size_t)ctx->max_pairs * VO_RECORD_DOUBLES));
+        HIPCHK(dmalloc(&ctx->rec_recv, (size_t)ctx->max_pairs * VO_RECORD_DOUBLES * world));
+        ctx->rec_cap = (size_t)ctx->max_pairs * VO_RECORD_DOUBLES * world;
+    }
+    hipStream_t s = ctx->stream;
+    StageTimer t(ctx, ST_MISC);
+    launch_pack_records(s, ctx->pb.res, B, ctx->rec_send);
+    HIPCHK(hipGetLastError());
+    const double* src = ctx->rec_send;
+    if (ctx->comm) {
+        const char* e = rccl_all_gather_f64(ctx->comm, ctx->rec_send, ctx->rec_recv, n, s);
+        if (e) FAIL(VO_ERR_HIP, "ncclAllGather failed: %s", e);
+        src = ctx->rec_recv;
+    }
+    HIPCHK(hipMemcpyAsync(gathered, src, n * world * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (wait) HIPCHK(hipStreamSynchronize(s));
     return VO_OK;
 }
 
@@ -1481,6 +1548,10 @@ extern "C" double vo_stage_bytes(vo_ctx* ctx, int stage, int F)
     case ST_ANGLE: b = N * 749; break;
     case ST_BLUR: b = total + total; break;
     case ST_BRIEF: b = N * 512 + N * 32 + N * 28; break;
+    case ST_MATCH_NN: b = 2 * N * 32; break;                                       // per pair ~ per frame: both descriptor sets
+    case ST_MATCH_SELECT: b = 16 * N; break;
+    case ST_RANSAC: b = 33 * N; break;                                             // SURVEY 8(d) geometry 65 N: 4 f64 coords + mask per match ...
+    case ST_POSE: b = 32 * N; break;                                               // ... + the inliers' coordinates again
     default: b = 0;
     }
     return b * F;

@@ -126,6 +126,14 @@ struct RansacParams {
     int dk_early;                // five-point root finder: 1 = stop at the noise floor, 0 = OpenCV's fixed 300 sweeps
 };
 
+// ---- trajectory gather over RCCL (gather_rccl.hip); the const char* results are error texts, nullptr = success
+const char* rccl_load(void);
+const char* rccl_unique_id(uint8_t* id128);
+const char* rccl_comm_init(void** comm, const uint8_t* id128, int rank, int world);
+void rccl_comm_destroy(void* comm);
+const char* rccl_all_gather_f64(void* comm, const double* send, double* recv, size_t count, hipStream_t s);
+void launch_pack_records(hipStream_t s, const vo_pair_result* res, int B, double* rec);
+
 // ---- launchers (defined in the .hip files) --------------------------------------------------
 void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
                  uint8_t* pyr, const PyrGeom& g, int F);

@@ -123,6 +123,17 @@ class FrontEnd:
         c = self.ctx
         c.check(c.lib.vo_sync(c.handle))
 
+    def gather_records(self, B, world=1, wait=True):
+        """All-gather the [R|t] + counts records (16 float64 per pair) of the first B pairs of the latest run_pairs
+        over the context's RCCL communicator (ctx.comm_init; without one: the local records).  Returns a
+        [world, B, 16] view of a reused page-locked buffer, valid at once (wait) or after self.wait()."""
+        if getattr(self, "_gath", None) is None or self._gath.array.shape[0] < world * self.max_pairs:
+            self._gath = _lib.PinnedArray((world * self.max_pairs, _lib.VO_RECORD_DOUBLES), np.float64)
+        out = self._gath.array[:world * B]
+        c = self.ctx
+        c.check(c.lib.vo_pairs_gather(c.handle, int(B), out.ctypes.data, int(bool(wait))))
+        return out.reshape(world, B, _lib.VO_RECORD_DOUBLES)
+
     def pair_matches(self, pair):
         cap = self.kp_cap
         qi = np.empty(cap, np.int32); ti = np.empty(cap, np.int32); d = np.empty(cap, np.float32)

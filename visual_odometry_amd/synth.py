@@ -94,6 +94,26 @@ def poses(n_frames: int, step: float = 1.0, yaw_deg: float = 0.5, seed: int = _S
     return np.stack(rs), np.stack(cs)
 
 
+def loop_poses(n_frames: int, radius: float = 36.0, seed: int = _SEED):
+    """A closed circular flight of n_frames views (frame n would be frame 0 again): heading along the tangent, so
+    consecutive frames differ by an arc of 2 pi radius / n and a yaw of 360 / n degrees, with the same seeded pitch
+    jitter as the straight path.  The whole footprint stays inside the texture, however long the sequence."""
+    rng = np.random.default_rng(seed + 2)
+    pitch = rng.uniform(-0.2, 0.2, n_frames) * np.pi / 180.0
+    r0 = np.diag([1.0, -1.0, -1.0])
+    rs, cs = [], []
+    for k in range(n_frames):
+        th = 2.0 * np.pi * k / n_frames
+        yaw = th + np.pi / 2.0                                   # image x axis along the direction of flight
+        cz, sz = np.cos(yaw), np.sin(yaw)
+        rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1.0]])
+        cp, sp = np.cos(pitch[k]), np.sin(pitch[k])
+        rx = np.array([[1.0, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        rs.append(rx @ r0 @ rz.T)
+        cs.append(np.array([radius * np.cos(th), radius * np.sin(th), HEIGHT]))
+    return np.stack(rs), np.stack(cs)
+
+
 def relative_pose(r1, c1, r2, c2):
     """R, t_hat with x2 ~ R x1 + t (the convention cv2.recoverPose returns)."""
     r = r2 @ r1.T
@@ -139,12 +159,22 @@ def render_frame(w, h, k, r, c, seed=_SEED, noise_seed=0):
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
+def _render_job(args):
+    w, h, k, r, c, seed, i = args
+    return render_frame(w, h, k, r, c, seed, i)
+
+
 def sequence(n_frames: int, w: int, h: int, step: float = 1.0, yaw_deg: float = 0.5,
-             seed: int = _SEED, cache_dir: str | None = None):
-    """Returns dict(frames u8 [n,h,w], K, R [n,3,3], C [n,3])."""
+             seed: int = _SEED, cache_dir: str | None = None, trajectory: str = "line", workers: int | None = None):
+    """Returns dict(frames u8 [n,h,w], K, R [n,3,3], C [n,3]).  trajectory = "line": the straight flight (step / yaw per
+    frame); "loop": the closed circular flight of loop_poses (n distinct views, frame n == frame 0)."""
     k = camera_matrix(w, h)
-    rs, cs = poses(n_frames, step, yaw_deg, seed)
-    tag = hashlib.sha1(f"{n_frames}-{w}-{h}-{step}-{yaw_deg}-{seed}-v1".encode()).hexdigest()[:16]
+    if trajectory == "loop":
+        rs, cs = loop_poses(n_frames, seed=seed)
+        tag = hashlib.sha1(f"loop-{n_frames}-{w}-{h}-{seed}-v1".encode()).hexdigest()[:16]
+    else:
+        rs, cs = poses(n_frames, step, yaw_deg, seed)
+        tag = hashlib.sha1(f"{n_frames}-{w}-{h}-{step}-{yaw_deg}-{seed}-v1".encode()).hexdigest()[:16]
     path = os.path.join(cache_dir, f"vo_synth_{tag}.npy") if cache_dir else None
     if path and os.path.exists(path):
         try:
@@ -153,7 +183,16 @@ def sequence(n_frames: int, w: int, h: int, step: float = 1.0, yaw_deg: float = 
                 return dict(frames=frames, K=k, R=rs, C=cs)
         except (OSError, ValueError):
             pass
-    frames = np.stack([render_frame(w, h, k, rs[i], cs[i], seed, i) for i in range(n_frames)])
+    ground_texture(seed)                         # built once, inherited by forked render workers
+    if workers is None:
+        workers = min(os.cpu_count() or 1, 16) if n_frames >= 32 else 1
+    jobs = [(w, h, k, rs[i], cs[i], seed, i) for i in range(n_frames)]
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            frames = np.stack(pool.map(_render_job, jobs, chunksize=2))
+    else:
+        frames = np.stack([_render_job(j) for j in jobs])
     if path:
         try:                                   # atomic publish: several ranks may render the same sequence at once
             tmp = f"{path}.{os.getpid()}.tmp.npy"
