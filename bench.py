@@ -180,6 +180,14 @@ def main():
     dist = torch = None
     device = local_rank
     use_dist = world > 1 or args.force_dist
+
+    # Render the views BEFORE anything initialises the GPU or a process group, and in a child process: the renderer
+    # forks workers.  Rank 0 fills the cache; the other ranks wait for it at init_process_group / the barrier below.
+    from visual_odometry_amd import synth
+    D = args.distinct_frames
+    if rank == 0:
+        synth.prerender(D, args.width, args.height, "/tmp", "loop")     # child process: this one never forks
+    seq = None
     if use_dist:
         import torch
         import torch.distributed as dist
@@ -193,17 +201,14 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     on_gpu = use_dist and args.dist_backend == "nccl"
 
-    from visual_odometry_amd import synth
     from visual_odometry_amd.frontend import (FrontEnd, MATCH_CROSSCHECK, MATCH_CROSSCHECK_LEGACY, MATCH_RATIO, chain_poses)
     from visual_odometry_amd.sharding import RECORD_WIDTH, pack_records
 
-    C, D, S = args.pairs_per_step, args.distinct_frames, max(1, args.pair_stride)
-    if rank == 0 or not use_dist:                         # one rank renders, the others read the cache
-        seq = synth.sequence(D, args.width, args.height, cache_dir="/tmp", trajectory="loop")
+    C, S = args.pairs_per_step, max(1, args.pair_stride)
     if use_dist:
         dist.barrier()
-        if rank != 0:
-            seq = synth.sequence(D, args.width, args.height, cache_dir="/tmp", trajectory="loop")
+    if seq is None:                                       # the cache rank 0 wrote (workers=1: never fork with a GPU context)
+        seq = synth.sequence(D, args.width, args.height, cache_dir="/tmp", trajectory="loop", workers=1)
     K = seq["K"]
     start = (rank * 37) % D
     if args.workload == "sequence":

@@ -41,6 +41,11 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # render before any GPU / process-group initialisation (the renderer forks workers); the other ranks read the cache
+    D = a.distinct_frames
+    if rank == 0:
+        synth.prerender(D, a.width, a.height, "/tmp", "loop")
+    seq = None
     dist = torch = None
     if world > 1:
         import torch
@@ -52,13 +57,10 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     device = local if a.dist_backend == "nccl" else 0
 
-    D = a.distinct_frames
-    if rank == 0:
-        seq = synth.sequence(D, a.width, a.height, cache_dir="/tmp", trajectory="loop")
     if dist:
         dist.barrier()
-    if rank != 0:
-        seq = synth.sequence(D, a.width, a.height, cache_dir="/tmp", trajectory="loop")
+    if seq is None:
+        seq = synth.sequence(D, a.width, a.height, cache_dir="/tmp", trajectory="loop", workers=1)
     K = seq["K"]
     n_items = a.items if a.workload == "batch" else max(a.items - 1, 0)         # items = independent units = pairs
 

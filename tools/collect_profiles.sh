@@ -6,11 +6,11 @@
 #   rocprofv3 --pmc SQ_*                      -> VALU / SALU / LDS instruction counts, wave cycles, issue stalls
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r01}
+TAG=${1:-r02}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --contexts 1 --no-cpu-baseline --no-stream-pass"
+B="python3 $R/bench.py --contexts 1 --no-cpu-baseline --no-stream-pass --no-sustain"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 8 --warmup 2 > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 3 --warmup 1 --no-profile > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 3 --warmup 1 --no-profile > $O/write.log 2>&1

@@ -12,6 +12,10 @@
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;         // non-blocking: no implicit ordering with the NULL stream (PyTorch / RCCL use it)
+    hipStream_t stream_hi = nullptr;      // same, highest priority: the latency-bound geometry tail (RANSAC, pose, DLT)
+    hipStream_t cur = nullptr;            // stream the StageTimer brackets are recorded on
+    hipEvent_t ev_tail[2] = {nullptr, nullptr};
+    int tail_priority = 0;
     char err[512] = {0};
 
     bool configured = false;
@@ -88,10 +92,10 @@ struct StageTimer {
         if (c->prof && c->n_ev < MAX_EVENTS) {
             idx = c->n_ev++;
             c->ev_stage[idx] = stage;
-            (void)hipEventRecord(c->ev[idx][0], c->stream);
+            (void)hipEventRecord(c->ev[idx][0], c->cur ? c->cur : c->stream);
         }
     }
-    ~StageTimer() { if (idx >= 0) (void)hipEventRecord(c->ev[idx][1], c->stream); }
+    ~StageTimer() { if (idx >= 0) (void)hipEventRecord(c->ev[idx][1], c->cur ? c->cur : c->stream); }
 };
 
 static void prof_collect(vo_ctx* c)
@@ -288,6 +292,19 @@ extern "C" int vo_create(int device_id, vo_ctx** out)
     for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventCreate(&ctx->ev[i][0]); (void)hipEventCreate(&ctx->ev[i][1]); }
     ctx->ev_ready = true;
     (void)hipEventCreateWithFlags(&ctx->ev_det, hipEventDisableTiming);
+    {   // experiment knob (VO_TAIL_PRIORITY=1 highest / 2 lowest): the geometry tail of a batch on a stream of its own.
+        // With the highest priority its few hundred big workgroups (k_pose: 1024 threads, k_ransac: 368 VGPRs) evict the
+        // other context's ORB kernels from whole CUs; with the lowest they wait for leftovers: both lose to one stream.
+        int lo = 0, hi = 0;
+        const char* e = getenv("VO_TAIL_PRIORITY");
+        ctx->tail_priority = e ? atoi(e) : 0;      // measured on MI355X: highest priority -17 %, lowest -6 % vs one stream: off
+        if (ctx->tail_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&ctx->stream_hi, hipStreamNonBlocking, ctx->tail_priority == 2 ? lo : hi) == hipSuccess) {
+            if (getenv("VO_DEBUG")) fprintf(stderr, "stream priority range: least %d greatest %d\n", lo, hi);
+            (void)hipEventCreateWithFlags(&ctx->ev_tail[0], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming);
+        } else ctx->stream_hi = nullptr;
+    }
     *out = ctx;
     return VO_OK;
 }
@@ -304,6 +321,8 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
     if (ctx->ev_det) (void)hipEventDestroy(ctx->ev_det);
+    if (ctx->stream_hi) { (void)hipStreamSynchronize(ctx->stream_hi); (void)hipStreamDestroy(ctx->stream_hi); }
+    for (int i = 0; i < 2; i++) if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
     if (ctx->comm) rccl_comm_destroy(ctx->comm);
     if (ctx->rec_send) (void)hipFree(ctx->rec_send);
     if (ctx->rec_recv) (void)hipFree(ctx->rec_recv);
@@ -789,9 +808,20 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t
     { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
     if (!do_geometry) return VO_OK;
     { int rc = ensure_rng(ctx, rp.seed); if (rc) return rc; }
+    const bool hi = ctx->stream_hi != nullptr && P >= 16;     // the tail on the high-priority stream, fenced by two events
+    if (hi) {
+        HIPCHK(hipEventRecord(ctx->ev_tail[0], s));
+        HIPCHK(hipStreamWaitEvent(ctx->stream_hi, ctx->ev_tail[0], 0));
+        s = ctx->stream_hi; ctx->cur = s;
+    }
     { StageTimer t(ctx, ST_RANSAC); launch_ransac(s, pb, cap, P, rp, ctx->rng_tab, RNG_TAB_N); }
     { StageTimer t(ctx, ST_POSE); launch_pose(s, pb, cap, P, rp); }
     if (want_points) { StageTimer t(ctx, ST_TRIANGULATE); launch_triangulate_pairs(s, pb, cap, P, rp); }
+    if (hi) {
+        ctx->cur = nullptr;
+        HIPCHK(hipEventRecord(ctx->ev_tail[1], s));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[1], 0));
+    }
     return VO_OK;
 }
 

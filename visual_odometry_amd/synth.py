@@ -201,3 +201,20 @@ def sequence(n_frames: int, w: int, h: int, step: float = 1.0, yaw_deg: float = 
         except OSError:
             pass
     return dict(frames=frames, K=k, R=rs, C=cs)
+
+
+def prerender(n_frames: int, w: int, h: int, cache_dir: str = "/tmp", trajectory: str = "line"):
+    """Fill the cache for sequence(...) in a CHILD process (python -m visual_odometry_amd.synth): the parallel renderer
+    forks workers, which a process that holds (or will hold) a GPU context and a process group should not do itself.
+    Call it before anything initialises the GPU; afterwards sequence(..., workers=1) only reads the cache."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, "-m", "visual_odometry_amd.synth", str(n_frames), str(w), str(h), cache_dir, trajectory],
+                          cwd=root, stdout=subprocess.DEVNULL)
+
+
+if __name__ == "__main__":
+    import sys
+    _n, _w, _h, _dir, _traj = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    sequence(_n, _w, _h, cache_dir=_dir, trajectory=_traj)
