@@ -385,6 +385,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
             if (lane_ok && r9 + RPS * k < FT_PXH) *(uint4*)(s_px + (r9 + RPS * k) * FT_PXW + 16 * c9) = pv[k];
     }
     __syncthreads();
+#if defined(FT_STOP_AFTER) && FT_STOP_AFTER == 1
+    if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = s_px[lane * 7]; return;
+#endif
 
     // B. compass pre-test on the tile + 1 ring.  Lane = (row parity, column group of 4 pixels): the wave sweeps the
     //    18 rows two at a time, every LDS address is the lane's base plus a compile-time offset (no index
@@ -447,6 +450,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         }
     }
     __syncthreads();
+#if defined(FT_STOP_AFTER) && FT_STOP_AFTER == 2
+    if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = gn + s_g[0]; return;
+#endif
     // B'. group queue -> pixel queue (score-tile row, column relative to x0-4)
     int qn = 0;                                       // wave-uniform queue length
     for (int e0 = 0; e0 < gn; e0 += 64) {
@@ -462,6 +468,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         }
     }
     __syncthreads();
+#if defined(FT_STOP_AFTER) && FT_STOP_AFTER == 3
+    if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = qn + s_q[0]; return;
+#endif
 #pragma unroll
     for (int i = lane; i < FT_SCH * FT_SCW / 16; i += 64) ((uint4*)s_sc)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -488,6 +497,9 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
             nc += na + (int)__popcll(mb);
         }
         __syncthreads();
+#if defined(FT_STOP_AFTER) && FT_STOP_AFTER == 4
+        if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = nc + s_q[0]; return;
+#endif
         // D. 3x3 non-max suppression on the corners, two per lane: decide (bits 2k, 2k+1 of `lose`), then clear
         uint32_t lose = 0;
         for (int e0 = 0, k = 0; e0 < nc; e0 += 128, k += 2) {
