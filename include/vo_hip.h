@@ -93,6 +93,13 @@ int vo_set_poly_solver(vo_ctx* ctx, int kind);
 int vo_match_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int cross_check,
                      int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
 
+/* self.matcher.match(d1, d2) for cv2.BFMatcher(cv2.NORM_L2, crossCheck=...) on float32 descriptors (nq x dim, nt x dim) —
+ * the reference's live matcher (src/visual_slam.py:19, SIFT rows: dim 128; also src/feature_detection.py:37-39).
+ * cross_check and the outputs as vo_match_hamming; distance = sqrt(sum of squared differences), float32, summed in
+ * cv::hal::normL2Sqr_'s order. */
+int vo_match_l2(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, int cross_check,
+                int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
+
 /* matcher.knnMatch(d1, d2, k=2) + `m.distance < ratio * n.distance` — src/feature_detection.py:20-26. */
 int vo_knn2_ratio_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
                           int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
@@ -238,6 +245,10 @@ int vo_rodrigues(vo_ctx* ctx, const double* in, int in_is_matrix, double* out);
  * (cv2.imread's JPEG decode stays on the host).  Host image in, host image out. */
 int vo_resize_linear(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels, int row_stride,
                      uint8_t* dst, int dh, int dw, int dst_stride);
+/* cv2.resize(img, dim, interpolation=cv2.INTER_AREA) for an image that shrinks on both axes —
+ * src/image_and_keypoints.py:42 (ImageAndKeypoints.set_image).  VO_ERR_UNSUPPORTED: enlargement. */
+int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels, int row_stride,
+                   uint8_t* dst, int dh, int dw, int dst_stride);
 /* The batched form of the same step: F full-resolution host frames are resized on the device to the configured
  * (w, h), converted to gray as ORB does, and become level 0 of slots first_slot..; resized_out (optional, host,
  * [F][h][w][channels] dense) receives the resized frames (the reference keeps them as Frame.image). */

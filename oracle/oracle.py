@@ -163,6 +163,19 @@ def match_hamming(q, t, cross_check=2):
     return qi[:n.value].copy(), ti[:n.value].copy(), d[:n.value].copy()
 
 
+def match_l2(q, t, cross_check=2):
+    """cv2.BFMatcher(cv2.NORM_L2, crossCheck).match on float32 descriptors."""
+    q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+    nq, nt = len(q), len(t)
+    dim = q.shape[1] if nq else (t.shape[1] if nt else 1)
+    qi = np.zeros(max(nq, 1), np.int32); ti = np.zeros(max(nq, 1), np.int32); d = np.zeros(max(nq, 1), np.float32)
+    n = C.c_int32(0)
+    rc = lib().voo_match_l2(_p(q, C.c_float), nq, _p(t, C.c_float), nt, int(dim), int(cross_check),
+                            _p(qi, C.c_int32), _p(ti, C.c_int32), _p(d, C.c_float), C.byref(n))
+    assert rc == 0
+    return qi[:n.value].copy(), ti[:n.value].copy(), d[:n.value].copy()
+
+
 def knn2_ratio_hamming(q, t, ratio):
     q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
     nq, nt = len(q), len(t)
@@ -278,6 +291,21 @@ def resize_linear(src, dw, dh):
     f = lib().voo_resize_linear
     f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     rc = f(src.ctypes.data, sw, sh, cn, src.strides[0], dst.ctypes.data, dw, dh, dst.strides[0])
+    assert rc == 0
+    return dst
+
+
+def resize_area(src, dw, dh):
+    """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) for a shrinking 8-bit image (voo_ingest.c)."""
+    src = _u8(src)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    f = lib().voo_resize_area
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rc = f(src.ctypes.data, sw, sh, cn, src.strides[0], dst.ctypes.data, dw, dh, dst.strides[0])
+    if rc == -2:
+        raise NotImplementedError("INTER_AREA enlargement is not restated")
     assert rc == 0
     return dst
 

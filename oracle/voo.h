@@ -68,6 +68,11 @@ int voo_match_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int cr
 int voo_knn2_ratio_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
                            int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
 
+/* cv2.BFMatcher(cv2.NORM_L2, crossCheck).match on float descriptors (the reference's live SIFT matcher,
+ * visual_slam.py:19): same cross_check values as voo_match_hamming, distances = sqrt(sum of squared differences) */
+int voo_match_l2(const float* q, int nq, const float* t, int nt, int dim, int cross_check,
+                 int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
+
 /* --- two-view geometry (float64) --------------------------------------------- */
 /* cv::solvePoly inside the five-point solver: 0 (default) = OpenCV's fixed 300 Durand-Kerner sweeps, 1 = stop at the
  * rounding-noise floor exactly as the HIP kernel's throughput mode does (process-wide switch, not thread safe) */
@@ -104,6 +109,11 @@ int voo_reprojection_sqerr(const double* poses, int ncam, const double* points, 
 int voo_resize_linear_tab(int ssize, int dsize, int32_t* ofs, int16_t* c0, int16_t* c1, int clamp_weight);
 int voo_resize_linear(const uint8_t* src, int sw, int sh, int cn, int sstride,
                       uint8_t* dst, int dw, int dh, int dstride);
+
+/* cv2.resize(img, dim, interpolation=cv2.INTER_AREA), shrinking only — image_and_keypoints.py:42 (-2: enlargement) */
+int voo_resize_area_tab(int ssize, int dsize, int32_t* si, float* alpha, int32_t* start /*dsize + 1*/);
+int voo_resize_area(const uint8_t* src, int sw, int sh, int cn, int sstride,
+                    uint8_t* dst, int dw, int dh, int dstride);
 
 /* --- "next" row: localisation, cv2.solvePnPRansac + cv2.Rodrigues, visual_slam.py:231-243 ---- */
 int voo_solve_pnp_ransac(const double* obj /*n x 3*/, const double* img /*n x 2*/, int n, const double* K,

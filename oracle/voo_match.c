@@ -7,7 +7,9 @@
  * Arithmetic: OpenCV 4.7 core/batch_distance.cpp + features2d/matchers.cpp; PARITY UNPINNED.
  */
 #include "voo.h"
+#include <float.h>
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -98,5 +100,70 @@ int voo_knn2_ratio_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, d
         }
     }
     *n_out = n;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match
+ * The reference's LIVE matcher (/root/reference/src/visual_slam.py:19, on SIFT descriptors; also
+ * /root/reference/src/feature_detection.py:37-39).  batchDistance with NORM_L2 on CV_32F rows stores
+ * sqrt(normL2Sqr_(a, b, n)) as float and selects on those values (ascending scan, strict <).
+ * normL2Sqr_ (core/src/norm.cpp, baseline SSE build = 4 float lanes, v_muladd = multiply then add):
+ *   four 4-lane accumulators over 16 elements per step, d = reduce_sum(((d0 + d1) + d2) + d3) with
+ *   reduce_sum(x) = (x0 + x2) + (x1 + x3), then the scalar tail d += t * t.  [unverified] lane count / reduction
+ *   order of the wheel's build. */
+static float l2sqr(const float* a, const float* b, int n)
+{
+    float acc[4][4] = {{0}};
+    int j = 0;
+    for (; j <= n - 16; j += 16)
+        for (int m = 0; m < 4; m++)
+            for (int l = 0; l < 4; l++) {
+                float t = a[j + 4 * m + l] - b[j + 4 * m + l];
+                float p = t * t;
+                acc[m][l] = p + acc[m][l];
+            }
+    float s[4];
+    for (int l = 0; l < 4; l++) s[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+    float d = (s[0] + s[2]) + (s[1] + s[3]);
+    for (; j < n; j++) { float t = a[j] - b[j]; float p = t * t; d = d + p; }
+    return d;
+}
+
+static void nn1_l2(const float* a, int na, const float* b, int nb, int dim, int32_t* idx, float* dist)
+{
+    for (int i = 0; i < na; i++) {
+        float best = FLT_MAX; int bi = -1;
+        for (int j = 0; j < nb; j++) {
+            float d = sqrtf(l2sqr(a + (size_t)dim * i, b + (size_t)dim * j, dim));
+            if (d < best) { best = d; bi = j; }
+        }
+        idx[i] = bi; dist[i] = best;
+    }
+}
+
+int voo_match_l2(const float* q, int nq, const float* t, int nt, int dim, int cross_check,
+                 int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out)
+{
+    *n_out = 0;
+    if (nq < 0 || nt < 0 || dim < 1 || cross_check < 0 || cross_check > 2) return -1;
+    if (nq == 0 || nt == 0) return 0;
+    int32_t* fi = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nq + nt));
+    float* fd = (float*)malloc(sizeof(float) * (size_t)(nq + nt));
+    int32_t* ri = fi + nq; float* rd = fd + nq;
+    int n = 0;
+    if (cross_check == 1) {
+        nn1_l2(t, nt, q, nq, dim, ri, rd);
+        for (int i = 0; i < nq; i++) { fi[i] = -1; fd[i] = FLT_MAX; }
+        for (int i = 0; i < nt; i++) { int idx = ri[i]; if (rd[i] < fd[idx]) { fd[idx] = rd[i]; fi[idx] = i; } }
+    } else {
+        nn1_l2(q, nq, t, nt, dim, fi, fd);
+        if (cross_check == 2) {
+            nn1_l2(t, nt, q, nq, dim, ri, rd);
+            for (int i = 0; i < nq; i++) if (fi[i] >= 0 && ri[fi[i]] != i) fi[i] = -1;
+        }
+    }
+    for (int i = 0; i < nq; i++) if (fi[i] >= 0) { qidx[n] = i; tidx[n] = fi[i]; dist[n] = fd[i]; n++; }
+    *n_out = n;
+    free(fi); free(fd);
     return 0;
 }

@@ -59,7 +59,8 @@ def main():
     rng = np.random.default_rng(123)
     big = rng.integers(0, 256, (108, 192, 3), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "ingest_192x108.npz"), src=big, dst_57x32=O.resize_linear(big, 57, 32),
-                        dst_96x54=O.resize_linear(big, 96, 54), dst_250x120=O.resize_linear(big, 250, 120))
+                        dst_96x54=O.resize_linear(big, 96, 54), dst_250x120=O.resize_linear(big, 250, 120),
+                        area_96x54=O.resize_area(big, 96, 54), area_64x36=O.resize_area(big, 64, 36), area_57x32=O.resize_area(big, 57, 32))
     # localisation: cv2.solvePnPRansac (visual_slam.py:231-235)
     rng = np.random.default_rng(77)
     Kp = np.array([[800., 0, 320], [0, 800, 240], [0, 0, 1]])

@@ -123,3 +123,25 @@ def test_popcount_kernel_gives_the_same_matches(oracle):
             c.check(c.lib.vo_set_matcher_kernel(c.handle, 7))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("dim,nq,nt", [(128, 700, 900), (128, 65, 64), (64, 300, 257), (61, 130, 70), (16, 40, 40), (3, 10, 200)])
+def test_l2_matcher_bit_exact(oracle, ctx, dim, nq, nt):
+    """cv2.BFMatcher(cv2.NORM_L2, crossCheck) on float rows (visual_slam.py:19, the reference's live matcher): indices AND
+    float distances equal the oracle's in every cross-check mode, including exact duplicates (ties go to the lowest index)
+    and dimensions with a scalar tail (61) or no 16-element block at all (3)."""
+    from visual_odometry_amd.matcher import BFMatcher, L2Matcher, NORM_L2
+    rng = np.random.default_rng(dim * 1000 + nq)
+    t = (rng.random((nt, dim), dtype=np.float32) * 255).astype(np.float32)
+    q = t[rng.integers(0, nt, nq)] + rng.normal(0, 3, (nq, dim)).astype(np.float32)
+    q[: nq // 8] = t[: nq // 8]                              # exact copies: distance 0
+    t[nt // 2:nt // 2 + 5] = t[0]                            # duplicated train rows: ties
+    for mode in (0, 1, 2):
+        m = L2Matcher(crossCheck=mode > 0, legacy_crosscheck=mode == 1, ctx=ctx)
+        gq, gt, gd = m.match_arrays(q, t)
+        rq, rt, rd = oracle.match_l2(q, t, mode)
+        assert np.array_equal(gq, rq) and np.array_equal(gt, rt) and np.array_equal(gd, rd), mode
+    ms = BFMatcher(NORM_L2, crossCheck=True).match(q, t)
+    assert ms[0].distance == 0.0 and ms[0].trainIdx == 0 and all(a.queryIdx < b.queryIdx for a, b in zip(ms, ms[1:]))
+    e = np.zeros((0, dim), np.float32)
+    assert L2Matcher(ctx=ctx).match(e, t) == [] and L2Matcher(ctx=ctx).match(q, e) == []

@@ -129,4 +129,28 @@ def test_ingest_into_the_front_end(oracle, ctx):
     ref = oracle.orb_detect_and_compute(oracle.resize_linear(seq["frames"][0], 384, 216), oracle.orb_params(nfeatures=500))
     assert np.array_equal(fe.features(0)["desc"], ref["desc"])
     with pytest.raises(NotImplementedError):
-        ingest.resize(big[0], (10, 10), interpolation=ingest.INTER_AREA)
+        ingest.resize(big[0], (2000, 1000), interpolation=ingest.INTER_AREA)     # enlarging INTER_AREA is not built
+
+
+@pytest.mark.parametrize("shape,dsize", [((2160, 3840, 3), (1152, 648)), ((216, 384, 3), (192, 108)), ((216, 384, 3), (128, 72)),
+                                         ((216, 384), (96, 108)), ((216, 384, 3), (115, 64)), ((97, 131), (64, 48)),
+                                         ((60, 80, 4), (80, 60)), ((60, 80, 4), (79, 59)), ((33, 47), (1, 1)), ((5, 5, 3), (5, 2))])
+def test_inter_area_resize_bit_exact(oracle, ctx, shape, dsize):
+    """cv2.resize(img, dim, interpolation=cv2.INTER_AREA) (image_and_keypoints.py:42): integer factors (2 x 2 and other
+    blocks), mixed integer factors, fractional factors (the reference's 0.3 among them), identity, 1, 3 and 4 channels."""
+    from visual_odometry_amd import ingest
+    rng = np.random.default_rng(sum(shape) + dsize[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = ingest.resize(img, dsize, interpolation=ingest.INTER_AREA)
+    assert got.shape[:2] == (dsize[1], dsize[0]) and np.array_equal(got, oracle.resize_area(img, dsize[0], dsize[1]))
+
+
+def test_image_and_keypoints_rescales_with_inter_area(oracle, ctx, seq_small):
+    from visual_odometry_amd import ImageAndKeypoints
+    iak = ImageAndKeypoints("ORB")
+    iak.scale_factor = 0.5
+    bgr = np.stack([seq_small["frames"][0]] * 3, axis=2)
+    iak.set_image(bgr)
+    assert iak.image.shape == (240, 320, 3) and np.array_equal(iak.image, oracle.resize_area(bgr, 320, 240))
+    iak.detect_keypoints()
+    assert len(iak.keypoints) > 50

@@ -84,6 +84,8 @@ def test_ingest_golden(oracle):
     g = np.load(os.path.join(G, "ingest_192x108.npz"))
     for name, (dw, dh) in (("dst_57x32", (57, 32)), ("dst_96x54", (96, 54)), ("dst_250x120", (250, 120))):
         assert np.array_equal(oracle.resize_linear(g["src"], dw, dh), g[name])
+    for name, (dw, dh) in (("area_96x54", (96, 54)), ("area_64x36", (64, 36)), ("area_57x32", (57, 32))):     # INTER_AREA
+        assert np.array_equal(oracle.resize_area(g["src"], dw, dh), g[name])
 
 
 def test_pnp_golden(oracle):

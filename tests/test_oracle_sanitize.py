@@ -45,6 +45,13 @@ O.recover_pose(E[0], gg["p1"][mask > 0], gg["p2"][mask > 0], gg["K"])
 gi = np.load(os.path.join(G, "ingest_192x108.npz"))
 assert np.array_equal(O.resize_linear(gi["src"], 57, 32), gi["dst_57x32"])
 O.resize_linear(gi["src"][:, :, 0].copy(), 250, 120); O.resize_linear(gi["src"], 96, 54)
+assert np.array_equal(O.resize_area(gi["src"], 57, 32), gi["area_57x32"])
+O.resize_area(gi["src"], 96, 54); O.resize_area(gi["src"], 64, 36); O.resize_area(gi["src"][:, :, 0].copy(), 192, 108); O.resize_area(gi["src"], 1, 1)
+fq = np.random.default_rng(2).random((70, 128)).astype(np.float32); ft = np.random.default_rng(3).random((90, 128)).astype(np.float32)
+for mode in (0, 1, 2):
+    O.match_l2(fq, ft, mode); O.match_l2(fq[:, :61].copy(), ft[:, :61].copy(), mode)
+O.retain_best_cv2(np.random.default_rng(4).integers(0, 9, 500).astype(np.float32), 100)
+O.set_keypoint_order("cv2"); O.orb_detect_and_compute(f[0], p); O.set_keypoint_order("canonical")
 gp = np.load(os.path.join(G, "pnp_240.npz"))
 rc, rv, tv, mk, ni = O.solve_pnp_ransac(gp["obj"], gp["img"], gp["K"])
 assert rc == 0 and ni == int(gp["n_inl"])

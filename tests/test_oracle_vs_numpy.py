@@ -352,3 +352,44 @@ def test_pnp_error_codes_and_rodrigues(oracle):
     assert np.array_equal(oracle.rodrigues(np.zeros(3)), np.eye(3))
     near_pi = np.array([np.pi - 1e-9, 0, 0])                                  # the s < 1e-5 branch of cvRodrigues2
     assert np.abs(oracle.rodrigues(oracle.rodrigues(near_pi)) - near_pi).max() < 1e-6
+
+
+def _area_weights(s, d):
+    W = np.zeros((d, s)); sc = s / d
+    for i in range(d):
+        a, b = i * sc, (i + 1) * sc
+        for j in range(int(np.floor(a)), min(int(np.ceil(b)), s)):
+            W[i, j] = max(0.0, min(b, j + 1) - max(a, j))
+        W[i] /= W[i].sum()
+    return W
+
+
+@pytest.mark.parametrize("dsize", [(192, 108), (128, 72), (96, 54), (96, 108), (115, 64), (384, 216), (383, 215), (1, 1)])
+def test_inter_area_against_exact_area_mean(oracle, dsize):
+    """cv2.resize(..., INTER_AREA) (image_and_keypoints.py:42) is the area-weighted mean of the covered source cells:
+    the float32 restatement must round the float64 mean to the nearest grey level (ties aside)."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (216, 384, 3), dtype=np.uint8)
+    out = oracle.resize_area(img, dsize[0], dsize[1]).astype(np.float64)
+    Wx, Wy = _area_weights(384, dsize[0]), _area_weights(216, dsize[1])
+    ref = np.einsum("yj,jxc->yxc", Wy, np.einsum("xi,jic->jxc", Wx, img.astype(np.float64)))
+    assert np.abs(out - ref).max() <= 0.5 + 1e-4
+    if dsize == (192, 108):                                   # 2 x 2 blocks round half up: (a + b + c + d + 2) >> 2
+        blk = img.reshape(108, 2, 192, 2, 3).astype(np.int64).sum(axis=(1, 3))
+        assert np.array_equal(out, (blk + 2) >> 2)
+    with pytest.raises(NotImplementedError):
+        oracle.resize_area(img, 500, 300)
+
+
+def test_l2_matcher_against_numpy(oracle):
+    """BFMatcher(NORM_L2) (visual_slam.py:19): float32 distances in normL2Sqr_'s order vs float64 numpy."""
+    rng = np.random.default_rng(9)
+    t = (rng.random((150, 128)) * 200).astype(np.float32)
+    q = t[rng.permutation(150)[:100]] + rng.normal(0, 2, (100, 128)).astype(np.float32)
+    D = np.sqrt(((q[:, None, :].astype(np.float64) - t[None].astype(np.float64)) ** 2).sum(2))
+    qi, ti, d = oracle.match_l2(q, t, 0)
+    assert np.array_equal(ti, D.argmin(axis=1)) and np.abs(d - D.min(axis=1)).max() < 1e-4
+    fwd, rev = D.argmin(axis=1), D.argmin(axis=0)
+    mutual = [i for i in range(100) if rev[fwd[i]] == i]
+    qi, ti, d = oracle.match_l2(q, t, 2)
+    assert qi.tolist() == mutual and np.array_equal(ti, fwd[mutual])

@@ -12,7 +12,7 @@ from .frame import Frame  # noqa: F401
 from .frame_generator import FrameGenerator  # noqa: F401
 
 __all__ = ["KeyPoint", "DMatch", "Feature", "Match", "Match3D", "MatchWithMap", "Frame", "FrameGenerator",
-           "OrbDetector", "ORB_create", "HammingMatcher", "BFMatcher", "NORM_HAMMING", "ImagePair", "ImageAndKeypoints",
+           "OrbDetector", "ORB_create", "HammingMatcher", "L2Matcher", "BFMatcher", "NORM_HAMMING", "NORM_L2", "ImagePair", "ImageAndKeypoints",
            "TriangulatePointsFromTwoImages", "FrontEnd"]
 
 
@@ -21,7 +21,7 @@ def __getattr__(name):
     if name in ("OrbDetector", "ORB_create"):
         from . import detector
         return getattr(detector, name)
-    if name in ("HammingMatcher", "BFMatcher", "NORM_HAMMING"):
+    if name in ("HammingMatcher", "L2Matcher", "BFMatcher", "NORM_HAMMING", "NORM_L2"):
         from . import matcher
         return getattr(matcher, name)
     if name == "ImagePair":

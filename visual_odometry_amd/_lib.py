@@ -44,6 +44,7 @@ _SIGS = {
     "vo_version": (C.c_int, []),
     "vo_orb_detect_and_compute": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "vo_match_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "vo_match_l2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "vo_knn2_ratio_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_double, _P, _P, _P, _P]),
     "vo_find_essential_ransac": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_double, C.c_double, C.c_int, C.c_uint64, _P, _P, _P, _P]),
     "vo_recover_pose": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P, _P, _P]),
@@ -81,6 +82,7 @@ _SIGS = {
     "vo_solve_pnp_ransac_batch": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_double, C.c_double, C.c_uint64, _P, _P, _P, _P, _P]),
     "vo_rodrigues": (C.c_int, [_P, _P, C.c_int, _P]),
     "vo_resize_linear": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "vo_resize_area": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vo_frames_ingest": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _P]),
     "vo_feature_tracks": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "vo_profile_enable": (C.c_int, [_P, C.c_int]),

@@ -6,6 +6,7 @@
 // Semantics follow OpenCV's batchDistance: ascending scan, strict `<`, so the lowest index wins ties;
 // crossCheck=True keeps the mutual nearest neighbours (mode 2); the older reverse-NN-only rule is mode 1.
 #include "vo_internal.h"
+#include <float.h>
 #include <limits.h>
 
 // ------------------------------------------------------------------ XOR + popcount matcher (the formulation BASELINE.json's
@@ -354,4 +355,75 @@ void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count,
     // above the 64 KB default a workgroup must opt in to its dynamic LDS (the API layer bounds kp_cap * 8 by 160 KB)
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_match_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     hipLaunchKernelGGL(k_match_select, dim3(P), dim3(256), shmem, s, kp_xy, kp_count, kp_cap, pb, mode, ratio, K);
+}
+
+// ------------------------------------------------------------------ BFMatcher(NORM_L2) on float descriptors
+// The reference's live matcher (src/visual_slam.py:19: cv2.BFMatcher(cv2.NORM_L2, crossCheck=True) on SIFT rows).
+// batchDistance stores sqrt(normL2Sqr_(a, b, n)) as float and selects on those values; normL2Sqr_'s summation order
+// (four 4-lane accumulators over 16 elements per step, ((d0 + d1) + d2) + d3 per lane, (s0 + s2) + (s1 + s3), scalar
+// tail) is reproduced term by term — multiply and add are separate roundings (-ffp-contract=off) — so the distances
+// and therefore every tie are the oracle's.  This is the direct difference form, not |a|^2 + |b|^2 - 2 a.b: the
+// matrix cores would change the rounding of every distance, and with it the winner of near-ties.
+// One lane per query row (its elements stay in registers for DIM = 128), train rows broadcast from LDS tiles.
+#define L2_TILE 32
+template <int DIM>
+__global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist)
+{
+    extern __shared__ float s_t[];                       // [L2_TILE][dim]
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    const bool live = row < na;
+    const float* a = A + (size_t)(live ? row : 0) * dim;
+    float areg[DIM > 0 ? DIM : 1];
+    if (DIM > 0) {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) areg[k] = a[k];
+    }
+    float best = FLT_MAX;
+    int bi = -1;
+    for (int base = 0; base < nb; base += L2_TILE) {
+        const int rows = min(L2_TILE, nb - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows * dim; i += 64) s_t[i] = B[(size_t)base * dim + i];
+        __syncthreads();
+        for (int r = 0; r < rows; r++) {
+            const float* b = s_t + r * dim;
+            float acc[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int l = 0; l < 4; l++) acc[m][l] = 0.f;
+            int j = 0;
+            if (DIM > 0) {
+#pragma unroll
+                for (int jj = 0; jj <= DIM - 16; jj += 16)
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+#pragma unroll
+                        for (int l = 0; l < 4; l++) { const float t = areg[jj + 4 * m + l] - b[jj + 4 * m + l]; const float p = t * t; acc[m][l] = p + acc[m][l]; }
+                j = DIM - DIM % 16;
+            } else {
+                for (; j <= dim - 16; j += 16)
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+#pragma unroll
+                        for (int l = 0; l < 4; l++) { const float t = a[j + 4 * m + l] - b[j + 4 * m + l]; const float p = t * t; acc[m][l] = p + acc[m][l]; }
+            }
+            float s[4];
+#pragma unroll
+            for (int l = 0; l < 4; l++) s[l] = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+            float d = (s[0] + s[2]) + (s[1] + s[3]);
+            for (; j < dim; j++) { const float t = (DIM > 0 ? areg[DIM > 0 ? min(j, DIM - 1) : 0] : a[j]) - b[j]; const float p = t * t; d = d + p; }
+            d = sqrtf(d);
+            if (d < best) { best = d; bi = base + r; }
+        }
+    }
+    if (live) { idx[row] = bi; dist[row] = best; }
+}
+
+void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist)
+{
+    if (na <= 0) return;
+    const size_t shmem = (size_t)L2_TILE * dim * sizeof(float);
+    if (dim == 128) hipLaunchKernelGGL(k_nn_l2<128>, dim3((na + 63) / 64), dim3(64), shmem, s, A, na, B, nb, dim, idx, dist);
+    else hipLaunchKernelGGL(k_nn_l2<0>, dim3((na + 63) / 64), dim3(64), shmem, s, A, na, B, nb, dim, idx, dist);
 }

@@ -267,6 +267,48 @@ void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, in
                        dst, dw, dh, dstride, dframe, xofs, (const short2*)xa, yofs, (const short2*)yb, area2);
 }
 
+// ------------------------------------------------------------------ cv2.resize(img, dim, interpolation=cv2.INTER_AREA), shrinking
+// image_and_keypoints.py:42.  OpenCV's resizeAreaFast_ (integer scale factors: 2 x 2 = (sum + 2) >> 2, other blocks
+// cvRound(sum * (1.f / area))) and resizeArea_ (DecimateAlpha tables from the host, float32: buf = sum S * alpha per
+// source row, then sum over the rows with beta; one multiply and one add per term, the library is built with
+// -ffp-contract=off).  One lane per destination byte.
+__global__ __launch_bounds__(256) void k_resize_area(const uint8_t* src, int cn, int sstride, uint8_t* dst, int dw, int dstride,
+                                                     int isx, int isy, const int* xsi, const float* xal, const int* xst,
+                                                     const int* ysi, const float* yal, const int* yst)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (i >= dw * cn) return;
+    const int dx = i / cn, k = i - dx * cn;
+    int v;
+    if (isx > 0) {                                         // both scale factors are integers
+        int sum = 0;
+        for (int y = 0; y < isy; y++) {
+            const uint8_t* s = src + (size_t)(dy * isy + y) * sstride + (size_t)(dx * isx) * cn + k;
+            for (int x = 0; x < isx; x++) sum += s[x * cn];
+        }
+        v = (isx == 2 && isy == 2) ? (sum + 2) >> 2 : __float2int_rn((float)sum * (1.f / (float)(isx * isy)));
+    } else {
+        float sum = 0.f;
+        const int j0 = yst[dy], j1 = yst[dy + 1], i0 = xst[dx], i1 = xst[dx + 1];
+        for (int j = j0; j < j1; j++) {
+            const uint8_t* s = src + (size_t)ysi[j] * sstride + k;
+            float buf = 0.f;
+            for (int q = i0; q < i1; q++) buf = buf + (float)s[(size_t)xsi[q] * cn] * xal[q];
+            const float term = yal[j] * buf;
+            sum = j == j0 ? term : sum + term;
+        }
+        v = __float2int_rn(sum);
+    }
+    dst[(size_t)dy * dstride + i] = (uint8_t)min(max(v, 0), 255);
+}
+
+void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride, uint8_t* dst, int dw, int dh, int dstride,
+                        int isx, int isy, const int* xsi, const float* xal, const int* xst, const int* ysi, const float* yal, const int* yst)
+{
+    hipLaunchKernelGGL(k_resize_area, dim3((dw * cn + 255) / 256, dh), dim3(256), 0, st, src, cn, sstride, dst, dw, dstride,
+                       isx, isy, xsi, xal, xst, ysi, yal, yst);
+}
+
 // ------------------------------------------------------------------ FAST-9/16 + cornerScore + 3x3 NMS
 // fast.cpp FAST_t<16> / fast_score.cpp cornerScore<16>.  One WAVEFRONT = one FAST_TW x FAST_TH output tile;
 // a workgroup is a single wave, so the kernel has no cross-wave barrier and every wave runs at its own pace.

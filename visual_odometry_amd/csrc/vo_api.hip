@@ -1,6 +1,7 @@
 // vo_api.hip — context, device buffers and the C ABI of libvo_hip.so (see include/vo_hip.h).
 // Host-side plumbing only: every arithmetic stage is a HIP kernel in orb_/match_/geom_kernels.hip.
 #include "vo_internal.h"
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -83,6 +84,8 @@ static const char* k_stage_names[VO_STAGE_COUNT] = {
 
 template <typename T>
 static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
+
+static int ensure_raw_d(vo_ctx* ctx, size_t n);
 
 // ------------------------------------------------------------------ profiling brackets
 struct StageTimer {
@@ -1056,6 +1059,55 @@ extern "C" int vo_match_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uin
     return match_raw(ctx, q, nq, t, nt, cross_check, 0.0, qidx, tidx, dist, n_out);
 }
 
+// cv2.BFMatcher(cv2.NORM_L2, crossCheck).match on float rows: the two nearest-neighbour passes run on the device, the
+// cross-check rule (a scan over nq + nt integers) and the ordered output on the host
+extern "C" int vo_match_l2(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, int cross_check,
+                           int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!n_out || nq < 0 || nt < 0 || dim < 1 || dim > 1024 || (nq > 0 && !q) || (nt > 0 && !t)) FAIL(VO_ERR_INVALID, "bad matcher arguments");
+    if (cross_check < 0 || cross_check > 2) FAIL(VO_ERR_INVALID, "cross_check must be 0, 1 or 2");
+    *n_out = 0;
+    if (nq == 0 || nt == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nf = (size_t)(nq + nt) * dim, ni = (size_t)2 * (nq + nt);
+    int rc = ensure_raw_d(ctx, (nf + ni) / 2 + 64);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    float* dq = (float*)ctx->raw_d; float* dt = dq + (size_t)nq * dim;
+    int* fi = (int*)(dt + (size_t)nt * dim); int* ri = fi + nq;
+    float* fd = (float*)(ri + nt); float* rd = fd + nq;
+    HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)nt * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    {
+        StageTimer tm(ctx, ST_MATCH_NN);
+        if (cross_check != 1) launch_nn_l2(s, dq, nq, dt, nt, dim, fi, fd);
+        if (cross_check != 0) launch_nn_l2(s, dt, nt, dq, nq, dim, ri, rd);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<int> hfi(nq, -1), hri(nt, -1);
+    std::vector<float> hfd(nq, FLT_MAX), hrd(nt, FLT_MAX);
+    if (cross_check != 1) {
+        HIPCHK(hipMemcpyAsync(hfi.data(), fi, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hfd.data(), fd, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    if (cross_check != 0) {
+        HIPCHK(hipMemcpyAsync(hri.data(), ri, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hrd.data(), rd, (size_t)nt * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    if (cross_check == 1) {                               // legacy rule: every train row votes for its nearest query
+        for (int i = 0; i < nt; i++) { const int k = hri[i]; if (k >= 0 && hrd[i] < hfd[k]) { hfd[k] = hrd[i]; hfi[k] = i; } }
+    } else if (cross_check == 2) {                        // OpenCV 4.x: mutual nearest neighbours
+        for (int i = 0; i < nq; i++) if (hfi[i] >= 0 && hri[hfi[i]] != i) hfi[i] = -1;
+    }
+    int n = 0;
+    for (int i = 0; i < nq; i++) if (hfi[i] >= 0) { qidx[n] = i; tidx[n] = hfi[i]; dist[n] = hfd[i]; n++; }
+    *n_out = n;
+    return VO_OK;
+}
+
 extern "C" int vo_knn2_ratio_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
                                      int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out)
 {
@@ -1424,6 +1476,76 @@ extern "C" int vo_resize_linear(vo_ctx* ctx, const uint8_t* src, int sh, int sw,
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(dst, ctx->ingest_out, dbytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+// resize.cpp computeResizeAreaTab: for every destination index the source cells it covers and their weights
+static int area_tab(int ssize, int dsize, double scale, std::vector<int>& si, std::vector<float>& al, std::vector<int>& start)
+{
+    si.clear(); al.clear(); start.assign((size_t)dsize + 1, 0);
+    for (int dx = 0; dx < dsize; dx++) {
+        start[dx] = (int)si.size();
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+        sx1 = sx1 < sx2 ? sx1 : sx2;
+        if (sx1 - fsx1 > 1e-3) { si.push_back(sx1 - 1); al.push_back((float)((sx1 - fsx1) / cell)); }
+        for (int sx = sx1; sx < sx2; sx++) { si.push_back(sx); al.push_back((float)(1.0 / cell)); }
+        if (fsx2 - sx2 > 1e-3) {
+            double a = fsx2 - sx2; a = a < 1. ? a : 1.; a = a < cell ? a : cell;
+            si.push_back(sx2); al.push_back((float)(a / cell));
+        }
+    }
+    start[dsize] = (int)si.size();
+    return (int)si.size();
+}
+
+extern "C" int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels, int row_stride,
+                              uint8_t* dst, int dh, int dw, int dst_stride)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!src || !dst || sh < 1 || sw < 1 || dh < 1 || dw < 1 || (channels != 1 && channels != 3 && channels != 4) ||
+        row_stride < sw * channels || dst_stride < dw * channels) FAIL(VO_ERR_INVALID, "bad arguments");
+    if (dw > sw || dh > sh) FAIL(VO_ERR_UNSUPPORTED, "INTER_AREA enlargement (a bilinear variant in OpenCV) is not built");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t sbytes = (size_t)row_stride * sh, dbytes = (size_t)dst_stride * dh;
+    int rc = ensure_bytes(ctx, &ctx->staging, &ctx->staging_bytes, sbytes); if (rc) return rc;
+    rc = ensure_bytes(ctx, &ctx->ingest_out, &ctx->ingest_out_bytes, dbytes); if (rc) return rc;
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);     // as resize() forms them
+    const int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
+    const bool fast = fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON;
+    hipStream_t s = ctx->stream;
+    const int *xsi = nullptr, *xst = nullptr, *ysi = nullptr, *yst = nullptr; const float *xal = nullptr, *yal = nullptr;
+    std::vector<int> hxs, hys, hxst, hyst; std::vector<float> hxa, hya;
+    if (!fast) {
+        const int nx = area_tab(sw, dw, scale_x, hxs, hxa, hxst), ny = area_tab(sh, dh, scale_y, hys, hya, hyst);
+        const size_t n = (size_t)2 * nx + 2 * ny + dw + dh + 2;
+        if (n > ctx->ingest_tab_n) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (ctx->ingest_tab) (void)hipFree(ctx->ingest_tab);
+            ctx->ingest_tab = nullptr; ctx->ingest_tab_n = 0;
+            HIPCHK(dmalloc(&ctx->ingest_tab, n));
+            ctx->ingest_tab_n = n;
+        }
+        int* d = ctx->ingest_tab;
+        int* dxs = d; float* dxa = (float*)(d + nx); int* dxst = d + 2 * nx;
+        int* dys = dxst + dw + 1; float* dya = (float*)(dys + ny); int* dyst = dys + 2 * ny;
+        HIPCHK(hipMemcpyAsync(dxs, hxs.data(), (size_t)nx * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dxa, hxa.data(), (size_t)nx * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dxst, hxst.data(), (size_t)(dw + 1) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dys, hys.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dya, hya.data(), (size_t)ny * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(dyst, hyst.data(), (size_t)(dh + 1) * 4, hipMemcpyHostToDevice, s));
+        xsi = dxs; xal = dxa; xst = dxst; ysi = dys; yal = dya; yst = dyst;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->staging, src, sbytes, hipMemcpyHostToDevice, s));
+    { StageTimer t(ctx, ST_MISC); launch_resize_area(s, ctx->staging, channels, row_stride, ctx->ingest_out, dw, dh, dst_stride,
+                                                     fast ? isx : 0, fast ? isy : 0, xsi, xal, xst, ysi, yal, yst); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst, ctx->ingest_out, dbytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));                                 // also keeps the host tables alive until copied
     if (ctx->prof) prof_collect(ctx);
     return VO_OK;
 }

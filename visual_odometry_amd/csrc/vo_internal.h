@@ -153,6 +153,8 @@ void launch_angle(hipStream_t s, const uint8_t* pyr, const PyrGeom& g, FrameFeat
 void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, int cn, int sstride, int64_t sframe,
                           uint8_t* dst, int dw, int dh, int dstride, int64_t dframe,
                           const int* xofs, const void* xa, const int* yofs, const void* yb, int area2, int F);
+void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride, uint8_t* dst, int dw, int dh, int dstride,
+                        int isx, int isy, const int* xsi, const float* xal, const int* xst, const int* ysi, const float* yal, const int* yst);
 void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, const int* offsets, int B, const double* Kd,
                        int iterations, double reproj_err, double confidence, uint64_t seed, const uint32_t* rng_tab, int rng_n,
                        double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status);
@@ -179,6 +181,8 @@ void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_
                               int dirs_mask, int knn2);
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
                          int mode, double ratio, const double* K);
+
+void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist);
 
 void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp, const uint32_t* rng_tab, int rng_n);
 void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);

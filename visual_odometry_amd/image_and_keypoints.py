@@ -6,6 +6,7 @@ from __future__ import annotations
 import numpy as np
 
 from .detector import ORB_create
+from .ingest import INTER_AREA, resize
 from .matcher import BFMatcher, NORM_HAMMING
 
 
@@ -26,10 +27,8 @@ class ImageAndKeypoints:
     def set_image(self, image):
         width = int(image.shape[1] * self.scale_factor)
         height = int(image.shape[0] * self.scale_factor)
-        if (height, width) != tuple(image.shape[:2]):
-            raise NotImplementedError("cv2.INTER_AREA rescaling is not built (visual_odometry_amd.ingest.resize offers "
-                                      "cv2.resize's default INTER_LINEAR); the reference runs with scale_factor = 1")
-        self.image = np.array(image, copy=True)                       # INTER_AREA at scale 1 is a copy
+        # cv2.resize(image, dim, interpolation=cv2.INTER_AREA)   (image_and_keypoints.py:42; scale_factor is 1 there)
+        self.image = resize(image, (width, height), interpolation=INTER_AREA)
 
     def detect_keypoints(self):
         self.keypoints, self.descriptors = self.detector.detectAndCompute(self.image, None)

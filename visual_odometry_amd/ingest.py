@@ -3,8 +3,8 @@
     img = cv2.imread(filename)                       # JPEG decode: host work, not rebuilt
     img = cv2.resize(img, (int(w * s), int(h * s)))  # -> ingest.resize(img, (int(w * s), int(h * s)))
 
-resize() mirrors cv2.resize(src, dsize) for 8-bit 1/3/4-channel images with the default INTER_LINEAR;
-INTER_AREA (src/image_and_keypoints.py:42, where scale_factor is 1) is accepted for the identity size only.
+resize() mirrors cv2.resize(src, dsize) for 8-bit 1/3/4-channel images with the default INTER_LINEAR and with
+INTER_AREA (src/image_and_keypoints.py:42) for any reduction (OpenCV's enlarging INTER_AREA is not built).
 """
 from __future__ import annotations
 
@@ -26,14 +26,12 @@ def resize(src, dsize, interpolation=INTER_LINEAR, ctx=None):
         raise ValueError("dsize must be positive")
     sh, sw = img.shape[:2]
     cn = 1 if img.ndim == 2 else img.shape[2]
-    if interpolation == INTER_AREA:
-        if (dw, dh) != (sw, sh):
-            raise NotImplementedError("INTER_AREA is only the identity here (image_and_keypoints.py:42 uses scale 1)")
-        return img.copy()
-    if interpolation != INTER_LINEAR:
-        raise NotImplementedError("only cv2.resize's default INTER_LINEAR is built")
+    if interpolation not in (INTER_LINEAR, INTER_AREA):
+        raise NotImplementedError("only INTER_LINEAR (cv2.resize's default) and INTER_AREA are built")
+    if interpolation == INTER_AREA and (dw > sw or dh > sh):
+        raise NotImplementedError("INTER_AREA enlargement (a bilinear variant in OpenCV) is not built")
     out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
     ctx = ctx or _lib.default_context()
-    ctx.check(ctx.lib.vo_resize_linear(ctx.handle, img.ctypes.data, sh, sw, cn, img.strides[0],
-                                       out.ctypes.data, dh, dw, out.strides[0]))
+    fn = ctx.lib.vo_resize_area if interpolation == INTER_AREA else ctx.lib.vo_resize_linear
+    ctx.check(fn(ctx.handle, img.ctypes.data, sh, sw, cn, img.strides[0], out.ctypes.data, dh, dw, out.strides[0]))
     return out

@@ -70,8 +70,49 @@ class HammingMatcher:
         return [DMatch(a, b, c) for a, b, c in zip(qi.tolist(), ti.tolist(), d.tolist())]
 
 
-def BFMatcher(normType=NORM_HAMMING, crossCheck=False) -> HammingMatcher:
-    """cv2.BFMatcher look-alike (Hamming only)."""
+class L2Matcher:
+    """cv2.BFMatcher(cv2.NORM_L2, crossCheck) on float32 descriptors — the reference's live matcher
+    (src/visual_slam.py:19; SIFT rows, 128 floats).  The SIFT detector itself is not built: this matcher takes any
+    float descriptor rows."""
+
+    def __init__(self, crossCheck: bool = False, legacy_crosscheck: bool = False, ctx: _lib.Context | None = None):
+        self.crossCheck = bool(crossCheck)
+        self.legacy_crosscheck = bool(legacy_crosscheck)
+        self._ctx = ctx
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
+
+    def match_arrays(self, query, train):
+        q = np.ascontiguousarray(query, dtype=np.float32); t = np.ascontiguousarray(train, dtype=np.float32)
+        if q.ndim != 2 or t.ndim != 2 or (len(q) and len(t) and q.shape[1] != t.shape[1]):
+            raise ValueError("descriptors must be N x dim float32 arrays of equal dim")
+        nq = len(q)
+        dim = q.shape[1] if nq else (t.shape[1] if len(t) else 1)
+        qi = np.empty(max(nq, 1), np.int32); ti = np.empty(max(nq, 1), np.int32); d = np.empty(max(nq, 1), np.float32)
+        n = C.c_int32(0)
+        mode = 0 if not self.crossCheck else (1 if self.legacy_crosscheck else 2)
+        ctx = self.ctx
+        ctx.check(ctx.lib.vo_match_l2(ctx.handle, q.ctypes.data, nq, t.ctypes.data, len(t), int(dim), mode,
+                                      qi.ctypes.data, ti.ctypes.data, d.ctypes.data, C.addressof(n)))
+        k = n.value
+        return qi[:k].copy(), ti[:k].copy(), d[:k].copy()
+
+    def match(self, queryDescriptors, trainDescriptors):
+        qi, ti, d = self.match_arrays(queryDescriptors, trainDescriptors)
+        return [DMatch(a, b, c) for a, b, c in zip(qi.tolist(), ti.tolist(), d.tolist())]
+
+
+NORM_L2 = 4
+
+
+def BFMatcher(normType=NORM_HAMMING, crossCheck=False):
+    """cv2.BFMatcher look-alike: NORM_HAMMING (ORB, the north-star path) or NORM_L2 (float descriptors)."""
+    if normType == NORM_L2:
+        return L2Matcher(crossCheck=crossCheck)
     if normType != NORM_HAMMING:
-        raise NotImplementedError("only NORM_HAMMING is implemented (ORB descriptors)")
+        raise NotImplementedError("only NORM_HAMMING and NORM_L2 are implemented")
     return HammingMatcher(crossCheck=crossCheck)
