@@ -29,7 +29,7 @@ extern "C" {
 #define VO_ERR_TOO_FEW       -3   /* fewer than 5 correspondences (cv2.findEssentialMat returns None) */
 #define VO_ERR_NO_MODEL      -4   /* RANSAC found no model with > 4 inliers */
 #define VO_ERR_NOT_CONFIGURED -5
-#define VO_ERR_UNSUPPORTED    -7   /* a branch of the cv2 call that is not built (solvePnPRansac with exactly 4 points: P3P) */
+#define VO_ERR_UNSUPPORTED    -7   /* a branch of the cv2 call that is not built (INTER_AREA enlargement) */
 #define VO_ERR_AMBIGUOUS      -6   /* exactly 5 correspondences: findEssentialMat stacks up to 10 solutions, which
                                      cv2.recoverPose (and the reference) cannot consume */
 
@@ -229,7 +229,8 @@ int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam, const dou
 /* cv2.solvePnPRansac(objectPoints, imagePoints, K, zeros(4)) with its default arguments (iterationsCount 100,
  * reprojectionError 8.0, confidence 0.99, SOLVEPNP_ITERATIVE) — src/visual_slam.py:231-235.
  * obj n x 3, img n x 2 (float64, row-major); rvec / tvec as cv2 returns them; mask[n] = 1 for inliers (cv2 returns
- * their indices).  VO_ERR_TOO_FEW: n < 4 (cv2 asserts); VO_ERR_UNSUPPORTED: n == 4; VO_ERR_NO_MODEL = retval False. */
+ * their indices).  n == 4 takes cv2's P3P branch (all four points inliers).  VO_ERR_TOO_FEW: n < 4 (cv2 asserts);
+ * VO_ERR_NO_MODEL = retval False. */
 int vo_solve_pnp_ransac(vo_ctx* ctx, const double* obj, const double* img, int n, const double K[9], int iterations,
                         double reproj_err, double confidence, uint64_t seed, double rvec[3], double tvec[3],
                         uint8_t* mask, int32_t* n_inl);

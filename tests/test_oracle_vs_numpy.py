@@ -342,7 +342,7 @@ def test_pnp_error_codes_and_rodrigues(oracle):
     from scipy.spatial.transform import Rotation
     K, X, uv, *_ = _pnp_problem(3, 4, 0.0)
     assert oracle.solve_pnp_ransac(X[:3], uv[:3], K)[0] == -3                # cv2 asserts npoints >= 4
-    assert oracle.solve_pnp_ransac(X, uv, K)[0] == -7                        # exactly 4: cv2's P3P branch, not restated
+    assert oracle.solve_pnp_ransac(X, uv, K)[0] == 0                         # exactly 4: cv2's P3P branch (test_p3p_branch_...)
     rng = np.random.default_rng(8)
     for _ in range(50):
         r = rng.normal(0, 1.3, 3)
@@ -393,3 +393,27 @@ def test_l2_matcher_against_numpy(oracle):
     mutual = [i for i in range(100) if rev[fwd[i]] == i]
     qi, ti, d = oracle.match_l2(q, t, 2)
     assert qi.tolist() == mutual and np.array_equal(ti, fwd[mutual])
+
+
+def test_p3p_branch_recovers_the_pose(oracle):
+    """solvePnPRansac's four-point branch (P3P + fourth-point disambiguation): on exact projections the generating
+    pose comes back, and the three solving points reproject to their pixels to float32 accuracy."""
+    rng = np.random.default_rng(5)
+    K = np.array([[800., 0, 320], [0, 800, 240], [0, 0, 1]])
+    good = 0
+    for _ in range(100):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 1.0)
+        kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * kx @ kx
+        t = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(4, 8)])
+        X = rng.uniform(-2, 2, (4, 3))
+        Xc = X @ R.T + t
+        uv = ((Xc / Xc[:, 2:]) @ K.T)[:, :2]
+        rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(X, uv, K)
+        assert rc == 0 and ninl == 4 and mask.tolist() == [1, 1, 1, 1]
+        Rg = oracle.rodrigues(rv)
+        Xg = X @ Rg.T + tv
+        rep = ((Xg / Xg[:, 2:]) @ K.T)[:, :2]
+        assert np.abs(rep[:3] - uv[:3]).max() < 1e-2             # the three points P3P solves with
+        good += np.abs(Rg - R).max() < 1e-4 and np.abs(tv - t).max() < 1e-3
+    assert good >= 95

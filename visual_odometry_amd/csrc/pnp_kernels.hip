@@ -512,6 +512,304 @@ struct PnpShared {
     int used, ctrl;
 };
 
+/* ------------------------------------------------------------------ P3P (calib3d p3p.cpp + polynom_solver.cpp), one thread
+ * cv2.solvePnPRansac with exactly four correspondences (src/visual_slam.py:231-235 when only four
+ * map points are matched): model_points == npoints, so solvePnP(..., SOLVEPNP_P3P) is called once and all four points
+ * are the inliers.  p3p::solve: Gao et al.'s complete P3P on the first three points (quartic in x = |PA| / |PC| by
+ * Ferrari's closed form, lengths, Horn's absolute orientation through a 4 x 4 Jacobi eigen-solver), candidates
+ * ordered by the squared reprojection error of the fourth point; the first is returned. */
+__device__ static int dq_solve_deg2(double a, double b, double c, double* x1, double* x2)
+{
+    double delta = b * b - 4 * a * c;
+    if (delta < 0) return 0;
+    double inv_2a = 0.5 / a;
+    if (delta == 0) { *x1 = -b * inv_2a; *x2 = *x1; return 1; }
+    double sqrt_delta = sqrt(delta);
+    *x1 = (-b + sqrt_delta) * inv_2a;
+    *x2 = (-b - sqrt_delta) * inv_2a;
+    return 2;
+}
+
+__device__ static int dq_solve_deg3(double a, double b, double c, double d, double* x0, double* x1, double* x2)
+{
+    if (a == 0) {
+        if (b == 0) {
+            if (c == 0) return 0;
+            *x0 = -d / c;
+            return 1;
+        }
+        *x2 = 0;
+        return dq_solve_deg2(b, c, d, x0, x1);
+    }
+    double inv_a = 1. / a;
+    double b_a = inv_a * b, b_a2 = b_a * b_a;
+    double c_a = inv_a * c;
+    double d_a = inv_a * d;
+    double Q = (3 * c_a - b_a2) / 9;
+    double R = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+    double Q3 = Q * Q * Q;
+    double D = Q3 + R * R;
+    double b_a_3 = (1. / 3.) * b_a;
+    if (Q == 0) {
+        if (R == 0) { *x0 = *x1 = *x2 = -b_a_3; return 3; }
+        *x0 = pow(2 * R, 1 / 3.0) - b_a_3;
+        return 1;
+    }
+    if (D <= 0) {
+        double theta = acos(R / sqrt(-Q3));
+        double sqrt_Q = sqrt(-Q);
+        *x0 = 2 * sqrt_Q * cos(theta / 3.0) - b_a_3;
+        *x1 = 2 * sqrt_Q * cos((theta + 2 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+        *x2 = 2 * sqrt_Q * cos((theta + 4 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+        return 3;
+    }
+    double AD = pow(fabs(R) + sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+    double BD = (AD == 0) ? 0 : -Q / AD;
+    *x0 = AD + BD - b_a_3;
+    return 1;
+}
+
+__device__ static int dq_solve_deg4(double a, double b, double c, double d, double e, double* x0, double* x1, double* x2, double* x3)
+{
+    if (a == 0) { *x3 = 0; return dq_solve_deg3(b, c, d, e, x0, x1, x2); }
+    double inv_a = 1. / a;
+    b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+    double b2 = b * b, bc = b * c, b3 = b2 * b;
+    double r0, r1, r2;
+    int n = dq_solve_deg3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, &r0, &r1, &r2);
+    if (n == 0) return 0;
+    double R2 = 0.25 * b2 - c + r0, R;
+    if (R2 < 0) return 0;
+    R = sqrt(R2);
+    double inv_R = 1. / R;
+    int nb_real_roots = 0;
+    double D2, E2;
+    if (R < 10E-12) {
+        double temp = r0 * r0 - 4 * e;
+        if (temp < 0) D2 = E2 = -1;
+        else {
+            double sqrt_temp = sqrt(temp);
+            D2 = 0.75 * b2 - 2 * c + 2 * sqrt_temp;
+            E2 = D2 - 4 * sqrt_temp;
+        }
+    } else {
+        double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+        D2 = u + v;
+        E2 = u - v;
+    }
+    double b_4 = 0.25 * b, R_2 = 0.5 * R;
+    if (D2 >= 0) {
+        double D = sqrt(D2);
+        nb_real_roots = 2;
+        double D_2 = 0.5 * D;
+        *x0 = R_2 + D_2 - b_4;
+        *x1 = *x0 - D;
+    }
+    if (E2 >= 0) {
+        double E = sqrt(E2);
+        double E_2 = 0.5 * E;
+        if (nb_real_roots == 0) { *x0 = -R_2 + E_2 - b_4; *x1 = *x0 - E; nb_real_roots = 2; }
+        else { *x2 = -R_2 + E_2 - b_4; *x3 = *x2 - E; nb_real_roots = 4; }
+    }
+    return nb_real_roots;
+}
+
+/* cyclic Jacobi eigen-solver of a symmetric 4 x 4 matrix (p3p::jacobi_4x4): D eigenvalues, columns of U eigenvectors */
+__device__ static int dq_jacobi_4x4(double* A, double* D, double* U)
+{
+    double B[4], Z[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1. : 0.;
+    B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+    for (int i = 0; i < 4; i++) D[i] = B[i];
+    for (int iter = 0; iter < 50; iter++) {
+        double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+        if (sum == 0.0) return 1;
+        double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+        for (int i = 0; i < 3; i++) {
+            double* pAij = A + 5 * i + 1;
+            for (int j = i + 1; j < 4; j++) {
+                double Aij = *pAij;
+                double eps_machine = 100.0 * fabs(Aij);
+                if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j])) *pAij = 0.0;
+                else if (fabs(Aij) > tresh) {
+                    double hh = D[j] - D[i], t;
+                    if (fabs(hh) + eps_machine == fabs(hh)) t = Aij / hh;
+                    else {
+                        double theta = 0.5 * hh / Aij;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    hh = t * Aij;
+                    Z[i] -= hh; Z[j] += hh; D[i] -= hh; D[j] += hh;
+                    *pAij = 0.0;
+                    double c = 1.0 / sqrt(1 + t * t);
+                    double s = t * c;
+                    double tau = s / (1.0 + c);
+                    for (int k = 0; k <= i - 1; k++) {
+                        double g = A[k * 4 + i], h = A[k * 4 + j];
+                        A[k * 4 + i] = g - s * (h + g * tau);
+                        A[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                    for (int k = i + 1; k <= j - 1; k++) {
+                        double g = A[i * 4 + k], h = A[k * 4 + j];
+                        A[i * 4 + k] = g - s * (h + g * tau);
+                        A[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                    for (int k = j + 1; k < 4; k++) {
+                        double g = A[i * 4 + k], h = A[j * 4 + k];
+                        A[i * 4 + k] = g - s * (h + g * tau);
+                        A[j * 4 + k] = h + s * (g - h * tau);
+                    }
+                    for (int k = 0; k < 4; k++) {
+                        double g = U[k * 4 + i], h = U[k * 4 + j];
+                        U[k * 4 + i] = g - s * (h + g * tau);
+                        U[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                }
+                pAij++;
+            }
+        }
+        for (int i = 0; i < 4; i++) { B[i] += Z[i]; D[i] = B[i]; Z[i] = 0; }
+    }
+    return 0;
+}
+
+/* Horn's closed-form absolute orientation of three point pairs (p3p::align) */
+__device__ static void dq_align(double M_end[3][3], const double X[3], const double Y[3], const double Z[3], double R[3][3], double T[3])
+{
+    double C_start[3], C_end[3];
+    for (int i = 0; i < 3; i++) C_end[i] = (M_end[0][i] + M_end[1][i] + M_end[2][i]) / 3;
+    C_start[0] = (X[0] + X[1] + X[2]) / 3;
+    C_start[1] = (Y[0] + Y[1] + Y[2]) / 3;
+    C_start[2] = (Z[0] + Z[1] + Z[2]) / 3;
+    double s[9];
+    for (int j = 0; j < 3; j++) {
+        s[0 * 3 + j] = (X[0] * M_end[0][j] + X[1] * M_end[1][j] + X[2] * M_end[2][j]) / 3 - C_end[j] * C_start[0];
+        s[1 * 3 + j] = (Y[0] * M_end[0][j] + Y[1] * M_end[1][j] + Y[2] * M_end[2][j]) / 3 - C_end[j] * C_start[1];
+        s[2 * 3 + j] = (Z[0] * M_end[0][j] + Z[1] * M_end[1][j] + Z[2] * M_end[2][j]) / 3 - C_end[j] * C_start[2];
+    }
+    double Qs[16], evs[4], U[16];
+    Qs[0 * 4 + 0] = s[0 * 3 + 0] + s[1 * 3 + 1] + s[2 * 3 + 2];
+    Qs[1 * 4 + 1] = s[0 * 3 + 0] - s[1 * 3 + 1] - s[2 * 3 + 2];
+    Qs[2 * 4 + 2] = s[1 * 3 + 1] - s[2 * 3 + 2] - s[0 * 3 + 0];
+    Qs[3 * 4 + 3] = s[2 * 3 + 2] - s[0 * 3 + 0] - s[1 * 3 + 1];
+    Qs[1 * 4 + 0] = Qs[0 * 4 + 1] = s[1 * 3 + 2] - s[2 * 3 + 1];
+    Qs[2 * 4 + 0] = Qs[0 * 4 + 2] = s[2 * 3 + 0] - s[0 * 3 + 2];
+    Qs[3 * 4 + 0] = Qs[0 * 4 + 3] = s[0 * 3 + 1] - s[1 * 3 + 0];
+    Qs[2 * 4 + 1] = Qs[1 * 4 + 2] = s[1 * 3 + 0] + s[0 * 3 + 1];
+    Qs[3 * 4 + 1] = Qs[1 * 4 + 3] = s[2 * 3 + 0] + s[0 * 3 + 2];
+    Qs[3 * 4 + 2] = Qs[2 * 4 + 3] = s[2 * 3 + 1] + s[1 * 3 + 2];
+    dq_jacobi_4x4(Qs, evs, U);
+    int i_ev = 0;
+    double ev_max = evs[0];
+    for (int i = 1; i < 4; i++) if (evs[i] > ev_max) ev_max = evs[i_ev = i];
+    double q[4];
+    for (int i = 0; i < 4; i++) q[i] = U[i * 4 + i_ev];
+    double q02 = q[0] * q[0], q12 = q[1] * q[1], q22 = q[2] * q[2], q32 = q[3] * q[3];
+    double q0_1 = q[0] * q[1], q0_2 = q[0] * q[2], q0_3 = q[0] * q[3];
+    double q1_2 = q[1] * q[2], q1_3 = q[1] * q[3], q2_3 = q[2] * q[3];
+    R[0][0] = q02 + q12 - q22 - q32; R[0][1] = 2. * (q1_2 - q0_3);     R[0][2] = 2. * (q1_3 + q0_2);
+    R[1][0] = 2. * (q1_2 + q0_3);     R[1][1] = q02 + q22 - q12 - q32; R[1][2] = 2. * (q2_3 - q0_1);
+    R[2][0] = 2. * (q1_3 - q0_2);     R[2][1] = 2. * (q2_3 + q0_1);     R[2][2] = q02 + q32 - q12 - q22;
+    for (int i = 0; i < 3; i++) T[i] = C_end[i] - (R[i][0] * C_start[0] + R[i][1] * C_start[1] + R[i][2] * C_start[2]);
+}
+
+/* Gao, Hou, Tang, Chang, "Complete Solution Classification for the Perspective-Three-Point Problem" (PAMI 2003),
+ * main branch, as p3p::solve_for_lengths: distances |BC|, |AC|, |AB|, cosines of the angles BPC, APC, APB */
+__device__ static int dq_solve_for_lengths(double lengths[4][3], const double distances[3], const double cosines[3])
+{
+    double p = cosines[0] * 2, q = cosines[1] * 2, r = cosines[2] * 2;
+    double inv_d22 = 1. / (distances[2] * distances[2]);
+    double a = inv_d22 * (distances[0] * distances[0]);
+    double b = inv_d22 * (distances[1] * distances[1]);
+    double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+    double pr = p * r, pqr = q * pr;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return 0;
+    double ab = a * b, a_2 = 2 * a;
+    double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return 0;
+    double a_4 = 4 * a;
+    double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+    double b0 = b * temp * temp;
+    if (b0 == 0) return 0;
+    double real_roots[4];
+    int n = dq_solve_deg4(A, B, C, D, E, &real_roots[0], &real_roots[1], &real_roots[2], &real_roots[3]);
+    if (n == 0) return 0;
+    int nb_solutions = 0;
+    double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+    double inv_b0 = 1. / b0;
+    for (int i = 0; i < n; i++) {
+        double x = real_roots[i];
+        if (x <= 0) continue;
+        double x2 = x * x;
+        double b1 =
+            ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+             2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+        if (b1 <= 0) continue;
+        double y = inv_b0 * b1;
+        double v = x2 + y * y - x * y * r;
+        if (v <= 0) continue;
+        double Z = distances[2] / sqrt(v);
+        lengths[nb_solutions][0] = x * Z;
+        lengths[nb_solutions][1] = y * Z;
+        lengths[nb_solutions][2] = Z;
+        nb_solutions++;
+    }
+    return nb_solutions;
+}
+
+/* p3p::solve with p4p: obj 4 x 3, img 4 x 2 (already through float32, as solvePnPRansac converts them); returns the
+ * number of candidates, the best (smallest reprojection error of point 3) in R[0], t[0] */
+__device__ static int dq_solve(const double* obj, const double* img, dp_cam K, double R[4][3][3], double t[4][3])
+{
+    const double inv_fx = 1. / K.fu, inv_fy = 1. / K.fv, cx_fx = K.uc / K.fu, cy_fy = K.vc / K.fv;
+    double mu[4], mv[4], mk[3], X[4], Y[4], Z[4];
+    for (int i = 0; i < 4; i++) { X[i] = (double)(float)obj[3 * i]; Y[i] = (double)(float)obj[3 * i + 1]; Z[i] = (double)(float)obj[3 * i + 2]; }
+    for (int i = 0; i < 4; i++) { mu[i] = inv_fx * (double)(float)img[2 * i] - cx_fx; mv[i] = inv_fy * (double)(float)img[2 * i + 1] - cy_fy; }
+    for (int i = 0; i < 3; i++) {
+        double norm = sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1);
+        mk[i] = 1. / norm; mu[i] *= mk[i]; mv[i] *= mk[i];
+    }
+    double distances[3], cosines[3];
+    distances[0] = sqrt((X[1] - X[2]) * (X[1] - X[2]) + (Y[1] - Y[2]) * (Y[1] - Y[2]) + (Z[1] - Z[2]) * (Z[1] - Z[2]));
+    distances[1] = sqrt((X[0] - X[2]) * (X[0] - X[2]) + (Y[0] - Y[2]) * (Y[0] - Y[2]) + (Z[0] - Z[2]) * (Z[0] - Z[2]));
+    distances[2] = sqrt((X[0] - X[1]) * (X[0] - X[1]) + (Y[0] - Y[1]) * (Y[0] - Y[1]) + (Z[0] - Z[1]) * (Z[0] - Z[1]));
+    cosines[0] = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
+    cosines[1] = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
+    cosines[2] = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
+    double lengths[4][3];
+    int n = dq_solve_for_lengths(lengths, distances, cosines);
+    int nb = 0;
+    double err[4];
+    for (int i = 0; i < n; i++) {
+        double M[3][3];
+        for (int k = 0; k < 3; k++) { M[k][0] = lengths[i][k] * mu[k]; M[k][1] = lengths[i][k] * mv[k]; M[k][2] = lengths[i][k] * mk[k]; }
+        dq_align(M, X, Y, Z, R[nb], t[nb]);
+        double X3p = R[nb][0][0] * X[3] + R[nb][0][1] * Y[3] + R[nb][0][2] * Z[3] + t[nb][0];
+        double Y3p = R[nb][1][0] * X[3] + R[nb][1][1] * Y[3] + R[nb][1][2] * Z[3] + t[nb][1];
+        double Z3p = R[nb][2][0] * X[3] + R[nb][2][1] * Y[3] + R[nb][2][2] * Z[3] + t[nb][2];
+        double mu3p = X3p / Z3p, mv3p = Y3p / Z3p;
+        err[nb] = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+        nb++;
+    }
+    for (int i = 1; i < nb; i++)                         /* insertion sort by the fourth point's error */
+        for (int j = i; j > 0 && err[j - 1] > err[j]; j--) {
+            double e = err[j]; err[j] = err[j - 1]; err[j - 1] = e;
+            for (int k = 0; k < 9; k++) { double v = (&R[j][0][0])[k]; (&R[j][0][0])[k] = (&R[j - 1][0][0])[k]; (&R[j - 1][0][0])[k] = v; }
+            for (int k = 0; k < 3; k++) { double v = t[j][k]; t[j][k] = t[j - 1][k]; t[j - 1][k] = v; }
+        }
+    return nb;
+}
+
 // sum of the 256 partials in thread order (the oracle's order); called by thread 0 after a barrier
 __device__ static void dp_reduce(const PnpShared& sh, double* tot)
 {
@@ -531,9 +829,22 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
     const double* obj = obj_all + (size_t)o0 * 3; const double* img = img_all + (size_t)o0 * 2;
     uint8_t* mask = mask_all + o0;
     const dp_cam K = {Kd[0], Kd[4], Kd[2], Kd[5]};
-    if (n < 4 || n == 4 || !(confidence > 0 && confidence < 1)) {
-        if (tid == 0) { status_out[pb] = n < 4 ? VO_ERR_TOO_FEW : n == 4 ? VO_ERR_UNSUPPORTED : VO_ERR_INVALID; ninl_out[pb] = 0; }
+    if (n < 4 || !(confidence > 0 && confidence < 1)) {
+        if (tid == 0) { status_out[pb] = n < 4 ? VO_ERR_TOO_FEW : VO_ERR_INVALID; ninl_out[pb] = 0; }
         for (int i = tid; i < n; i += 256) mask[i] = 0;
+        return;
+    }
+    if (n == 4) {                       // model_points == npoints == 4: solvePnP(SOLVEPNP_P3P) once, every point an inlier
+        if (tid == 0) {
+            double Rs[4][3][3], ts[4][3], r[3];
+            const int ns = dq_solve(obj, img, K, Rs, ts);
+            if (ns > 0) {
+                dp_rodrigues_to_vec(&Rs[0][0][0], r);
+                for (int k = 0; k < 3; k++) { rvec_out[3 * pb + k] = r[k]; tvec_out[3 * pb + k] = ts[0][k]; }
+            }
+            status_out[pb] = ns > 0 ? VO_OK : VO_ERR_NO_MODEL; ninl_out[pb] = ns > 0 ? 4 : 0;
+            for (int i = 0; i < 4; i++) mask[i] = ns > 0 ? 1 : 0;
+        }
         return;
     }
     if (n == 5) {                       // model_points == npoints: one EPnP, every point an inlier

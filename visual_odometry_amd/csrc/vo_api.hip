@@ -1384,7 +1384,6 @@ extern "C" int vo_solve_pnp_ransac(vo_ctx* ctx, const double* obj, const double*
                                        n > 0 ? mask : &dummy, n_inl, &status);
     if (rc) return rc;
     if (status == VO_ERR_TOO_FEW) FAIL(VO_ERR_TOO_FEW, "solvePnPRansac needs at least 4 correspondences, got %d", n);
-    if (status == VO_ERR_UNSUPPORTED) FAIL(VO_ERR_UNSUPPORTED, "solvePnPRansac with exactly 4 points (P3P) is not built");
     if (status == VO_ERR_NO_MODEL) FAIL(VO_ERR_NO_MODEL, "no pose with more than 4 inliers");
     if (status < 0) FAIL(status, "solvePnPRansac failed");
     return VO_OK;
