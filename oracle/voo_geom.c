@@ -266,17 +266,20 @@ static int solve_poly(const double* c, int n0, cplx* roots, int max_iters)
             }
             num = cdiv(num, denom);
             roots[i] = csub(p, num);
-            double ab = sqrt(num.re * num.re + num.im * num.im);
-            if (ab > max_diff) max_diff = ab;
+            /* the exit tests work on SQUARED magnitudes (OpenCV's only test, maxDiff <= 0, is the same on squares) */
+            double ab2 = num.re * num.re + num.im * num.im;
+            if (ab2 > max_diff) max_diff = ab2;
             double mag = fabs(roots[i].re) + fabs(roots[i].im);
             if (mag > max_mag) max_mag = mag;
-            conv_all &= ab <= 4 * DBL_EPSILON * mag;
+            double lim = 4 * DBL_EPSILON * mag;
+            conv_all &= ab2 <= lim * lim;
         }
         if (max_diff <= 0) break;
         if (g_dk_early_exit) {
             if (conv_all) break;
-            if (max_diff < 1e-7 * (1.0 + max_mag)) {
-                if (max_diff > 0.5 * prev) { if (++stall >= 2) break; }
+            double small = 1e-7 * (1.0 + max_mag);
+            if (max_diff < small * small) {
+                if (max_diff > 0.25 * prev) { if (++stall >= 2) break; }
                 else stall = 0;
             }
             prev = max_diff;

@@ -17,7 +17,9 @@
 #define WAVE 64
 // throughput mode gives up on a sample after this many sweeps (oracle/voo_geom.c VOO_DK_FAST_CAP: 0.07 % of the samples
 // never settle, and one such lane would hold its wavefront for all 300 sweeps)
+#ifndef VO_DK_FAST_CAP
 #define VO_DK_FAST_CAP 64
+#endif
 #ifndef VO_DK_ITERS
 #define VO_DK_ITERS 300
 #endif
@@ -213,24 +215,70 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
     for (int iter = 0; iter < sweeps; iter++) {
         bool conv_all = true;
         double max_diff = 0, max_mag = 0;
+        if (FULL) {
+            // The polynomial value at root i depends only on that root's value from the previous sweep, not on this
+            // sweep's updates of the roots before it: the ten Horner recurrences are evaluated first, interleaved
+            // (ten independent dependency chains instead of one), each in exactly the operation order of the
+            // sequential form.  Only the denominators, which do use the updated roots, stay in Gauss-Seidel order;
+            // the scheduler overlaps root i + 1's leading factors with the tail of root i.
+            double nr[10], ni[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) { nr[i] = c[10]; ni[i] = 0; }
+#pragma unroll
+            for (int j = 0; j < 10; j++)
+#pragma unroll
+                for (int i = 0; i < 10; i++) {
+                    const cplx np = cmul({nr[i], ni[i]}, {rr[i], ri[i]});
+                    nr[i] = np.re + c[9 - j]; ni[i] = np.im;
+                }
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const cplx p = {rr[i], ri[i]};
+                cplx denom = {c[10], 0};
+                bool coincident = false;                 // two estimates exactly equal: OpenCV skips that factor
+#pragma unroll
+                for (int j = 0; j < 10; j++)
+                    if (j != i) {
+                        const cplx d = {p.re - rr[j], p.im - ri[j]};
+                        coincident |= d.re == 0 && d.im == 0;
+                        denom = cmul(denom, d);
+                    }
+                if (__ballot(coincident)) {              // wave-uniform branch; never taken from the distinct starting points (1+i)^k in practice
+                  if (coincident) {
+                    denom = {c[10], 0};
+#pragma unroll
+                    for (int j = 0; j < 10; j++)
+                        if (j != i) {
+                            const cplx d = {p.re - rr[j], p.im - ri[j]};
+                            if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
+                        }
+                  }
+                }
+                const cplx num = cdiv({nr[i], ni[i]}, denom);
+                rr[i] = p.re - num.re; ri[i] = p.im - num.im;
+                // squared magnitudes: the exit tests compare squares (no square root per root)
+                const double ab2 = num.re * num.re + num.im * num.im;
+                max_diff = fmax(max_diff, ab2);
+                const double mag = fabs(rr[i]) + fabs(ri[i]);
+                max_mag = fmax(max_mag, mag);
+                const double lim = 4 * DBL_EPSILON * mag;
+                conv_all &= ab2 <= lim * lim;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 10; i++) {
-            if (FULL || i < n) {
+            if (i < n) {
                 cplx p = {rr[i], ri[i]};
                 double lead = c[10];
-                if (!FULL) {
 #pragma unroll
-                    for (int q = 1; q <= 10; q++) if (q == n) lead = c[q];
-                }
+                for (int q = 1; q <= 10; q++) if (q == n) lead = c[q];
                 cplx num = {lead, 0}, denom = {lead, 0};
 #pragma unroll
                 for (int j = 0; j < 10; j++) {
-                    if (FULL || j < n) {
+                    if (j < n) {
                         double cj = c[9 - j];
-                        if (!FULL) {
 #pragma unroll
-                            for (int q = 0; q < 10; q++) if (q == n - j - 1) cj = c[q];
-                        }
+                        for (int q = 0; q < 10; q++) if (q == n - j - 1) cj = c[q];
                         cplx np = cmul(num, p);
                         num.re = np.re + cj; num.im = np.im;
                         if (j != i) {
@@ -241,16 +289,20 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
                 }
                 num = cdiv(num, denom);
                 rr[i] = p.re - num.re; ri[i] = p.im - num.im;
-                const double ab = sqrt(num.re * num.re + num.im * num.im);
-                max_diff = fmax(max_diff, ab);
+                const double ab2 = num.re * num.re + num.im * num.im;
+                max_diff = fmax(max_diff, ab2);
                 const double mag = fabs(rr[i]) + fabs(ri[i]);
                 max_mag = fmax(max_mag, mag);
-                conv_all &= ab <= 4 * DBL_EPSILON * mag;
+                const double lim = 4 * DBL_EPSILON * mag;
+                conv_all &= ab2 <= lim * lim;
             }
         }
+        }
+        // max_diff holds the largest SQUARED correction of the sweep
         if (max_diff <= 0 || (early && conv_all)) break;
-        if (early && max_diff < 1e-7 * (1.0 + max_mag)) {
-            if (max_diff > 0.5 * prev) { if (++stall >= 2) break; }
+        const double small = 1e-7 * (1.0 + max_mag);
+        if (early && max_diff < small * small) {
+            if (max_diff > 0.25 * prev) { if (++stall >= 2) break; }
             else stall = 0;
         }
         prev = max_diff;
