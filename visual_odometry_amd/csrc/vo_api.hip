@@ -410,6 +410,23 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
             for (int x0 = 0; x0 < d.w && ok; x0 += RS_TW) { const int xl = (x0 + RS_TW < d.w ? x0 + RS_TW : d.w) - 1; ok = xo[xl] + 2 - (xo[x0] & ~15) <= RS_LW - 12; }
             for (int y0 = 0; y0 < d.h && ok; y0 += RS_TH) { const int yl = (y0 + RS_TH < d.h ? y0 + RS_TH : d.h) - 1; ok = yo[yl] + 2 - yo[y0] <= RS_LH; }
             t.tiled = ok ? 1 : 0;
+            // ... and k_resize_strip's: 256 x 64 tiles, 4 destination pixels within an 8-byte window starting at the first one
+            bool ok2 = true;
+            for (int x = 0; x + 3 < d.w && ok2; x++) ok2 = xo[x + 3] - xo[x] <= 4;
+            for (int x0 = 0; x0 < d.w && ok2; x0 += RS2_WW) { const int xl = (x0 + RS2_WW < d.w ? x0 + RS2_WW : d.w) - 1; ok2 = xo[xl] + 2 - (xo[x0] & ~15) <= RS2_LW - 12; }
+            for (int y0 = 0; y0 < d.h && ok2; y0 += RS2_TH) { const int yl = (y0 + RS2_TH < d.h ? y0 + RS2_TH : d.h) - 1; ok2 = yo[yl] + 2 - yo[y0] <= RS2_LH; }
+            for (int y = 0; y + 1 < d.h && ok2; y++) ok2 = yo[y + 1] > yo[y];          // every source row is the lower row of at most one destination row
+            const int ntx = (d.w + RS2_WW - 1) / RS2_WW, nty = (d.h + RS2_TH - 1) / RS2_TH;
+            ok2 = ok2 && ntx <= RS2_MAX_TX && nty <= RS2_MAX_TY;
+            for (int tx = 0; tx < ntx && ok2; tx++) t.strip_sx0[tx] = (short)(xo[tx * RS2_WW] & ~15);
+            for (int ty = 0; ty < nty && ok2; ty++) {
+                const int y0 = ty * RS2_TH, yl = (y0 + RS2_TH < d.h ? y0 + RS2_TH : d.h) - 1;
+                t.strip_sy0[ty] = (short)yo[y0];
+                t.strip_rows[ty] = (short)(yo[yl] + 2 - yo[y0] < RS2_LH ? yo[yl] + 2 - yo[y0] : RS2_LH);
+            }
+            const char* ev = getenv("VO_RESIZE_STRIP");
+            t.strip = ok2 && !(ev && ev[0] == '0') ? 1 : 0;
+            if (getenv("VO_DEBUG")) fprintf(stderr, "resize level %d: tiled %d strip %d\n", l, t.tiled, t.strip);
         }
     }
     HIPCHK(hipMemcpy(d_ofs, hofs.data(), int_bytes, hipMemcpyHostToDevice));
