@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PROFILE_TAG = "r02"       # profiles/<tag>_pmc_traffic.json holds this round's rocprofv3 PMC passes
 
 STAGE_KERNELS = {"fast_score_nms": [("k_fast<false>", 1)], "gaussian_blur": [("k_blur", 1)],
-                 "pyramid_resize": [("k_resize_tiled", 7)],
+                 "pyramid_resize": [("k_resize_strip", 7)],
                  "select_fast": [("k_sel_threshold", 1), ("k_sel_rows<false>", 1), ("k_sel_rows<true>", 1)],
                  "match_nn": [("k_nn_mfma<false>", 1)], "essential_ransac": [("k_ransac", 1)]}
 
