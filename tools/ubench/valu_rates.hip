@@ -14,7 +14,7 @@
 #include <vector>
 #include <algorithm>
 
-#define ITERS 256
+#define ITERS 2048
 #define PER_ITER 32
 
 #define R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
