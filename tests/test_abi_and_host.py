@@ -36,12 +36,12 @@ def test_struct_layouts_match_the_header():
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(ROOT, "visual_odometry_amd")
-    for dp, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".h")):
-                text = open(os.path.join(dp, f)).read()
-                assert "libvoo" not in text and "from oracle" not in text and "import oracle" not in text, f
+    for top in ("visual_odometry_amd", "examples", "tools", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".sh")):
+                    text = open(os.path.join(dp, f)).read()
+                    assert "libvoo" not in text and "from oracle" not in text and "import oracle" not in text, (top, f)
 
 
 def test_missing_gpu_fails_loudly():

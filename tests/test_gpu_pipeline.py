@@ -253,3 +253,30 @@ def test_reconfigure_recycles_memory_safely(oracle, seq_small):
         noise = np.stack([random_image(40 + round_ * 7 + k, 1080, 1920) | 0x80 for k in range(6)])
         big.upload(noise); big.detect(0, 6)
     c.close()
+
+
+def test_library_gather_equals_local_records(seq_small):
+    """vo_pairs_gather: the [R|t] + counts records packed on the device (k_pack_records) and all-gathered by the
+    library itself (ncclAllGather from librccl.so on the context's stream).  Without a communicator it returns the
+    local records; with a world-size-1 RCCL communicator the same bytes must come back through the collective.  Both
+    equal sharding.pack_records of the structured results (the host-side statement of the record layout)."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    from visual_odometry_amd.sharding import pack_records
+    frames, K = seq_small["frames"], seq_small["K"]
+    c = _lib.Context(0)
+    fe = FrontEnd(480, 640, max_frames=4, max_pairs=3, nfeatures=500, ctx=c)
+    fe.upload(frames[:4]); fe.detect(0, 4)
+    res = fe.run_pairs([[0, 1], [1, 2], [2, 3]], K)[0]
+    want = pack_records(res)
+    local = fe.gather_records(3).copy()
+    assert local.shape == (1, 3, _lib.VO_RECORD_DOUBLES) and np.array_equal(local[0], want)
+    c.comm_init(c.comm_unique_id(), 0, 1)
+    try:
+        got = fe.gather_records(3, world=1).copy()
+        assert np.array_equal(got[0], want)
+        part = fe.gather_records(2, world=1).copy()                    # a shorter prefix of the same run
+        assert np.array_equal(part[0], want[:2])
+    finally:
+        c.comm_destroy()
+    c.close()
