@@ -310,6 +310,36 @@ def resize_area(src, dw, dh):
     return dst
 
 
+JPEG_ERRORS = {-1: "corrupt", -2: "unsupported", -3: "output too small"}
+
+
+def jpeg_info(buf):
+    """(h, w, components, sampling of component 0 as h << 4 | v, EXIF orientation or 0) of a JPEG in memory (voo_jpeg.c)."""
+    b = np.frombuffer(bytes(buf), np.uint8)
+    v = [C.c_int32(0) for _ in range(5)]
+    f = lib().voo_jpeg_info
+    f.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 5
+    rc = f(b.ctypes.data, len(b), *[C.addressof(x) for x in v])
+    if rc == -1:
+        raise ValueError("corrupt JPEG header")
+    return tuple(x.value for x in v) + (rc == 0,)
+
+
+def jpeg_decode(buf):
+    """cv2.imdecode(buf, cv2.IMREAD_COLOR) / cv2.imread(file) for a baseline JPEG -> [h, w, 3] uint8, B G R (voo_jpeg.c)."""
+    b = np.frombuffer(bytes(buf), np.uint8)
+    h, w = jpeg_info(buf)[:2]
+    out = np.empty((h, w, 3), np.uint8)
+    f = lib().voo_jpeg_decode
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rc = f(b.ctypes.data, len(b), out.ctypes.data, out.strides[0], h, w)
+    if rc == -2:
+        raise NotImplementedError("JPEG layout outside the restated subset")
+    if rc != 0:
+        raise ValueError("JPEG decode failed: " + JPEG_ERRORS.get(rc, str(rc)))
+    return out
+
+
 def solve_pnp_ransac(obj, img, K, iterations=100, reproj_err=8.0, confidence=0.99, seed=0xFFFFFFFFFFFFFFFF):
     """cv2.solvePnPRansac(obj, img, K, zeros(4)) -> (rc, rvec [3], tvec [3], inlier mask, n_inliers)  (voo_pnp.c)."""
     obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3); img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)

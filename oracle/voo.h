@@ -15,6 +15,7 @@
  */
 #ifndef VOO_H
 #define VOO_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -114,6 +115,14 @@ int voo_resize_linear(const uint8_t* src, int sw, int sh, int cn, int sstride,
 int voo_resize_area_tab(int ssize, int dsize, int32_t* si, float* alpha, int32_t* start /*dsize + 1*/);
 int voo_resize_area(const uint8_t* src, int sw, int sh, int cn, int sstride,
                     uint8_t* dst, int dw, int dh, int dstride);
+
+/* the JPEG decode of cv2.imread(filename), visual_slam.py:346 (voo_jpeg.c; pinned against Pillow's libjpeg-turbo) */
+#define VOO_OK 0
+#define VOO_JPEG_CORRUPT (-1)
+#define VOO_JPEG_UNSUPPORTED (-2)
+#define VOO_JPEG_TOO_SMALL (-3)
+int voo_jpeg_info(const uint8_t* data, size_t n, int32_t* h, int32_t* w, int32_t* ncomp, int32_t* sampling, int32_t* orientation);
+int voo_jpeg_decode(const uint8_t* data, size_t n, uint8_t* out_bgr, int out_stride, int cap_h, int cap_w);
 
 /* --- "next" row: localisation, cv2.solvePnPRansac + cv2.Rodrigues, visual_slam.py:231-243 ---- */
 int voo_solve_pnp_ransac(const double* obj /*n x 3*/, const double* img /*n x 2*/, int n, const double* K,

@@ -1,0 +1,105 @@
+"""The JPEG-decode oracle (oracle/voo_jpeg.c = what cv2.imread does to a .jpg, /root/reference/src/visual_slam.py:346)
+PINNED against a real libjpeg-turbo: Pillow wraps the same library with the same defaults (JDCT_ISLOW, fancy
+upsampling), so PIL.Image.open(...) decodes byte for byte what cv2.imread decodes (cv2 returns the channels as B, G, R).
+Every supported layout is encoded with Pillow and compared bit for bit."""
+import io
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL")
+from PIL import Image  # noqa: E402
+
+
+def scene(seed, h, w, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if kind == "flat":
+        return np.full((h, w, 3), rng.integers(0, 256, 3), np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) * 7 % 256)], -1).astype(np.uint8)
+    for _ in range(12):                                                   # hard-edged coloured boxes: strong chroma edges
+        y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+        img[y0:y0 + int(rng.integers(1, 40)), x0:x0 + int(rng.integers(1, 40))] = rng.integers(0, 256, 3)
+    if kind == "saturated":
+        img = np.where(img > 127, 255, 0).astype(np.uint8)                # drives YCbCr -> RGB into the clamps
+    return img
+
+
+def encode(img, **kw):
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def pil_bgr(buf):
+    im = Image.open(io.BytesIO(buf))
+    im.load()
+    return np.asarray(im.convert("RGB"))[:, :, ::-1]
+
+
+CASES = [(h, w, ss, q, kind)
+         for (h, w) in [(8, 8), (1, 1), (2, 3), (5, 4), (16, 16), (17, 33), (64, 80), (99, 101), (240, 320), (31, 257)]
+         for ss in (0, 1, 2) for q, kind in [(90, "boxes"), (35, "noise")]]
+
+
+@pytest.mark.parametrize("h,w,ss,q,kind", CASES)
+def test_oracle_equals_libjpeg_turbo(oracle, h, w, ss, q, kind):
+    buf = encode(scene(h * 1000 + w, h, w, kind), quality=q, subsampling=ss)
+    got = oracle.jpeg_decode(buf)
+    want = pil_bgr(buf)
+    assert got.shape == want.shape and np.array_equal(got, want), (np.abs(got.astype(int) - want).max(), np.argwhere(got != want)[:4])
+
+
+@pytest.mark.parametrize("kw", [dict(quality=100, subsampling=0), dict(quality=1, subsampling=2), dict(quality=75, subsampling=2, optimize=True),
+                                dict(quality=95, subsampling=1, optimize=True), dict(quality=60, subsampling=2, restart_marker_blocks=1),
+                                dict(quality=60, subsampling=0, restart_marker_blocks=7), dict(quality=85, subsampling=2, restart_marker_rows=1),
+                                dict(quality=50, subsampling=2, qtables=[[min(255, 3 + 5 * i) for i in range(64)], [255 - 3 * i for i in range(64)]])])
+def test_table_and_restart_variants(oracle, kw):
+    for seed, kind in enumerate(["boxes", "saturated", "noise", "flat"]):
+        try:
+            buf = encode(scene(seed, 123, 187, kind), **kw)
+        except TypeError:
+            pytest.skip("this Pillow cannot write restart markers")
+        assert np.array_equal(oracle.jpeg_decode(buf), pil_bgr(buf)), (kw, kind)
+
+
+def test_grayscale_file_becomes_three_equal_channels(oracle):
+    g = scene(5, 77, 130, "boxes")[:, :, 1]
+    b = io.BytesIO(); Image.fromarray(g).save(b, "JPEG", quality=80)
+    got = oracle.jpeg_decode(b.getvalue())
+    want = np.asarray(Image.open(io.BytesIO(b.getvalue())))
+    assert got.shape == (77, 130, 3)
+    for c in range(3):
+        assert np.array_equal(got[:, :, c], want)
+
+
+def test_header_info_and_rejections(oracle):
+    img = scene(9, 40, 56, "boxes")
+    h, w, nc, samp, orient, ok = oracle.jpeg_info(encode(img, quality=80, subsampling=2))
+    assert (h, w, nc, samp, ok) == (40, 56, 3, 0x22, True)
+    assert oracle.jpeg_info(encode(img, quality=80, subsampling=1))[3] == 0x21
+    prog = encode(img, quality=80, progressive=True)
+    assert oracle.jpeg_info(prog)[5] is False
+    with pytest.raises(NotImplementedError):
+        oracle.jpeg_decode(prog)
+    cmyk = io.BytesIO(); Image.fromarray(img).convert("CMYK").save(cmyk, "JPEG")
+    with pytest.raises(NotImplementedError):
+        oracle.jpeg_decode(cmyk.getvalue())
+    good = encode(img, quality=80)
+    with pytest.raises(ValueError):
+        oracle.jpeg_decode(good[:2] + good[4:])                            # broken marker structure
+    with pytest.raises(ValueError):
+        oracle.jpeg_decode(b"not a jpeg at all")
+    # a truncated entropy segment decodes (libjpeg pads with zero bits); rows already complete are untouched
+    cut = good[:len(good) * 2 // 3] + b"\xff\xd9"
+    assert np.array_equal(oracle.jpeg_decode(cut)[:8], pil_bgr(good)[:8])
+
+
+def test_exif_orientation_is_reported(oracle):
+    img = scene(3, 24, 40, "boxes")
+    ex = Image.Exif(); ex[0x0112] = 6
+    b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", exif=ex)
+    assert oracle.jpeg_info(b.getvalue())[4] == 6
+    assert oracle.jpeg_info(encode(img))[4] == 0
