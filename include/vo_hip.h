@@ -250,6 +250,26 @@ int vo_resize_linear(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channe
  * src/image_and_keypoints.py:42 (ImageAndKeypoints.set_image).  VO_ERR_UNSUPPORTED: enlargement. */
 int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels, int row_stride,
                    uint8_t* dst, int dh, int dw, int dst_stride);
+/* cv2.imread(filename) for a .jpg — /root/reference/src/visual_slam.py:346 (also triangulate_points_from_images.py:14-15,
+ * feature_detection.py:5,10).  What cv2 does with such a file is libjpeg-turbo's default decompression: baseline Huffman
+ * decoding, the 13-bit integer IDCT (JDCT_ISLOW), triangle-filter ("fancy") chroma upsampling, fixed-point YCbCr -> RGB,
+ * channels delivered as B, G, R; a grey-scale file comes back with three equal channels (IMREAD_COLOR).  All of it runs
+ * on the device, Huffman decoding included (parallel inside one scan by self-synchronisation).
+ * Supported: SOF0 / SOF1 8-bit, grey or three components in one interleaved scan, 4:4:4 / 4:2:2 / 4:2:0, restart
+ * intervals.  VO_ERR_UNSUPPORTED: progressive, lossless, arithmetic, 12-bit, CMYK, other sampling ratios, multi-scan
+ * files.  VO_ERR_INVALID: not a JPEG / broken marker structure.  EXIF orientation is reported by vo_jpeg_info and NOT
+ * applied (cv2.imread applies it; the Python wrapper does the flip / transpose).
+ * vo_jpeg_info: header only, no context, no GPU.  sampling = (h << 4) | v of the first component. */
+int vo_jpeg_info(const uint8_t* data, size_t nbytes, int32_t* h, int32_t* w, int32_t* ncomp, int32_t* sampling, int32_t* orientation);
+/* cv2.imdecode(buf, cv2.IMREAD_COLOR): bgr_out = [h][w][3] dense, needs cap_h x cap_w >= h x w (sizes from vo_jpeg_info) */
+int vo_jpeg_decode(vo_ctx* ctx, const uint8_t* data, size_t nbytes, uint8_t* bgr_out, int cap_h, int cap_w, int32_t* h, int32_t* w);
+/* F files of identical size h x w, file f = blob[offsets[f] .. offsets[f + 1]); bgr_out = [F][h][w][3] dense */
+int vo_jpeg_decode_batch(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int F, uint8_t* bgr_out, int h, int w);
+/* The reference's whole ingest (visual_slam.py:346-352) for F files of identical size: imread -> cv2.resize(img, (w, h) of
+ * the batch configuration) -> gray into level 0 of slots first_slot ..; nothing but the compressed bytes crosses PCIe.
+ * resized_out (optional, host, [F][h][w][3]) receives the resized B G R frames (Frame.image). */
+int vo_frames_ingest_jpeg(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int F, int first_slot, uint8_t* resized_out);
+
 /* The batched form of the same step: F full-resolution host frames are resized on the device to the configured
  * (w, h), converted to gray as ORB does, and become level 0 of slots first_slot..; resized_out (optional, host,
  * [F][h][w][channels] dense) receives the resized frames (the reference keeps them as Frame.image). */

@@ -42,6 +42,7 @@ typedef struct {
     const uint8_t* p; size_t n, pos;
     uint32_t acc; int cnt;      /* bit accumulator */
     int marker;                 /* a marker was met inside the entropy-coded segment (0 = none) */
+    int insufficient;           /* bits were requested after the data ran out (jdhuff.c insufficient_data) */
 } bits_t;
 
 static int next_bit(bits_t* b)
@@ -55,7 +56,8 @@ static int next_bit(bits_t* b)
                 if (nx == 0) b->pos += 2;                    /* stuffed zero */
                 else { b->marker = nx; byte = 0; }           /* libjpeg: feed zero bits once a marker is reached */
             } else b->pos++;
-        }
+        } else if (!b->marker) b->marker = 0xD9;             /* the file simply ends */
+        if (b->marker) b->insufficient = 1;
         b->acc = (uint32_t)byte; b->cnt = 8;
     }
     b->cnt--;
@@ -331,7 +333,7 @@ int voo_jpeg_decode(const uint8_t* data, size_t n, uint8_t* out, int out_stride,
             if (!C[i].plane) goto done;
         }
         /* entropy-coded segment: MCU by MCU */
-        bits_t b = {data, n, pos, 0, 0, 0};
+        bits_t b = {data, n, pos, 0, 0, 0, 0};
         int16_t coef[64];
         const long total = (long)mx * my;
         for (long mcu = 0; mcu < total; mcu++) {
@@ -340,15 +342,20 @@ int voo_jpeg_decode(const uint8_t* data, size_t n, uint8_t* out, int out_stride,
                 if (!b.marker) {                                              /* (padding bits were not all consumed) */
                     if (b.pos + 1 < n && b.p[b.pos] == 0xFF && b.p[b.pos + 1] >= 0xD0 && b.p[b.pos + 1] <= 0xD7) b.marker = b.p[b.pos + 1];
                 }
-                if (b.marker < 0xD0 || b.marker > 0xD7) goto done;
-                b.pos += 2; b.marker = 0;
+                if (b.marker >= 0xD0 && b.marker <= 0xD7) { b.pos += 2; b.marker = 0; b.insufficient = 0; }
+                else if (!b.insufficient) goto done;
                 for (int i = 0; i < nc; i++) C[i].pred = 0;
             }
+            /* jdhuff.c decode_mcu: "If we've run out of data, just leave the MCU set to zeroes" — the MCU during which the
+             * data ran out is still decoded (from zero bits), every later one of the segment is left all-zero */
+            const int skip = b.insufficient;
             const int mxi = (int)(mcu % mx), myi = (int)(mcu / mx);
             for (int i = 0; i < nc; i++)
                 for (int by = 0; by < C[i].v; by++)
                     for (int bx = 0; bx < C[i].h; bx++) {
                         memset(coef, 0, sizeof(coef));
+                        const int px = (mxi * C[i].h + bx) * 8, py = (myi * C[i].v + by) * 8;
+                        if (skip) { idct_islow(coef, Q[C[i].tq], C[i].plane + (size_t)py * (C[i].bw * 8) + px, C[i].bw * 8); continue; }
                         int sy = decode_sym(&b, &H[C[i].td]);
                         if (sy < 0 || sy > 15) goto done;
                         C[i].pred += extend(receive(&b, sy), sy);
@@ -362,7 +369,6 @@ int voo_jpeg_decode(const uint8_t* data, size_t n, uint8_t* out, int out_stride,
                             if (k > 63) goto done;
                             coef[ZIGZAG[k]] = (int16_t)extend(receive(&b, sz), sz);
                         }
-                        const int px = (mxi * C[i].h + bx) * 8, py = (myi * C[i].v + by) * 8;
                         idct_islow(coef, Q[C[i].tq], C[i].plane + (size_t)py * (C[i].bw * 8) + px, C[i].bw * 8);
                     }
         }

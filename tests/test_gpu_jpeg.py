@@ -1,0 +1,124 @@
+"""JPEG decode on the MI355X (cv2.imread in front of the path, /root/reference/src/visual_slam.py:346): the HIP path
+(parallel Huffman decoding by self-synchronisation, integer IDCT, fancy upsampling, YCbCr -> B G R) against the CPU
+oracle AND against Pillow's libjpeg-turbo — bit for bit; this row's parity is pinned."""
+import io
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL")
+from PIL import Image  # noqa: E402
+
+from test_oracle_jpeg import encode, pil_bgr, scene  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("h,w", [(8, 8), (1, 1), (2, 3), (5, 4), (16, 16), (17, 33), (64, 80), (99, 101), (240, 320), (31, 257), (480, 640)])
+@pytest.mark.parametrize("ss", [0, 1, 2])
+def test_decode_equals_oracle_and_libjpeg(oracle, ctx, h, w, ss):
+    from visual_odometry_amd import ingest
+    for q, kind in [(90, "boxes"), (35, "noise")]:
+        buf = encode(scene(h * 1000 + w, h, w, kind), quality=q, subsampling=ss)
+        got = ingest.imdecode(buf, ctx)
+        assert np.array_equal(got, oracle.jpeg_decode(buf)), (q, kind)
+        assert np.array_equal(got, pil_bgr(buf)), (q, kind)
+
+
+@pytest.mark.parametrize("kw", [dict(quality=100, subsampling=0), dict(quality=1, subsampling=2), dict(quality=75, subsampling=2, optimize=True),
+                                dict(quality=95, subsampling=1, optimize=True), dict(quality=60, subsampling=2, restart_marker_blocks=1),
+                                dict(quality=60, subsampling=0, restart_marker_blocks=7), dict(quality=85, subsampling=2, restart_marker_rows=1),
+                                dict(quality=98, subsampling=0, restart_marker_blocks=3)])
+def test_tables_restarts_and_hard_content(oracle, ctx, kw):
+    from visual_odometry_amd import ingest
+    for seed, kind in enumerate(["boxes", "saturated", "noise", "flat"]):
+        buf = encode(scene(seed, 123, 187, kind), **kw)
+        got = ingest.imdecode(buf, ctx)
+        assert np.array_equal(got, oracle.jpeg_decode(buf)), (kw, kind)
+        assert np.array_equal(got, pil_bgr(buf)), (kw, kind)
+
+
+def test_flat_grey_with_restarts_every_block(oracle, ctx):
+    """4-bit MCUs (DC difference 0 + end of block) next to restart padding: the case where a padding run and a real MCU
+    can only be told apart by 'no Huffman code is all ones'."""
+    from visual_odometry_amd import ingest
+    for val in (0, 128, 255):
+        g = np.full((64, 200), val, np.uint8)
+        for rb in (1, 2, 3, 5):
+            b = io.BytesIO(); Image.fromarray(g).save(b, "JPEG", quality=90, restart_marker_blocks=rb)
+            got = ingest.imdecode(b.getvalue(), ctx)
+            assert np.array_equal(got, oracle.jpeg_decode(b.getvalue())), (val, rb)
+
+
+def test_large_frames_and_batches(oracle, ctx):
+    """A 1280x720 4:2:0 frame (every thread of the entropy kernel holds a few hundred symbols), a 4:2:2 one, and a batch
+    of 9 different files in one launch."""
+    from visual_odometry_amd import ingest
+    big = scene(77, 720, 1280, "boxes")
+    big = (big.astype(np.int32) + np.random.default_rng(5).integers(-12, 12, big.shape)).clip(0, 255).astype(np.uint8)
+    for ss, q in [(2, 92), (1, 70), (0, 50)]:
+        buf = encode(big, quality=q, subsampling=ss)
+        got = ingest.imdecode(buf, ctx)
+        assert np.array_equal(got, pil_bgr(buf)), (ss, q)
+    bufs = [encode(scene(100 + k, 240, 320, ["boxes", "noise", "saturated"][k % 3]), quality=30 + 7 * k, subsampling=k % 3,
+                   **({"restart_marker_rows": 1} if k % 4 == 0 else {})) for k in range(9)]
+    out = ingest.decode_batch(bufs, ctx)
+    for k, b in enumerate(bufs):
+        assert np.array_equal(out[k], pil_bgr(b)), k
+        assert np.array_equal(out[k], oracle.jpeg_decode(b)), k
+
+
+def test_grayscale_orientation_and_rejections(oracle, ctx, tmp_path):
+    from visual_odometry_amd import ingest
+    g = scene(5, 77, 130, "boxes")[:, :, 1]
+    b = io.BytesIO(); Image.fromarray(g).save(b, "JPEG", quality=80)
+    got = ingest.imdecode(b.getvalue(), ctx)
+    assert got.shape == (77, 130, 3) and np.array_equal(got, oracle.jpeg_decode(b.getvalue()))
+    img = scene(3, 24, 40, "boxes")
+    for o in range(1, 9):                                                   # cv2.imread applies the EXIF orientation
+        ex = Image.Exif(); ex[0x0112] = o
+        bb = io.BytesIO(); Image.fromarray(img).save(bb, "JPEG", exif=ex, quality=95)
+        from PIL import ImageOps
+        want = np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(bb.getvalue()))).convert("RGB"))[:, :, ::-1]
+        assert np.array_equal(ingest.imdecode(bb.getvalue(), ctx), want), o
+    path = tmp_path / "frame.jpg"
+    path.write_bytes(encode(img, quality=85))
+    assert np.array_equal(ingest.imread(str(path), ctx), pil_bgr(path.read_bytes()))
+    assert ingest.imread(str(tmp_path / "missing.jpg"), ctx) is None          # cv2.imread's behaviour
+    with pytest.raises(NotImplementedError):
+        ingest.imdecode(encode(img, progressive=True), ctx)
+    cmyk = io.BytesIO(); Image.fromarray(img).convert("CMYK").save(cmyk, "JPEG")
+    with pytest.raises(NotImplementedError):
+        ingest.imdecode(cmyk.getvalue(), ctx)
+    with pytest.raises(ValueError):
+        ingest.imdecode(b"definitely not a jpeg", ctx)
+    # truncated data: libjpeg decodes the MCU in which the data runs out from zero bits and leaves the later ones grey
+    from PIL import ImageFile
+    for frac in (0.4, 0.66, 0.9):
+        for ss in (0, 2):
+            good = encode(scene(11, 120, 200, "boxes"), quality=80, subsampling=ss)
+            cut = good[:int(len(good) * frac)] + b"\xff\xd9"
+            got = ingest.imdecode(cut, ctx)
+            assert np.array_equal(got, oracle.jpeg_decode(cut)), (frac, ss)
+            ImageFile.LOAD_TRUNCATED_IMAGES = True
+            try:
+                assert np.array_equal(got, pil_bgr(cut)), (frac, ss)
+            finally:
+                ImageFile.LOAD_TRUNCATED_IMAGES = False
+
+
+def test_ingest_jpeg_equals_decode_resize_gray(oracle, ctx):
+    """vo_frames_ingest_jpeg = imread -> cv2.resize -> gray (visual_slam.py:346-352) without leaving the device."""
+    from visual_odometry_amd.frontend import FrontEnd
+    bufs = [encode(scene(200 + k, 540, 960, "boxes"), quality=88, subsampling=2) for k in range(3)]
+    fe = FrontEnd(324, 576, max_frames=3, max_pairs=2, nfeatures=300, ctx=ctx)
+    resized = fe.ingest_jpeg(bufs, want_resized=True)
+    for k, b in enumerate(bufs):
+        want = oracle.resize_linear(oracle.jpeg_decode(b), 576, 324)
+        assert np.array_equal(resized[k], want), k
+    fe.detect(0, 3)
+    p = oracle.orb_params(nfeatures=300)
+    for k in range(3):
+        o = oracle.orb_detect_and_compute(resized[k], p)
+        f = fe.features(k)
+        assert np.array_equal(f["desc"], o["desc"]) and np.array_equal(f["xy"], o["xy"]), k

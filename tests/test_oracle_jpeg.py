@@ -92,9 +92,18 @@ def test_header_info_and_rejections(oracle):
         oracle.jpeg_decode(good[:2] + good[4:])                            # broken marker structure
     with pytest.raises(ValueError):
         oracle.jpeg_decode(b"not a jpeg at all")
-    # a truncated entropy segment decodes (libjpeg pads with zero bits); rows already complete are untouched
-    cut = good[:len(good) * 2 // 3] + b"\xff\xd9"
-    assert np.array_equal(oracle.jpeg_decode(cut)[:8], pil_bgr(good)[:8])
+    # a truncated entropy segment: the MCU in which the data runs out is decoded from zero bits, the later ones stay grey
+    for frac in (0.4, 0.66, 0.9):
+        for ss in (0, 2):
+            good = encode(scene(11, 120, 200, "boxes"), quality=80, subsampling=ss)
+            cut = good[:int(len(good) * frac)] + b"\xff\xd9"
+            from PIL import ImageFile
+            ImageFile.LOAD_TRUNCATED_IMAGES = True
+            try:
+                want = pil_bgr(cut)
+            finally:
+                ImageFile.LOAD_TRUNCATED_IMAGES = False
+            assert np.array_equal(oracle.jpeg_decode(cut), want), (frac, ss)
 
 
 def test_exif_orientation_is_reported(oracle):

@@ -84,6 +84,10 @@ _SIGS = {
     "vo_resize_linear": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vo_resize_area": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vo_frames_ingest": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _P]),
+    "vo_jpeg_info": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
+    "vo_jpeg_decode": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P]),
+    "vo_jpeg_decode_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int]),
+    "vo_frames_ingest_jpeg": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "vo_feature_tracks": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "vo_profile_enable": (C.c_int, [_P, C.c_int]),
     "vo_profile_reset": (C.c_int, [_P]),
@@ -181,6 +185,10 @@ class Context:
         """'fast' (default): Durand-Kerner sweeps stop at the rounding-noise floor; 'opencv300': cv::solvePoly's fixed
         300 sweeps (the faithful, 10x slower form of the five-point solver's root finder)."""
         self.check(self.lib.vo_set_poly_solver(self.handle, {"fast": 0, "opencv300": 1}[kind]))
+
+    def last_error(self) -> str:
+        msg = self.lib.vo_last_error(self.handle)
+        return msg.decode() if msg else ""
 
     def check(self, rc):
         if rc < 0:

@@ -1,0 +1,648 @@
+// jpeg_kernels.hip — the JPEG decode in front of the path: cv2.imread(filename), /root/reference/src/visual_slam.py:346
+// (also src/triangulate_points_from_images.py:14-15, src/feature_detection.py:5,10).  cv2 hands the file to
+// libjpeg-turbo with default parameters: baseline Huffman, JDCT_ISLOW, fancy chroma upsampling, YCbCr -> B G R.
+//
+// Device pipeline for a batch of files (one launch each, one workgroup per image for the two entropy kernels):
+//   k_jpeg_unstuff   byte stuffing (FF 00) and RSTn markers removed from the entropy-coded segment; the restart
+//                    positions and the end of the data found in parallel (flags -> workgroup scans -> scatter);
+//   k_jpeg_huffman   Huffman decoding IN PARALLEL inside one scan: the clean stream is cut into one subsequence per
+//                    thread; every thread decodes its subsequence from a guessed state, then the end states are
+//                    propagated (thread i restarts from thread i-1's end state) until nothing changes — Huffman codes
+//                    self-synchronise after a few symbols, so this takes two or three rounds; a scan of the per-thread
+//                    block counts gives every thread its first coefficient block, a last pass writes the coefficients
+//                    (de-zigzagged, DC as differences), and a segmented scan turns the DC differences into values;
+//   k_jpeg_idct      lane per 8x8 block: dequantisation + jidctint.c's two-pass 13-bit integer IDCT;
+//   k_jpeg_color     lane per 4 output pixels: h2v1 / h2v2 triangle upsampling (jdsample.c), jdcolor.c's fixed-point
+//                    YCbCr -> RGB, stores B G R.
+// Headers (SOI .. SOS) are parsed on the host (jpeg_parse): a few hundred bytes per file.
+#include "vo_internal.h"
+#include <string.h>
+
+static const uint8_t h_zigzag[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+__constant__ uint8_t d_zigzag[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ------------------------------------------------------------------ host: marker segments up to the scan header
+static inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+static int exif_orientation_of(const uint8_t* s, int len)
+{
+    if (len < 14 || memcmp(s, "Exif\0\0", 6) != 0) return 0;
+    const uint8_t* t = s + 6; const uint32_t n = (uint32_t)(len - 6);
+    const bool le = t[0] == 'I' && t[1] == 'I';
+    if (!le && !(t[0] == 'M' && t[1] == 'M')) return 0;
+    auto u16 = [&](uint32_t o) -> uint32_t { return le ? (uint32_t)(t[o] | (t[o + 1] << 8)) : (uint32_t)((t[o] << 8) | t[o + 1]); };
+    auto u32 = [&](uint32_t o) -> uint32_t { return le ? (u16(o) | (u16(o + 2) << 16)) : ((u16(o) << 16) | u16(o + 2)); };
+    const uint32_t ifd = u32(4);
+    if (ifd > n || ifd + 2 > n) return 0;
+    const uint32_t cnt = u16(ifd);
+    for (uint32_t i = 0; i < cnt; i++) {
+        const uint32_t e = ifd + 2 + 12 * i;
+        if (e + 12 > n) return 0;
+        if (u16(e) == 0x0112) { const uint32_t v = u16(e + 8); return v >= 1 && v <= 8 ? (int)v : 0; }
+    }
+    return 0;
+}
+
+int jpeg_info(const uint8_t* d, size_t n, int* h, int* w, int* ncomp, int* sampling, int* orientation)
+{
+    if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) return VO_ERR_INVALID;
+    size_t pos = 2;
+    int orient = 0;
+    while (pos + 4 <= n) {
+        if (d[pos] != 0xFF) return VO_ERR_INVALID;
+        while (pos < n && d[pos] == 0xFF) pos++;
+        if (pos >= n) break;
+        const int m = d[pos++];
+        if (m == 0xD9 || m == 0xDA || pos + 2 > n) break;
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        const int len = rd16(d + pos);
+        if (len < 2 || pos + (size_t)len > n) return VO_ERR_INVALID;
+        if (m == 0xE1 && !orient) orient = exif_orientation_of(d + pos + 2, len - 2);
+        if (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            if (len < 8) return VO_ERR_INVALID;
+            if (h) *h = rd16(d + pos + 3);
+            if (w) *w = rd16(d + pos + 5);
+            if (ncomp) *ncomp = d[pos + 7];
+            if (sampling) *sampling = len >= 11 ? d[pos + 9] : 0;
+            if (orientation) *orientation = orient;
+            return (m == 0xC0 || m == 0xC1) && d[pos + 2] == 8 ? VO_OK : VO_ERR_UNSUPPORTED;
+        }
+        pos += (size_t)len;
+    }
+    return VO_ERR_INVALID;
+}
+
+// canonical code book -> 9-bit look-ahead table + the (maxcode, value offset) pairs of the longer codes
+static bool build_tables(const uint8_t* counts /*16*/, const uint8_t* vals, int nvals, JpegTables* T, int slot)
+{
+    uint16_t* lut = T->lut[slot];
+    memset(lut, 0, sizeof(T->lut[slot]));
+    memset(T->vals[slot], 0, 256);
+    memcpy(T->vals[slot], vals, (size_t)nvals);
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; l++) {
+        const int cnt = counts[l - 1];
+        T->valoff[slot][l] = k - code;
+        if (cnt) {
+            if (l <= JPG_LOOK)
+                for (int i = 0; i < cnt; i++) {
+                    const int c = (code + i) << (JPG_LOOK - l);
+                    for (int j = 0; j < (1 << (JPG_LOOK - l)); j++) lut[c + j] = (uint16_t)((l << 8) | vals[k + i]);
+                }
+            code += cnt; k += cnt;
+            T->maxcode[slot][l] = code - 1;
+        } else T->maxcode[slot][l] = -1;
+        if (code > (1 << l)) return false;
+        code <<= 1;
+    }
+    T->maxcode[slot][17] = 0x7fffffff; T->valoff[slot][17] = 0;
+    T->maxcode[slot][0] = -1; T->valoff[slot][0] = 0;
+    return k == nvals;
+}
+
+// Fills img (geometry, table selectors, where the entropy-coded bytes start) and T; the caller assigns buffer offsets.
+int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why)
+{
+    static const char* dummy; if (!why) why = &dummy;
+    memset(img, 0, sizeof(*img)); memset(T, 0, sizeof(*T));
+    bool qseen[4] = {false, false, false, false}, hseen[8] = {false, false, false, false, false, false, false, false};
+    bool sof = false, jfif = false, adobe = false;
+    int adobe_tr = 0, cid[3] = {0, 0, 0};
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) { *why = "no SOI marker"; return VO_ERR_INVALID; }
+    size_t pos = 2;
+    for (;;) {
+        if (pos + 4 > n || d[pos] != 0xFF) { *why = "broken marker structure"; return VO_ERR_INVALID; }
+        while (pos < n && d[pos] == 0xFF) pos++;
+        if (pos >= n) { *why = "truncated file"; return VO_ERR_INVALID; }
+        const int m = d[pos++];
+        if (m == 0xD9) { *why = "no scan before EOI"; return VO_ERR_INVALID; }
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > n) { *why = "truncated file"; return VO_ERR_INVALID; }
+        const int len = rd16(d + pos);
+        if (len < 2 || pos + (size_t)len > n) { *why = "segment length past the end of the file"; return VO_ERR_INVALID; }
+        const uint8_t* s = d + pos + 2; const int sl = len - 2;
+        pos += (size_t)len;
+        if (m == 0xDB) {
+            for (int o = 0; o < sl;) {
+                const int pq = s[o] >> 4, tq = s[o] & 15; o++;
+                if (tq > 3 || pq > 1 || o + 64 * (pq + 1) > sl) { *why = "bad DQT"; return VO_ERR_INVALID; }
+                for (int i = 0; i < 64; i++) T->q[tq][h_zigzag[i]] = (uint16_t)(pq ? rd16(s + o + 2 * i) : s[o + i]);
+                o += 64 * (pq + 1); qseen[tq] = true;
+            }
+        } else if (m == 0xC4) {
+            for (int o = 0; o < sl;) {
+                if (o + 17 > sl) { *why = "bad DHT"; return VO_ERR_INVALID; }
+                const int tc = s[o] >> 4, th = s[o] & 15; o++;
+                int cnt = 0;
+                for (int l = 0; l < 16; l++) cnt += s[o + l];
+                if (tc > 1 || th > 3 || cnt > 256 || o + 16 + cnt > sl || !build_tables(s + o, s + o + 16, cnt, T, tc * 4 + th)) { *why = "bad DHT"; return VO_ERR_INVALID; }
+                hseen[tc * 4 + th] = true;
+                o += 16 + cnt;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {
+            if (sof || sl < 6) { *why = "bad SOF"; return VO_ERR_INVALID; }
+            if (s[0] != 8) { *why = "12-bit samples"; return VO_ERR_UNSUPPORTED; }
+            img->H = rd16(s + 1); img->W = rd16(s + 3); img->nc = s[5];
+            if (img->H == 0 || img->W == 0) { *why = "height defined by a DNL marker"; return VO_ERR_UNSUPPORTED; }
+            if (img->nc != 1 && img->nc != 3) { *why = "neither grey nor three components (CMYK?)"; return VO_ERR_UNSUPPORTED; }
+            if (sl < 6 + 3 * img->nc) { *why = "bad SOF"; return VO_ERR_INVALID; }
+            for (int i = 0; i < img->nc; i++) {
+                cid[i] = s[6 + 3 * i]; img->ch[i] = s[7 + 3 * i] >> 4; img->cv[i] = s[7 + 3 * i] & 15; img->tq[i] = s[8 + 3 * i];
+                if (img->ch[i] < 1 || img->ch[i] > 4 || img->cv[i] < 1 || img->cv[i] > 4 || img->tq[i] > 3) { *why = "bad SOF"; return VO_ERR_INVALID; }
+            }
+            sof = true;
+        } else if (m >= 0xC2 && m <= 0xCF) {
+            *why = "progressive, lossless or arithmetic-coded frame"; return VO_ERR_UNSUPPORTED;
+        } else if (m == 0xDD) {
+            if (sl < 2) { *why = "bad DRI"; return VO_ERR_INVALID; }
+            img->ri = rd16(s);
+        } else if (m == 0xE0) {
+            if (sl >= 5 && !memcmp(s, "JFIF\0", 5)) jfif = true;
+        } else if (m == 0xE1) {
+            if (!img->orientation) img->orientation = exif_orientation_of(s, sl);
+        } else if (m == 0xEE) {
+            if (sl >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_tr = s[11]; }
+        } else if (m == 0xDA) {
+            if (!sof || sl < 1) { *why = "scan before frame header"; return VO_ERR_INVALID; }
+            if (s[0] != img->nc) { *why = "components spread over several scans"; return VO_ERR_UNSUPPORTED; }
+            if (sl < 1 + 2 * img->nc + 3) { *why = "bad SOS"; return VO_ERR_INVALID; }
+            for (int i = 0; i < img->nc; i++) {
+                if (s[1 + 2 * i] != cid[i]) { *why = "scan component order differs from the frame's"; return VO_ERR_UNSUPPORTED; }
+                img->td[i] = s[2 + 2 * i] >> 4; img->ta[i] = s[2 + 2 * i] & 15;
+                if (img->td[i] > 3 || img->ta[i] > 3 || !hseen[img->td[i]] || !hseen[4 + img->ta[i]] || !qseen[img->tq[i]]) { *why = "scan refers to a missing table"; return VO_ERR_INVALID; }
+            }
+            break;
+        }
+    }
+    if (img->nc == 1) img->ch[0] = img->cv[0] = 1;                 // a single-component scan is never interleaved
+    int hmax = 1, vmax = 1;
+    for (int i = 0; i < img->nc; i++) { hmax = img->ch[i] > hmax ? img->ch[i] : hmax; vmax = img->cv[i] > vmax ? img->cv[i] : vmax; }
+    img->mode = 0;
+    if (img->nc == 3) {
+        if (img->ch[0] != hmax || img->cv[0] != vmax || img->ch[1] != img->ch[2] || img->cv[1] != img->cv[2]) { *why = "sampling factors outside 4:4:4 / 4:2:2 / 4:2:0"; return VO_ERR_UNSUPPORTED; }
+        if (img->ch[1] == hmax && img->cv[1] == vmax) img->mode = 0;
+        else if (img->ch[1] * 2 == hmax && img->cv[1] == vmax) img->mode = 1;
+        else if (img->ch[1] * 2 == hmax && img->cv[1] * 2 == vmax) img->mode = 2;
+        else { *why = "sampling factors outside 4:4:4 / 4:2:2 / 4:2:0"; return VO_ERR_UNSUPPORTED; }
+        img->ycc = jfif ? 1 : adobe ? (adobe_tr != 0) : !(cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B');
+    }
+    img->mx = (img->W + 8 * hmax - 1) / (8 * hmax); img->my = (img->H + 8 * vmax - 1) / (8 * vmax);
+    img->bpm = 0;
+    for (int i = 0; i < img->nc; i++) {
+        img->bw[i] = img->mx * img->ch[i]; img->bh[i] = img->my * img->cv[i];
+        img->dw[i] = (img->W * img->ch[i] + hmax - 1) / hmax; img->dh[i] = (img->H * img->cv[i] + vmax - 1) / vmax;
+        for (int by = 0; by < img->cv[i]; by++)
+            for (int bx = 0; bx < img->ch[i]; bx++) {
+                if (img->bpm >= JPG_MAX_BPM) { *why = "more than 10 blocks per MCU"; return VO_ERR_INVALID; }
+                img->blk_comp[img->bpm] = (uint8_t)i; img->blk_bx[img->bpm] = (uint8_t)bx; img->blk_by[img->bpm] = (uint8_t)by; img->bpm++;
+            }
+    }
+    const long long blocks = (long long)img->mx * img->my * img->bpm;
+    if (blocks > 0x3fffffff || n - pos > 0x7fffffffull) { *why = "image too large"; return VO_ERR_UNSUPPORTED; }
+    img->total_blocks = (int32_t)blocks;
+    img->raw_len = (uint32_t)(n - pos);
+    img->hdr_len = (uint32_t)pos;
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------ device helpers
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+__device__ __forceinline__ int wg_scan_excl(int v, int* s_tmp, int tid, int* total)
+{
+    // exclusive scan over JPG_NT threads: wave scans + one pass over the wave totals
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if ((tid & 63) >= d) inc += o; }
+    __syncthreads();
+    if ((tid & 63) == 63) s_tmp[tid >> 6] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < JPG_NT / 64; w++) { const int t = s_tmp[w]; if (w < (tid >> 6)) base += t; tot += t; }
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------ k_jpeg_unstuff
+// Byte i of the entropy-coded segment is dropped when it is the 00 of an FF 00 pair, a fill FF, or part of an RSTn
+// marker; any other FF xx ends the data.  An RSTn leaves its position in the clean stream in the restart list.
+__global__ __launch_bounds__(JPG_NT) void k_jpeg_unstuff(const uint8_t* blob, JpegImage* imgs, uint8_t* clean, uint32_t* rst)
+{
+    __shared__ int s_tmp[JPG_NT / 64];
+    __shared__ unsigned int s_end;
+    JpegImage& im = imgs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint8_t* raw = blob + im.raw_off;
+    const uint32_t n = im.raw_len;
+    const uint32_t per = (n + JPG_NT - 1) / JPG_NT;
+    const uint32_t lo = min(n, per * (uint32_t)tid), hi = min(n, lo + per);
+    if (tid == 0) s_end = n;
+    __syncthreads();
+    // the first terminating marker
+    uint32_t my_end = n;
+    for (uint32_t i = lo; i < hi; i++) {
+        if (raw[i] != 0xFF) continue;
+        const int nx = i + 1 < n ? raw[i + 1] : 0xD9;
+        if (nx != 0 && nx != 0xFF && !(nx >= 0xD0 && nx <= 0xD7)) { my_end = i; break; }
+    }
+    if (my_end < n) atomicMin(&s_end, my_end);
+    __syncthreads();
+    const uint32_t end = s_end;
+    int keep = 0, nr = 0;
+    for (uint32_t i = lo; i < hi && i < end; i++) {
+        const int c = raw[i], pv = i > 0 ? raw[i - 1] : 0, nx = i + 1 < n ? raw[i + 1] : 0xD9;
+        const bool rstm = c == 0xFF && nx >= 0xD0 && nx <= 0xD7;
+        const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
+        keep += !drop; nr += rstm;
+    }
+    int tot_keep, tot_r;
+    int kpos = wg_scan_excl(keep, s_tmp, tid, &tot_keep);
+    __syncthreads();
+    int rpos = wg_scan_excl(nr, s_tmp, tid, &tot_r);
+    uint8_t* out = clean + im.clean_off;
+    uint32_t* rl = rst + im.rst_off;
+    for (uint32_t i = lo; i < hi && i < end; i++) {
+        const int c = raw[i], pv = i > 0 ? raw[i - 1] : 0, nx = i + 1 < n ? raw[i + 1] : 0xD9;
+        const bool rstm = c == 0xFF && nx >= 0xD0 && nx <= 0xD7;
+        const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
+        if (rstm) { if ((uint32_t)rpos < im.rst_cap) rl[rpos] = (uint32_t)kpos; rpos++; }
+        if (!drop) out[kpos++] = (uint8_t)c;
+    }
+    // zero padding after the data: a decoder that runs past the end reads zero bits (as libjpeg supplies them)
+    for (uint32_t i = (uint32_t)tot_keep + tid; i < (uint32_t)tot_keep + JPG_PAD; i += JPG_NT) out[i] = 0;
+    if (tid == 0) { im.clean_len = (uint32_t)tot_keep; im.nrst = min((uint32_t)tot_r, im.rst_cap); }
+}
+
+// ------------------------------------------------------------------ k_jpeg_huffman
+struct JState { uint32_t bit; uint32_t bk; };              // position in the clean stream, (block in MCU << 8) | coefficient index
+
+struct JReader {
+    const uint8_t* p; uint32_t limit;                     // stream, number of readable bytes (data + padding)
+    uint64_t buf; int nb; uint32_t bytepos;
+    __device__ __forceinline__ void seek(uint32_t bit)
+    {
+        bytepos = bit >> 3; buf = 0; nb = 0;
+        refill();
+        const int skip = (int)(bit & 7u);
+        buf <<= skip; nb -= skip;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (nb <= 32) {
+            uint32_t w = 0;
+            if (bytepos + 4 <= limit) w = __builtin_bswap32(*(const u32_unaligned*)(p + bytepos));
+            buf |= (uint64_t)w << (32 - nb);
+            nb += 32; bytepos += 4;
+        }
+    }
+    __device__ __forceinline__ uint32_t pos() const { return bytepos * 8u - (uint32_t)nb; }
+    __device__ __forceinline__ void skip(int n) { buf <<= n; nb -= n; }
+};
+
+struct JTabs {                                            // LDS copies of the image's tables
+    uint16_t lut[8][1 << JPG_LOOK];
+    int32_t maxcode[8][18];
+    int32_t valoff[8][18];
+    uint8_t vals[8][256];
+};
+
+__device__ __forceinline__ int jpg_symbol(JReader& r, const JTabs& T, int slot)
+{
+    const uint32_t top = (uint32_t)(r.buf >> 48);                         // next 16 bits
+    const uint32_t e = T.lut[slot][top >> (16 - JPG_LOOK)];
+    if (e) { r.skip((int)(e >> 8)); return (int)(e & 255u); }
+    int l = JPG_LOOK + 1;
+    while (l <= 16 && (int)(top >> (16 - l)) > T.maxcode[slot][l]) l++;
+    if (l > 16) { r.skip(16); return 0; }                                 // no such code: corrupt data
+    const int sym = T.vals[slot][(T.valoff[slot][l] + (int)(top >> (16 - l))) & 255];
+    r.skip(l);
+    return sym;
+}
+
+__device__ __forceinline__ int jpg_value(JReader& r, int s)
+{
+    if (s == 0) return 0;
+    const int v = (int)(r.buf >> (64 - s));
+    r.skip(s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+// Decodes symbols from state st until the bit position reaches `boundary` (or max_done blocks are complete).  Returns
+// the number of blocks completed; WRITE stores the coefficients of block blk, blk + 1, ... (DC as the raw difference).
+template <bool WRITE>
+__device__ __forceinline__ int jpg_span(const JpegImage& im, const JTabs& T, const uint8_t* clean, const uint32_t* rst,
+                                        JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done = 0x7fffffff)
+{
+    JReader r; r.p = clean; r.limit = im.clean_len + JPG_PAD;
+    if (st.bit >= boundary) return 0;
+    r.seek(st.bit);
+    int b = (int)(st.bk >> 8), k = (int)(st.bk & 255u), done = 0;
+    // the first restart position after the start (positions are clean-stream byte offsets)
+    uint32_t ri_next = 0xffffffffu; int rj = 0;
+    const int nrst = (int)im.nrst;
+    if (im.ri && nrst) {
+        int lo = 0, hi = nrst;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rst[mid] * 8u > st.bit) hi = mid; else lo = mid + 1; }
+        rj = lo; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
+    }
+    const uint32_t total = (uint32_t)im.total_blocks;
+    uint32_t pos = st.bit;
+    while (pos < boundary && done < max_done) {
+        r.refill();
+        const int c = im.blk_comp[b];
+        if (k == 0) {
+            if (b == 0 && ri_next != 0xffffffffu && pos + 8 > ri_next) {
+                // an MCU boundary inside the last byte before a restart: the rest of the byte is padding (all ones —
+                // no Huffman code is all ones, so a real MCU cannot start like that)
+                const int rem = (int)(ri_next - pos);
+                if (rem == 0 || (r.buf >> (64 - rem)) == ((1ull << rem) - 1ull)) {
+                    r.seek(ri_next); pos = ri_next;
+                    rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
+                    continue;
+                }
+            }
+            const int s = jpg_symbol(r, T, im.td[c]) & 15;
+            r.refill();
+            const int diff = jpg_value(r, s);
+            if (WRITE && blk + done < total) coef[(size_t)(blk + done) * 64] = (int16_t)diff;
+            k = 1;
+        } else {
+            const int rs = jpg_symbol(r, T, 4 + im.ta[c]);
+            const int run = rs >> 4, s = rs & 15;
+            if (s == 0) k = run == 15 ? k + 16 : 64;
+            else {
+                k += run;
+                const int v = jpg_value(r, s);
+                if (WRITE && k < 64 && blk + done < total) coef[(size_t)(blk + done) * 64 + d_zigzag[k]] = (int16_t)v;
+                k++;
+            }
+            if (k >= 64) { k = 0; b = b + 1 == im.bpm ? 0 : b + 1; done++; }
+        }
+        pos = r.pos();
+        if (pos > ri_next) {                              // ran across a restart boundary: only a mis-synchronised thread does
+            r.seek(ri_next); pos = ri_next; b = 0; k = 0;
+            rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
+        }
+    }
+    st.bit = pos; st.bk = ((uint32_t)b << 8) | (uint32_t)k;
+    return done;
+}
+
+__global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, const JpegTables* tabs, const uint8_t* clean_all,
+                                                         const uint32_t* rst_all, int16_t* coef_all)
+{
+    __shared__ JTabs T;
+    __shared__ JState s_st[JPG_NT];
+    __shared__ int s_cnt[JPG_NT];
+    __shared__ int s_tmp[JPG_NT / 64];
+    __shared__ int s_dc[JPG_NT][4];                        // per-thread DC sums of three components + "saw a restart"
+    __shared__ int s_valid_mcus;
+    const JpegImage& im = imgs[blockIdx.x];
+    const JpegTables& G = tabs[blockIdx.x];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8 * (1 << JPG_LOOK); i += JPG_NT) (&T.lut[0][0])[i] = (&G.lut[0][0])[i];
+    for (int i = tid; i < 8 * 18; i += JPG_NT) { (&T.maxcode[0][0])[i] = (&G.maxcode[0][0])[i]; (&T.valoff[0][0])[i] = (&G.valoff[0][0])[i]; }
+    for (int i = tid; i < 8 * 256; i += JPG_NT) (&T.vals[0][0])[i] = (&G.vals[0][0])[i];
+    const uint8_t* clean = clean_all + im.clean_off;
+    const uint32_t* rst = rst_all + im.rst_off;
+    int16_t* coef = coef_all + (size_t)im.coef_blk * 64;
+    const uint32_t nbits = im.clean_len * 8u;
+    // one subsequence per thread, a whole number of bytes, at least 32 bytes
+    uint32_t sub = (im.clean_len + JPG_NT - 1) / JPG_NT; sub = sub < 32 ? 32 : sub;
+    const uint32_t b0 = min(nbits, sub * 8u * (uint32_t)tid), b1 = min(nbits, b0 + sub * 8u);
+    const bool live = b0 < nbits;                          // threads past the end of the data hold empty subsequences
+    __syncthreads();
+    // 1. cold start: assume a block starts at the subsequence boundary (true for thread 0)
+    JState mine; mine.bit = b0; mine.bk = 0;
+    int cnt = 0;
+    if (live) cnt = jpg_span<false>(im, T, clean, rst, mine, b1, nullptr, 0);
+    s_st[tid] = mine; s_cnt[tid] = cnt;
+    __syncthreads();
+    // 2. propagate end states until they are stable: thread i restarts from thread i-1's end state
+    JState used; used.bit = 0xffffffffu; used.bk = 0xffffffffu;      // the start state the current result was computed from
+    if (tid == 0) { used.bit = 0; used.bk = 0; }
+    for (int round = 0; round < JPG_NT; round++) {
+        JState prev; prev.bit = 0; prev.bk = 0;
+        if (tid > 0) prev = s_st[tid - 1];
+        const bool redo = live && tid > 0 && (prev.bit != used.bit || prev.bk != used.bk);
+        __syncthreads();
+        bool changed = false;
+        if (redo) {
+            JState st = prev;
+            const int c = jpg_span<false>(im, T, clean, rst, st, b1, nullptr, 0);
+            changed = st.bit != s_st[tid].bit || st.bk != s_st[tid].bk;
+            s_st[tid] = st; s_cnt[tid] = c; used = prev;
+        }
+        if (!__syncthreads_or(changed ? 1 : 0)) break;
+    }
+    __syncthreads();
+    // 3. first coefficient block of every subsequence; 4. decode once more, writing
+    int total_cnt;
+    const int first = wg_scan_excl(live ? s_cnt[tid] : 0, s_tmp, tid, &total_cnt);
+    if (live) {
+        JState st; st.bit = 0; st.bk = 0;
+        if (tid > 0) st = s_st[tid - 1];
+        jpg_span<true>(im, T, clean, rst, st, b1, coef, (uint32_t)first);
+    }
+    // 4b. a file whose data ends early (truncated, or cut by a stray marker): libjpeg decodes the MCU in which the data
+    //     ran out from zero bits and leaves every later MCU all-zero (jdhuff.c: insufficient_data) — the last
+    //     subsequence's owner finishes that MCU from the zero padding, the MCUs after it keep their cleared coefficients
+    if (tid == 0) s_valid_mcus = im.mx * im.my;
+    __syncthreads();
+    if (total_cnt < im.total_blocks) {
+        const int last = (int)min((uint32_t)(JPG_NT - 1), (nbits ? (nbits - 1) / (sub * 8u) : 0u));
+        if (tid == last) {
+            JState st = s_st[last];
+            if (nbits == 0) { st.bit = 0; st.bk = 0; }
+            const int mcu = total_cnt / im.bpm;
+            jpg_span<true>(im, T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, (mcu + 1) * im.bpm - total_cnt);
+            s_valid_mcus = mcu + 1;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // 5. DC differences -> DC values: a segmented scan over the MCUs (the prediction restarts every `ri` MCUs)
+    const int mcus = s_valid_mcus, per = (mcus + JPG_NT - 1) / JPG_NT;
+    const int m0 = min(mcus, per * tid), m1 = min(mcus, m0 + per);
+    int sum[3] = {0, 0, 0}, reset = 0;
+    for (int m = m0; m < m1; m++) {
+        if (im.ri && m % im.ri == 0) { sum[0] = sum[1] = sum[2] = 0; reset = 1; }
+        for (int j = 0; j < im.bpm; j++) sum[im.blk_comp[j]] += coef[((size_t)m * im.bpm + j) * 64];
+    }
+    s_dc[tid][0] = sum[0]; s_dc[tid][1] = sum[1]; s_dc[tid][2] = sum[2]; s_dc[tid][3] = reset;
+    __syncthreads();
+    for (int d = 1; d < JPG_NT; d <<= 1) {                 // inclusive scan with the operator (a, b) -> b.reset ? b : a + b
+        int a0 = 0, a1 = 0, a2 = 0, ar = 0;
+        const bool has = tid >= d;
+        if (has) { a0 = s_dc[tid - d][0]; a1 = s_dc[tid - d][1]; a2 = s_dc[tid - d][2]; ar = s_dc[tid - d][3]; }
+        __syncthreads();
+        if (has && !s_dc[tid][3]) { s_dc[tid][0] += a0; s_dc[tid][1] += a1; s_dc[tid][2] += a2; s_dc[tid][3] = ar; }
+        __syncthreads();
+    }
+    int pred[3] = {0, 0, 0};
+    if (tid > 0) { pred[0] = s_dc[tid - 1][0]; pred[1] = s_dc[tid - 1][1]; pred[2] = s_dc[tid - 1][2]; }
+    for (int m = m0; m < m1; m++) {
+        if (im.ri && m % im.ri == 0) pred[0] = pred[1] = pred[2] = 0;
+        for (int j = 0; j < im.bpm; j++) {
+            int16_t* p = coef + ((size_t)m * im.bpm + j) * 64;
+            const int c = im.blk_comp[j];
+            pred[c] += *p; *p = (int16_t)pred[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_jpeg_idct  (jidctint.c jpeg_idct_islow)
+__device__ __forceinline__ int32_t jmul(int32_t a, int32_t c) { return (int32_t)((uint32_t)a * (uint32_t)c); }
+__device__ __forceinline__ int32_t jadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t jsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t jdescale(int32_t x, int n) { return jadd(x, 1 << (n - 1)) >> n; }
+
+template <int SHIFT>
+__device__ __forceinline__ void jidct_1d(const int32_t* in, int32_t* out)
+{
+    int32_t z1, z2, z3, z4, z5, t0, t1, t2, t3, t10, t11, t12, t13;
+    z2 = in[2]; z3 = in[6];
+    z1 = jmul(jadd(z2, z3), 4433);
+    t2 = jadd(z1, jmul(z3, -15137));
+    t3 = jadd(z1, jmul(z2, 6270));
+    z2 = in[0]; z3 = in[4];
+    t0 = (int32_t)((uint32_t)jadd(z2, z3) << 13); t1 = (int32_t)((uint32_t)jsub(z2, z3) << 13);
+    t10 = jadd(t0, t3); t13 = jsub(t0, t3); t11 = jadd(t1, t2); t12 = jsub(t1, t2);
+    t0 = in[7]; t1 = in[5]; t2 = in[3]; t3 = in[1];
+    z1 = jadd(t0, t3); z2 = jadd(t1, t2); z3 = jadd(t0, t2); z4 = jadd(t1, t3);
+    z5 = jmul(jadd(z3, z4), 9633);
+    t0 = jmul(t0, 2446); t1 = jmul(t1, 16819); t2 = jmul(t2, 25172); t3 = jmul(t3, 12299);
+    z1 = jmul(z1, -7373); z2 = jmul(z2, -20995); z3 = jmul(z3, -16069); z4 = jmul(z4, -3196);
+    z3 = jadd(z3, z5); z4 = jadd(z4, z5);
+    t0 = jadd(t0, jadd(z1, z3)); t1 = jadd(t1, jadd(z2, z4)); t2 = jadd(t2, jadd(z2, z3)); t3 = jadd(t3, jadd(z1, z4));
+    out[0] = jdescale(jadd(t10, t3), SHIFT); out[7] = jdescale(jsub(t10, t3), SHIFT);
+    out[1] = jdescale(jadd(t11, t2), SHIFT); out[6] = jdescale(jsub(t11, t2), SHIFT);
+    out[2] = jdescale(jadd(t12, t1), SHIFT); out[5] = jdescale(jsub(t12, t1), SHIFT);
+    out[3] = jdescale(jadd(t13, t0), SHIFT); out[4] = jdescale(jsub(t13, t0), SHIFT);
+}
+
+__device__ __forceinline__ uint32_t jlimit(int32_t v)
+{
+    const int s = (int)(((uint32_t)v & 1023u) ^ 512u) - 512;              // IDCT_range_limit[v & RANGE_MASK]
+    return (uint32_t)min(max(s + 128, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImage* imgs, const JpegTables* tabs, const int16_t* coef_all, uint8_t* planes)
+{
+    const JpegImage& im = imgs[blockIdx.y];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= im.total_blocks) return;
+    const int mcu = j / im.bpm, jj = j - mcu * im.bpm;
+    const int c = im.blk_comp[jj];
+    const int px = ((mcu % im.mx) * im.ch[c] + im.blk_bx[jj]) * 8, py = ((mcu / im.mx) * im.cv[c] + im.blk_by[jj]) * 8;
+    const uint16_t* q = tabs[blockIdx.y].q[im.tq[c]];
+    const uint4* src = (const uint4*)(coef_all + ((size_t)im.coef_blk + j) * 64);
+    int32_t ws[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {                                         // one row of coefficients per 16-byte load
+        const uint4 v = src[r];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ws[8 * r + 2 * k] = jmul((int32_t)(int16_t)(w[k] & 0xffffu), (int32_t)q[8 * r + 2 * k]);
+            ws[8 * r + 2 * k + 1] = jmul((int32_t)(int16_t)(w[k] >> 16), (int32_t)q[8 * r + 2 * k + 1]);
+        }
+    }
+#pragma unroll
+    for (int col = 0; col < 8; col++) {
+        int32_t in[8], o[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) in[r] = ws[8 * r + col];
+        jidct_1d<11>(in, o);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[8 * r + col] = o[r];
+    }
+    const int stride = im.bw[c] * 8;
+    uint8_t* dst = planes + im.plane_off[c] + (size_t)py * stride + px;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int32_t o[8];
+        jidct_1d<18>(ws + 8 * r, o);
+        uint2 pk;
+        pk.x = jlimit(o[0]) | (jlimit(o[1]) << 8) | (jlimit(o[2]) << 16) | (jlimit(o[3]) << 24);
+        pk.y = jlimit(o[4]) | (jlimit(o[5]) << 8) | (jlimit(o[6]) << 16) | (jlimit(o[7]) << 24);
+        *(uint2*)(dst + (size_t)r * stride) = pk;
+    }
+}
+
+// ------------------------------------------------------------------ k_jpeg_color  (jdsample.c + jdcolor.c)
+__device__ __forceinline__ int up_h2v1(const uint8_t* in, int dw, int x)
+{
+    const int i = x >> 1;
+    if (dw <= 2 || x == 0 || x == 2 * dw - 1) return in[i];
+    return (x & 1) ? (in[i] * 3 + in[i + 1] + 2) >> 2 : (in[i] * 3 + in[i - 1] + 1) >> 2;
+}
+
+__device__ __forceinline__ int up_h2v2(const uint8_t* in0, const uint8_t* in1, int dw, int x)
+{
+    const int i = x >> 1;
+    if (dw <= 2) return in0[i];
+    const int cur = in0[i] * 3 + in1[i];
+    if (x == 0) return (cur * 4 + 8) >> 4;
+    if (x == 2 * dw - 1) return (cur * 4 + 7) >> 4;
+    return (x & 1) ? (cur * 3 + in0[i + 1] * 3 + in1[i + 1] + 7) >> 4 : (cur * 3 + in0[i - 1] * 3 + in1[i - 1] + 8) >> 4;
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const uint8_t* planes, uint8_t* out_all)
+{
+    const JpegImage& im = imgs[blockIdx.z];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (y >= im.H || x4 >= im.W) return;
+    const uint8_t* yrow = planes + im.plane_off[0] + (size_t)y * (im.bw[0] * 8);
+    uint8_t* o = out_all + im.out_off + (size_t)y * im.out_stride + (size_t)x4 * 3;
+    uint8_t px[12];
+    const int nx = min(4, im.W - x4);
+    if (im.nc == 1) {
+        for (int k = 0; k < nx; k++) px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = yrow[x4 + k];
+    } else {
+        const int st = im.bw[1] * 8, dw = im.dw[1], dh = im.dh[1];
+        const uint8_t* cbp = planes + im.plane_off[1]; const uint8_t* crp = planes + im.plane_off[2];
+        for (int k = 0; k < nx; k++) {
+            const int x = x4 + k;
+            int Cb, Cr;
+            if (im.mode == 0) { Cb = cbp[(size_t)y * st + x]; Cr = crp[(size_t)y * st + x]; }
+            else if (im.mode == 1) { Cb = up_h2v1(cbp + (size_t)y * st, dw, x); Cr = up_h2v1(crp + (size_t)y * st, dw, x); }
+            else {
+                const int r = y >> 1;
+                const int r1 = min(max((y & 1) ? r + 1 : r - 1, 0), dh - 1);        // the context row: above (even rows) / below (odd rows)
+                Cb = up_h2v2(cbp + (size_t)r * st, cbp + (size_t)r1 * st, dw, x);
+                Cr = up_h2v2(crp + (size_t)r * st, crp + (size_t)r1 * st, dw, x);
+            }
+            const int Y = yrow[x];
+            if (!im.ycc) { px[3 * k] = (uint8_t)Cr; px[3 * k + 1] = (uint8_t)Cb; px[3 * k + 2] = (uint8_t)Y; continue; }
+            const int xb = Cb - 128, xr = Cr - 128;
+            const int R = Y + ((91881 * xr + 32768) >> 16);
+            const int G = Y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
+            const int B = Y + ((116130 * xb + 32768) >> 16);
+            px[3 * k] = (uint8_t)min(max(B, 0), 255); px[3 * k + 1] = (uint8_t)min(max(G, 0), 255); px[3 * k + 2] = (uint8_t)min(max(R, 0), 255);
+        }
+    }
+    if (nx == 4 && (((size_t)(o - out_all)) & 3) == 0) {
+        uint32_t* o32 = (uint32_t*)o;
+        o32[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
+        o32[1] = px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24);
+        o32[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
+    } else {
+        for (int k = 0; k < 3 * nx; k++) o[k] = px[k];
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
+                        int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h)
+{
+    hipLaunchKernelGGL(k_jpeg_unstuff, dim3(F), dim3(JPG_NT), 0, s, blob, imgs, clean, rst);
+    hipLaunchKernelGGL(k_jpeg_huffman, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, F), dim3(256), 0, s, imgs, tabs, coef, planes);
+    hipLaunchKernelGGL(k_jpeg_color, dim3((max_w + 1023) / 1024, max_h, F), dim3(256), 0, s, imgs, planes, out);
+}

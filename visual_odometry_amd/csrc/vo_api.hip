@@ -30,6 +30,10 @@ struct vo_ctx {
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
     uint8_t* desc_x = nullptr;            // descriptors expanded to +1 / -1 bytes for the MFMA matcher
     uint8_t* ingest_out = nullptr; size_t ingest_out_bytes = 0;      // resized frames (frame ingest)
+    // JPEG decode: the batch's files, clean streams, restart lists, coefficients, component planes, B G R output, descriptors
+    uint8_t *jpg_blob = nullptr, *jpg_clean = nullptr, *jpg_rst = nullptr, *jpg_coef = nullptr, *jpg_planes = nullptr, *jpg_out = nullptr,
+            *jpg_img = nullptr, *jpg_tab = nullptr;
+    size_t jpg_blob_n = 0, jpg_clean_n = 0, jpg_rst_n = 0, jpg_coef_n = 0, jpg_planes_n = 0, jpg_out_n = 0, jpg_img_n = 0, jpg_tab_n = 0;
     int* ingest_tab = nullptr; size_t ingest_tab_n = 0;              // resize tables
     int *sel_thr = nullptr, *sel_chunk_count = nullptr, *har_kept = nullptr;
     float* har_thr = nullptr;
@@ -331,7 +335,8 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     free_config(ctx);
     free_pairbuf(ctx->raw_pb);
     void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab, ctx->raw_desc_x,
-                    ctx->ingest_out, ctx->ingest_tab};
+                    ctx->ingest_out, ctx->ingest_tab, ctx->jpg_blob, ctx->jpg_clean, ctx->jpg_rst, ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out,
+                    ctx->jpg_img, ctx->jpg_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
     if (ctx->ev_det) (void)hipEventDestroy(ctx->ev_det);
@@ -1588,6 +1593,38 @@ extern "C" int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, i
     return VO_OK;
 }
 
+// n full-resolution frames already on the device -> cv2.resize to the configured (w, h) -> gray -> level 0 of the slots
+static int ingest_from_device(vo_ctx* ctx, const uint8_t* src, int n, int sh, int sw, int channels, int row_stride, int64_t frame_stride,
+                              int first_slot, uint8_t* resized_out)
+{
+    const int dw = ctx->w, dh = ctx->h;
+    const size_t dper = (size_t)dw * dh * channels;
+    int rc = ensure_bytes(ctx, &ctx->ingest_out, &ctx->ingest_out_bytes, dper * n); if (rc) return rc;
+    const int* xofs; const void* xa; const int* yofs; const void* yb;
+    rc = ingest_tables(ctx, sw, sh, dw, dh, &xofs, &xa, &yofs, &yb); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    const LevelGeom& lv = ctx->g.lv[0];
+    uint8_t* lvl0 = ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes + lv.off;
+    {
+        StageTimer t(ctx, ST_MISC);
+        if (channels == 1 && !resized_out)                   // gray input: straight into level 0
+            launch_resize_linear(s, src, sw, sh, 1, row_stride, frame_stride, lvl0, dw, dh, lv.stride, ctx->g.frame_bytes,
+                                 xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, n);
+        else
+            launch_resize_linear(s, src, sw, sh, channels, row_stride, frame_stride, ctx->ingest_out, dw, dh, dw * channels,
+                                 (int64_t)dper, xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, n);
+    }
+    if (!(channels == 1 && !resized_out)) {
+        StageTimer t(ctx, ST_GRAY);
+        launch_gray(s, ctx->ingest_out, channels, dw * channels, (int64_t)dper,
+                    ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes, ctx->g, n);
+        if (resized_out) HIPCHK(hipMemcpyAsync(resized_out, ctx->ingest_out, dper * n, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return VO_OK;
+}
+
 // Full-resolution frames (host) -> resized to the configured (w, h) on the device -> gray -> level 0 of the slots.
 // `resized_out` (optional, host, [F][h][w][channels] dense) receives the resized frames, which the reference
 // keeps as Frame.image.
@@ -1605,32 +1642,142 @@ extern "C" int vo_frames_ingest(vo_ctx* ctx, const uint8_t* frames, int F, int s
     const size_t per = (size_t)frame_stride, dper = (size_t)dw * dh * channels;
     size_t chunk = (size_t)512 * 1024 * 1024 / per; if (chunk < 1) chunk = 1; if (chunk > (size_t)F) chunk = F;
     int rc = ensure_bytes(ctx, &ctx->staging, &ctx->staging_bytes, per * chunk); if (rc) return rc;
-    rc = ensure_bytes(ctx, &ctx->ingest_out, &ctx->ingest_out_bytes, dper * chunk); if (rc) return rc;
-    const int* xofs; const void* xa; const int* yofs; const void* yb;
-    rc = ingest_tables(ctx, sw, sh, dw, dh, &xofs, &xa, &yofs, &yb); if (rc) return rc;
     hipStream_t s = ctx->stream;
-    const LevelGeom& lv = ctx->g.lv[0];
     for (int f0 = 0; f0 < F; f0 += (int)chunk) {
         const int n = F - f0 < (int)chunk ? F - f0 : (int)chunk;
         HIPCHK(hipMemcpyAsync(ctx->staging, frames + (size_t)f0 * per, per * n, hipMemcpyHostToDevice, s));
-        uint8_t* lvl0 = ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes + lv.off;
-        {
-            StageTimer t(ctx, ST_MISC);
-            if (channels == 1 && !resized_out)                   // gray input: straight into level 0
-                launch_resize_linear(s, ctx->staging, sw, sh, 1, row_stride, (int64_t)per, lvl0, dw, dh, lv.stride, ctx->g.frame_bytes,
-                                     xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, n);
-            else
-                launch_resize_linear(s, ctx->staging, sw, sh, channels, row_stride, (int64_t)per, ctx->ingest_out, dw, dh, dw * channels,
-                                     (int64_t)dper, xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, n);
-        }
-        if (!(channels == 1 && !resized_out)) {
-            StageTimer t(ctx, ST_GRAY);
-            launch_gray(s, ctx->ingest_out, channels, dw * channels, (int64_t)dper,
-                        ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes, ctx->g, n);
-            if (resized_out) HIPCHK(hipMemcpyAsync(resized_out + (size_t)f0 * dper, ctx->ingest_out, dper * n, hipMemcpyDeviceToHost, s));
-        }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
+        rc = ingest_from_device(ctx, ctx->staging, n, sh, sw, channels, row_stride, (int64_t)per, first_slot + f0,
+                                resized_out ? resized_out + (size_t)f0 * dper : nullptr);
+        if (rc) return rc;
+    }
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+
+// ------------------------------------------------------------------ "next" row: JPEG decode (cv2.imread, visual_slam.py:346)
+extern "C" int vo_jpeg_info(const uint8_t* data, size_t nbytes, int32_t* h, int32_t* w, int32_t* ncomp, int32_t* sampling, int32_t* orientation)
+{
+    int hh = 0, ww = 0, nc = 0, sa = 0, orr = 0;
+    const int rc = jpeg_info(data, nbytes, &hh, &ww, &nc, &sa, &orr);
+    if (rc == VO_ERR_INVALID) return rc;
+    if (h) *h = hh; if (w) *w = ww; if (ncomp) *ncomp = nc; if (sampling) *sampling = sa; if (orientation) *orientation = orr;
+    return rc;
+}
+
+// Decodes files [f0, f0 + n) of the blob into ctx->jpg_out (device, B G R, image k at k * out_frame bytes, rows of
+// out_w * 3 bytes).  Every file must be exactly out_h x out_w.  Leaves the work queued on the context's stream.
+static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int f0, int n, int out_h, int out_w)
+{
+    std::vector<JpegImage> imgs((size_t)n);
+    std::vector<JpegTables> tabs((size_t)n);
+    const size_t base = (size_t)offsets[f0], bytes = (size_t)(offsets[f0 + n] - offsets[f0]);
+    size_t clean = 0, rst = 0, blocks = 0, planes = 0;
+    int max_blocks = 0;
+    for (int k = 0; k < n; k++) {
+        const char* why = "";
+        const size_t o = (size_t)offsets[f0 + k], len = (size_t)(offsets[f0 + k + 1] - offsets[f0 + k]);
+        const int rc = jpeg_parse(blob + o, len, &imgs[k], &tabs[k], &why);
+        if (rc) FAIL(rc, "JPEG %d: %s", f0 + k, why);
+        JpegImage& im = imgs[k];
+        if (im.H != out_h || im.W != out_w) FAIL(VO_ERR_INVALID, "JPEG %d is %d x %d, the batch expects %d x %d", f0 + k, im.W, im.H, out_w, out_h);
+        im.raw_off = (uint32_t)(o - base + im.hdr_len);
+        im.clean_off = (uint32_t)clean; clean += ((size_t)im.raw_len + JPG_PAD + 15) & ~(size_t)15;
+        im.rst_off = (uint32_t)rst; im.rst_cap = im.ri ? (uint32_t)((im.mx * im.my + im.ri - 1) / im.ri + 2) : 0; rst += im.rst_cap;
+        im.coef_blk = (uint32_t)blocks; blocks += (size_t)im.total_blocks;
+        for (int c = 0; c < im.nc; c++) { im.plane_off[c] = planes; planes += ((size_t)im.bw[c] * 8 * im.bh[c] * 8 + 255) & ~(size_t)255; }
+        im.out_off = (uint64_t)k * out_h * out_w * 3; im.out_stride = (uint32_t)out_w * 3;
+        if (im.total_blocks > max_blocks) max_blocks = im.total_blocks;
+        if (clean > 0xf0000000ull || blocks > 0xf0000000ull) FAIL(VO_ERR_UNSUPPORTED, "JPEG batch too large for one launch");
+    }
+    if (bytes > 0xf0000000ull) FAIL(VO_ERR_UNSUPPORTED, "JPEG batch too large for one launch");
+    int rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_blob, &ctx->jpg_blob_n, bytes + 16))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_clean, &ctx->jpg_clean_n, clean + 16))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_rst, &ctx->jpg_rst_n, (rst + 4) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_coef, &ctx->jpg_coef_n, blocks * 128 + 16))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_planes, &ctx->jpg_planes_n, planes + 256))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_out, &ctx->jpg_out_n, (size_t)n * out_h * out_w * 3 + 16))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_img, &ctx->jpg_img_n, (size_t)n * sizeof(JpegImage)))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_tab, &ctx->jpg_tab_n, (size_t)n * sizeof(JpegTables)))) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemcpyAsync(ctx->jpg_blob, blob + base, bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->jpg_img, imgs.data(), (size_t)n * sizeof(JpegImage), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->jpg_tab, tabs.data(), (size_t)n * sizeof(JpegTables), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(ctx->jpg_coef, 0, blocks * 128, s));
+    {
+        StageTimer t(ctx, ST_MISC);
+        launch_jpeg_decode(s, ctx->jpg_blob, (JpegImage*)ctx->jpg_img, (const JpegTables*)ctx->jpg_tab, n, ctx->jpg_clean, (uint32_t*)ctx->jpg_rst,
+                           (int16_t*)ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out, max_blocks, out_w, out_h);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));                  // the host vectors must outlive their copies
+    return VO_OK;
+}
+
+// how many files of a batch go through the device at once (coefficients: 2 bytes per sample and component)
+static int jpeg_chunk(int h, int w, int F)
+{
+    const size_t per = (size_t)h * w * 8 + (1 << 20);
+    size_t c = ((size_t)6 << 30) / per;
+    if (c < 1) c = 1;
+    return c > (size_t)F ? F : (int)c;
+}
+
+extern "C" int vo_jpeg_decode_batch(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int F, uint8_t* bgr_out, int h, int w)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!blob || !offsets || !bgr_out || F < 0 || h < 1 || w < 1) FAIL(VO_ERR_INVALID, "bad arguments");
+    for (int f = 0; f < F; f++) if (offsets[f + 1] < offsets[f] + 4) FAIL(VO_ERR_INVALID, "file %d is empty", f);
+    if (F == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int chunk = jpeg_chunk(h, w, F);
+    const size_t per = (size_t)h * w * 3;
+    for (int f0 = 0; f0 < F; f0 += chunk) {
+        const int n = F - f0 < chunk ? F - f0 : chunk;
+        const int rc = jpeg_decode_device(ctx, blob, offsets, f0, n, h, w);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(bgr_out + (size_t)f0 * per, ctx->jpg_out, per * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+extern "C" int vo_jpeg_decode(vo_ctx* ctx, const uint8_t* data, size_t nbytes, uint8_t* bgr_out, int cap_h, int cap_w, int32_t* h, int32_t* w)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!data || !bgr_out) FAIL(VO_ERR_INVALID, "bad arguments");
+    int hh = 0, ww = 0, nc = 0, sa = 0, orr = 0;
+    const int irc = jpeg_info(data, nbytes, &hh, &ww, &nc, &sa, &orr);
+    if (irc == VO_ERR_INVALID) FAIL(VO_ERR_INVALID, "not a JPEG file");
+    if (h) *h = hh; if (w) *w = ww;
+    if (irc) FAIL(irc, "JPEG frame type outside the baseline decoder (progressive, lossless, arithmetic or 12-bit)");
+    if (hh > cap_h || ww > cap_w) FAIL(VO_ERR_INVALID, "output buffer %d x %d too small for a %d x %d image", cap_w, cap_h, ww, hh);
+    const int64_t offs[2] = {0, (int64_t)nbytes};
+    return vo_jpeg_decode_batch(ctx, data, offs, 1, bgr_out, hh, ww);
+}
+
+extern "C" int vo_frames_ingest_jpeg(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int F, int first_slot, uint8_t* resized_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!blob || !offsets || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    for (int f = 0; f < F; f++) if (offsets[f + 1] < offsets[f] + 4) FAIL(VO_ERR_INVALID, "file %d is empty", f);
+    if (F == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    int sh = 0, sw = 0, nc = 0, sa = 0, orr = 0;
+    const int irc = jpeg_info(blob + offsets[0], (size_t)(offsets[1] - offsets[0]), &sh, &sw, &nc, &sa, &orr);
+    if (irc) FAIL(irc, "file 0 is not a baseline JPEG");
+    const int chunk = jpeg_chunk(sh, sw, F);
+    const size_t dper = (size_t)ctx->w * ctx->h * 3;
+    for (int f0 = 0; f0 < F; f0 += chunk) {
+        const int n = F - f0 < chunk ? F - f0 : chunk;
+        int rc = jpeg_decode_device(ctx, blob, offsets, f0, n, sh, sw);
+        if (rc) return rc;
+        rc = ingest_from_device(ctx, ctx->jpg_out, n, sh, sw, 3, sw * 3, (int64_t)sh * sw * 3, first_slot + f0,
+                                resized_out ? resized_out + (size_t)f0 * dper : nullptr);
+        if (rc) return rc;
     }
     if (ctx->prof) prof_collect(ctx);
     return VO_OK;

@@ -1,7 +1,11 @@
-"""Frame ingest on the MI355X: the resize in front of the path (src/visual_slam.py:346-352).
+"""Frame ingest on the MI355X: the decode and resize in front of the path (src/visual_slam.py:346-352).
 
-    img = cv2.imread(filename)                       # JPEG decode: host work, not rebuilt
+    img = cv2.imread(filename)                       # -> ingest.imread(filename)   (baseline JPEG, decoded on the GPU)
     img = cv2.resize(img, (int(w * s), int(h * s)))  # -> ingest.resize(img, (int(w * s), int(h * s)))
+
+imread() / imdecode() mirror cv2.imread(file) / cv2.imdecode(buf, cv2.IMREAD_COLOR) for baseline JPEG files: what cv2 gets
+from libjpeg-turbo (integer IDCT, fancy upsampling, B G R), EXIF orientation applied as cv2 does; decode_batch() takes many
+files of one size in a single launch sequence.
 
 resize() mirrors cv2.resize(src, dsize) for 8-bit 1/3/4-channel images with the default INTER_LINEAR and with
 INTER_AREA (src/image_and_keypoints.py:42) for any reduction (OpenCV's enlarging INTER_AREA is not built).
@@ -34,4 +38,69 @@ def resize(src, dsize, interpolation=INTER_LINEAR, ctx=None):
     ctx = ctx or _lib.default_context()
     fn = ctx.lib.vo_resize_area if interpolation == INTER_AREA else ctx.lib.vo_resize_linear
     ctx.check(fn(ctx.handle, img.ctypes.data, sh, sw, cn, img.strides[0], out.ctypes.data, dh, dw, out.strides[0]))
+    return out
+
+
+# EXIF orientation -> the array operation cv2.imread applies (ExifTransform in OpenCV's loadsave.cpp)
+def _apply_orientation(img, o):
+    if o == 2: return img[:, ::-1]
+    if o == 3: return img[::-1, ::-1]
+    if o == 4: return img[::-1]
+    if o == 5: return img.transpose(1, 0, 2)
+    if o == 6: return img.transpose(1, 0, 2)[:, ::-1]
+    if o == 7: return img.transpose(1, 0, 2)[::-1, ::-1]
+    if o == 8: return img.transpose(1, 0, 2)[::-1]
+    return img
+
+
+def jpeg_info(buf):
+    """(height, width, components, sampling of component 0 as (h << 4) | v, EXIF orientation or 0, decodable here)."""
+    b = np.frombuffer(buf, np.uint8)
+    v = [_lib.C.c_int32(0) for _ in range(5)]
+    rc = _lib.load().vo_jpeg_info(b.ctypes.data, len(b), *[_lib.C.addressof(x) for x in v])
+    if rc == _lib.VO_ERR_INVALID:
+        raise ValueError("not a JPEG file")
+    return tuple(x.value for x in v) + (rc == 0,)
+
+
+def imdecode(buf, ctx=None, apply_orientation=True):
+    """cv2.imdecode(buf, cv2.IMREAD_COLOR) for a JPEG held in memory -> [h, w, 3] uint8, B G R."""
+    b = np.frombuffer(buf, np.uint8)
+    h, w, _, _, orient, ok = jpeg_info(b)
+    if not ok:
+        raise NotImplementedError("JPEG frame type outside the baseline decoder (progressive, lossless, arithmetic or 12-bit)")
+    out = np.empty((h, w, 3), np.uint8)
+    ctx = ctx or _lib.default_context()
+    hh = _lib.C.c_int32(0); ww = _lib.C.c_int32(0)
+    rc = ctx.lib.vo_jpeg_decode(ctx.handle, b.ctypes.data, len(b), out.ctypes.data, h, w, _lib.C.addressof(hh), _lib.C.addressof(ww))
+    if rc == _lib.VO_ERR_UNSUPPORTED:
+        raise NotImplementedError(ctx.last_error())
+    ctx.check(rc)
+    return np.ascontiguousarray(_apply_orientation(out, orient)) if apply_orientation and orient > 1 else out
+
+
+def imread(filename, ctx=None):
+    """cv2.imread(filename) for a .jpg (src/visual_slam.py:346).  Like cv2, returns None when the file cannot be read."""
+    try:
+        with open(filename, "rb") as f:
+            data = f.read()
+    except OSError:
+        return None
+    return imdecode(data, ctx)
+
+
+def decode_batch(buffers, ctx=None):
+    """Many JPEG files of ONE size -> [F, h, w, 3] uint8 (B G R) with one upload and one launch sequence."""
+    bufs = [bytes(b) for b in buffers]
+    if not bufs:
+        return np.empty((0, 0, 0, 3), np.uint8)
+    h, w = jpeg_info(bufs[0])[:2]
+    blob = np.frombuffer(b"".join(bufs), np.uint8)
+    offs = np.zeros(len(bufs) + 1, np.int64); offs[1:] = np.cumsum([len(b) for b in bufs])
+    out = np.empty((len(bufs), h, w, 3), np.uint8)
+    ctx = ctx or _lib.default_context()
+    rc = ctx.lib.vo_jpeg_decode_batch(ctx.handle, blob.ctypes.data, offs.ctypes.data, len(bufs), out.ctypes.data, h, w)
+    if rc == _lib.VO_ERR_UNSUPPORTED:
+        raise NotImplementedError(ctx.last_error())
+    ctx.check(rc)
     return out
