@@ -105,8 +105,18 @@ static bool build_tables(const uint8_t* counts /*16*/, const uint8_t* vals, int 
 }
 
 // Fills img (geometry, table selectors, where the entropy-coded bytes start) and T; the caller assigns buffer offsets.
-int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why)
+// Frames of one camera / encoder carry identical DQT and DHT segments: when `prev` (the header bytes and tables of the
+// file parsed before) starts with the same bytes up to the scan header, its tables are copied instead of rebuilt.
+int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why, const uint8_t* prev_hdr, size_t prev_hdr_len,
+               const JpegImage* prev_img, const JpegTables* prev_T)
 {
+    if (prev_hdr && prev_hdr_len > 4 && prev_hdr_len <= n && !memcmp(d, prev_hdr, prev_hdr_len)) {
+        static const char* dummy2; if (!why) why = &dummy2;
+        *img = *prev_img; memcpy(T, prev_T, sizeof(*T));
+        if (n - prev_hdr_len > 0x7fffffffull) { *why = "image too large"; return VO_ERR_UNSUPPORTED; }
+        img->raw_len = (uint32_t)(n - prev_hdr_len);
+        return VO_OK;
+    }
     static const char* dummy; if (!why) why = &dummy;
     memset(img, 0, sizeof(*img)); memset(T, 0, sizeof(*T));
     bool qseen[4] = {false, false, false, false}, hseen[8] = {false, false, false, false, false, false, false, false};
@@ -231,51 +241,67 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* s_tmp, int tid, int* tot
 // ------------------------------------------------------------------ k_jpeg_unstuff
 // Byte i of the entropy-coded segment is dropped when it is the 00 of an FF 00 pair, a fill FF, or part of an RSTn
 // marker; any other FF xx ends the data.  An RSTn leaves its position in the clean stream in the restart list.
+// Every thread owns a contiguous run of bytes and reads it four at a time.
+struct UnstuffScan {
+    const uint8_t* raw; uint32_t n, lo, hi;
+    // calls f(i, c, keep, is_rst) for the bytes of [lo, min(hi, stop)); returns the index of the first terminating
+    // marker it met (then it stops there) or n
+    template <typename F>
+    __device__ __forceinline__ uint32_t run(uint32_t stop, F f) const
+    {
+        int pv = lo > 0 ? raw[lo - 1] : 0;
+        for (uint32_t i = lo; i < hi && i < stop; i += 4) {
+            const uint32_t w = *(const u32_unaligned*)(raw + i);
+            const int after = i + 4 < n ? raw[i + 4] : 0xD9;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t at = i + j;
+                if (at >= hi || at >= stop) return n;
+                const int c = (int)((w >> (8 * j)) & 255u);
+                int nx = j < 3 ? (int)((w >> (8 * j + 8)) & 255u) : after;
+                if (at + 1 >= n) nx = 0xD9;
+                const bool rstn = nx >= 0xD0 && nx <= 0xD7;
+                if (c == 0xFF && nx != 0 && nx != 0xFF && !rstn) return at;                    // EOI or any other marker
+                const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
+                f(at, c, !drop, c == 0xFF && rstn);
+                pv = c;
+            }
+        }
+        return n;
+    }
+};
+
 __global__ __launch_bounds__(JPG_NT) void k_jpeg_unstuff(const uint8_t* blob, JpegImage* imgs, uint8_t* clean, uint32_t* rst)
 {
     __shared__ int s_tmp[JPG_NT / 64];
     __shared__ unsigned int s_end;
     JpegImage& im = imgs[blockIdx.x];
     const int tid = threadIdx.x;
-    const uint8_t* raw = blob + im.raw_off;
-    const uint32_t n = im.raw_len;
-    const uint32_t per = (n + JPG_NT - 1) / JPG_NT;
-    const uint32_t lo = min(n, per * (uint32_t)tid), hi = min(n, lo + per);
-    if (tid == 0) s_end = n;
+    UnstuffScan sc;
+    sc.raw = blob + im.raw_off; sc.n = im.raw_len;
+    const uint32_t per = (((sc.n + JPG_NT - 1) / JPG_NT) + 3u) & ~3u;
+    sc.lo = min(sc.n, per * (uint32_t)tid); sc.hi = min(sc.n, sc.lo + per);
+    if (tid == 0) s_end = sc.n;
     __syncthreads();
-    // the first terminating marker
-    uint32_t my_end = n;
-    for (uint32_t i = lo; i < hi; i++) {
-        if (raw[i] != 0xFF) continue;
-        const int nx = i + 1 < n ? raw[i + 1] : 0xD9;
-        if (nx != 0 && nx != 0xFF && !(nx >= 0xD0 && nx <= 0xD7)) { my_end = i; break; }
-    }
-    if (my_end < n) atomicMin(&s_end, my_end);
+    int keep = 0, nr = 0;
+    const uint32_t my_end = sc.run(sc.n, [&](uint32_t, int, bool k, bool r) { keep += k; nr += r; });
+    if (my_end < sc.n) atomicMin(&s_end, my_end);
     __syncthreads();
     const uint32_t end = s_end;
-    int keep = 0, nr = 0;
-    for (uint32_t i = lo; i < hi && i < end; i++) {
-        const int c = raw[i], pv = i > 0 ? raw[i - 1] : 0, nx = i + 1 < n ? raw[i + 1] : 0xD9;
-        const bool rstm = c == 0xFF && nx >= 0xD0 && nx <= 0xD7;
-        const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
-        keep += !drop; nr += rstm;
-    }
+    if (sc.lo >= end) { keep = 0; nr = 0; }                 // (a thread that starts before `end` stopped at `end` by itself)
     int tot_keep, tot_r;
     int kpos = wg_scan_excl(keep, s_tmp, tid, &tot_keep);
-    __syncthreads();
     int rpos = wg_scan_excl(nr, s_tmp, tid, &tot_r);
     uint8_t* out = clean + im.clean_off;
     uint32_t* rl = rst + im.rst_off;
-    for (uint32_t i = lo; i < hi && i < end; i++) {
-        const int c = raw[i], pv = i > 0 ? raw[i - 1] : 0, nx = i + 1 < n ? raw[i + 1] : 0xD9;
-        const bool rstm = c == 0xFF && nx >= 0xD0 && nx <= 0xD7;
-        const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
-        if (rstm) { if ((uint32_t)rpos < im.rst_cap) rl[rpos] = (uint32_t)kpos; rpos++; }
-        if (!drop) out[kpos++] = (uint8_t)c;
-    }
+    const uint32_t cap = im.rst_cap;
+    sc.run(end, [&](uint32_t, int c, bool k, bool r) {
+        if (r) { if ((uint32_t)rpos < cap) rl[rpos] = (uint32_t)kpos; rpos++; }
+        if (k) out[kpos++] = (uint8_t)c;
+    });
     // zero padding after the data: a decoder that runs past the end reads zero bits (as libjpeg supplies them)
     for (uint32_t i = (uint32_t)tot_keep + tid; i < (uint32_t)tot_keep + JPG_PAD; i += JPG_NT) out[i] = 0;
-    if (tid == 0) { im.clean_len = (uint32_t)tot_keep; im.nrst = min((uint32_t)tot_r, im.rst_cap); }
+    if (tid == 0) { im.clean_len = (uint32_t)tot_keep; im.nrst = min((uint32_t)tot_r, cap); }
 }
 
 // ------------------------------------------------------------------ k_jpeg_huffman
@@ -284,9 +310,15 @@ struct JState { uint32_t bit; uint32_t bk; };              // position in the cl
 struct JReader {
     const uint8_t* p; uint32_t limit;                     // stream, number of readable bytes (data + padding)
     uint64_t buf; int nb; uint32_t bytepos;
+    uint32_t ahead;                                       // the word at bytepos, loaded one refill early (its latency hides behind ~5 symbols)
+    __device__ __forceinline__ uint32_t word(uint32_t at) const
+    {
+        return at + 4 <= limit ? __builtin_bswap32(*(const u32_unaligned*)(p + at)) : 0u;
+    }
     __device__ __forceinline__ void seek(uint32_t bit)
     {
         bytepos = bit >> 3; buf = 0; nb = 0;
+        ahead = word(bytepos);
         refill();
         const int skip = (int)(bit & 7u);
         buf <<= skip; nb -= skip;
@@ -294,24 +326,27 @@ struct JReader {
     __device__ __forceinline__ void refill()
     {
         if (nb <= 32) {
-            uint32_t w = 0;
-            if (bytepos + 4 <= limit) w = __builtin_bswap32(*(const u32_unaligned*)(p + bytepos));
-            buf |= (uint64_t)w << (32 - nb);
+            buf |= (uint64_t)ahead << (32 - nb);
             nb += 32; bytepos += 4;
+            ahead = word(bytepos);
         }
     }
     __device__ __forceinline__ uint32_t pos() const { return bytepos * 8u - (uint32_t)nb; }
     __device__ __forceinline__ void skip(int n) { buf <<= n; nb -= n; }
 };
 
-struct JTabs {                                            // LDS copies of the image's tables
+struct JLocal {                                           // LDS copies of what the decoding loop reads per symbol
     uint16_t lut[8][1 << JPG_LOOK];
     int32_t maxcode[8][18];
     int32_t valoff[8][18];
     uint8_t vals[8][256];
+    uint8_t zigzag[64];
+    uint8_t dc_slot[JPG_MAX_BPM], ac_slot[JPG_MAX_BPM];
+    int32_t bpm, ri, nrst, total_blocks;
+    uint32_t clean_len;
 };
 
-__device__ __forceinline__ int jpg_symbol(JReader& r, const JTabs& T, int slot)
+__device__ __forceinline__ int jpg_symbol(JReader& r, const JLocal& T, int slot)
 {
     const uint32_t top = (uint32_t)(r.buf >> 48);                         // next 16 bits
     const uint32_t e = T.lut[slot][top >> (16 - JPG_LOOK)];
@@ -324,68 +359,62 @@ __device__ __forceinline__ int jpg_symbol(JReader& r, const JTabs& T, int slot)
     return sym;
 }
 
-__device__ __forceinline__ int jpg_value(JReader& r, int s)
+__device__ __forceinline__ int jpg_value(JReader& r, int s)               // s value bits, sign-extended the JPEG way; s = 0 -> 0
 {
-    if (s == 0) return 0;
-    const int v = (int)(r.buf >> (64 - s));
+    const int v = (int)((uint32_t)(r.buf >> 33) >> (31 - s));
     r.skip(s);
-    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    return v < ((1 << s) >> 1) ? v - (1 << s) + 1 : v;
 }
 
 // Decodes symbols from state st until the bit position reaches `boundary` (or max_done blocks are complete).  Returns
 // the number of blocks completed; WRITE stores the coefficients of block blk, blk + 1, ... (DC as the raw difference).
+// DC and AC symbols take the same path (table, run and store position selected arithmetically): the 64 lanes of a
+// wavefront are at different places of their blocks.
 template <bool WRITE>
-__device__ __forceinline__ int jpg_span(const JpegImage& im, const JTabs& T, const uint8_t* clean, const uint32_t* rst,
+__device__ __forceinline__ int jpg_span(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
                                         JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done = 0x7fffffff)
 {
-    JReader r; r.p = clean; r.limit = im.clean_len + JPG_PAD;
+    JReader r; r.p = clean; r.limit = T.clean_len + JPG_PAD;
     if (st.bit >= boundary) return 0;
     r.seek(st.bit);
     int b = (int)(st.bk >> 8), k = (int)(st.bk & 255u), done = 0;
     // the first restart position after the start (positions are clean-stream byte offsets)
     uint32_t ri_next = 0xffffffffu; int rj = 0;
-    const int nrst = (int)im.nrst;
-    if (im.ri && nrst) {
+    const int nrst = T.nrst, bpm = T.bpm;
+    if (T.ri && nrst) {
         int lo = 0, hi = nrst;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (rst[mid] * 8u > st.bit) hi = mid; else lo = mid + 1; }
         rj = lo; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
     }
-    const uint32_t total = (uint32_t)im.total_blocks;
+    const uint32_t total = (uint32_t)T.total_blocks;
     uint32_t pos = st.bit;
+    int slot_dc = T.dc_slot[b], slot_ac = T.ac_slot[b];     // table slots of the current block's component
     while (pos < boundary && done < max_done) {
         r.refill();
-        const int c = im.blk_comp[b];
-        if (k == 0) {
-            if (b == 0 && ri_next != 0xffffffffu && pos + 8 > ri_next) {
-                // an MCU boundary inside the last byte before a restart: the rest of the byte is padding (all ones —
-                // no Huffman code is all ones, so a real MCU cannot start like that)
-                const int rem = (int)(ri_next - pos);
-                if (rem == 0 || (r.buf >> (64 - rem)) == ((1ull << rem) - 1ull)) {
-                    r.seek(ri_next); pos = ri_next;
-                    rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
-                    continue;
-                }
+        const bool dc = k == 0;
+        if (dc && b == 0 && pos + 8 > ri_next) {
+            // an MCU boundary inside the last byte before a restart: the rest of the byte is padding (all ones —
+            // no Huffman code is all ones, so a real MCU cannot start like that)
+            const int rem = (int)(ri_next - pos);
+            if (rem == 0 || (r.buf >> (64 - rem)) == ((1ull << rem) - 1ull)) {
+                r.seek(ri_next); pos = ri_next;
+                rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
+                continue;
             }
-            const int s = jpg_symbol(r, T, im.td[c]) & 15;
-            r.refill();
-            const int diff = jpg_value(r, s);
-            if (WRITE && blk + done < total) coef[(size_t)(blk + done) * 64] = (int16_t)diff;
-            k = 1;
-        } else {
-            const int rs = jpg_symbol(r, T, 4 + im.ta[c]);
-            const int run = rs >> 4, s = rs & 15;
-            if (s == 0) k = run == 15 ? k + 16 : 64;
-            else {
-                k += run;
-                const int v = jpg_value(r, s);
-                if (WRITE && k < 64 && blk + done < total) coef[(size_t)(blk + done) * 64 + d_zigzag[k]] = (int16_t)v;
-                k++;
-            }
-            if (k >= 64) { k = 0; b = b + 1 == im.bpm ? 0 : b + 1; done++; }
         }
+        const int sym = jpg_symbol(r, T, dc ? slot_dc : slot_ac);
+        const int s = sym & 15, run = dc ? 0 : sym >> 4;
+        const int v = jpg_value(r, s);
+        if (!dc && s == 0) k = run == 15 ? k + 16 : 64;     // ZRL / end of block
+        else {
+            k += run;
+            if (WRITE && k < 64 && blk + done < total) coef[(size_t)(blk + done) * 64 + T.zigzag[k]] = (int16_t)v;
+            k++;
+        }
+        if (k >= 64) { k = 0; b = b + 1 == bpm ? 0 : b + 1; done++; slot_dc = T.dc_slot[b]; slot_ac = T.ac_slot[b]; }
         pos = r.pos();
         if (pos > ri_next) {                              // ran across a restart boundary: only a mis-synchronised thread does
-            r.seek(ri_next); pos = ri_next; b = 0; k = 0;
+            r.seek(ri_next); pos = ri_next; b = 0; k = 0; slot_dc = T.dc_slot[0]; slot_ac = T.ac_slot[0];
             rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
         }
     }
@@ -393,10 +422,10 @@ __device__ __forceinline__ int jpg_span(const JpegImage& im, const JTabs& T, con
     return done;
 }
 
-__global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, const JpegTables* tabs, const uint8_t* clean_all,
+__global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const JpegTables* tabs, const uint8_t* clean_all,
                                                          const uint32_t* rst_all, int16_t* coef_all)
 {
-    __shared__ JTabs T;
+    __shared__ JLocal T;
     __shared__ JState s_st[JPG_NT];
     __shared__ int s_cnt[JPG_NT];
     __shared__ int s_tmp[JPG_NT / 64];
@@ -408,6 +437,13 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, 
     for (int i = tid; i < 8 * (1 << JPG_LOOK); i += JPG_NT) (&T.lut[0][0])[i] = (&G.lut[0][0])[i];
     for (int i = tid; i < 8 * 18; i += JPG_NT) { (&T.maxcode[0][0])[i] = (&G.maxcode[0][0])[i]; (&T.valoff[0][0])[i] = (&G.valoff[0][0])[i]; }
     for (int i = tid; i < 8 * 256; i += JPG_NT) (&T.vals[0][0])[i] = (&G.vals[0][0])[i];
+    if (tid < 64) T.zigzag[tid] = d_zigzag[tid];
+    if (tid < JPG_MAX_BPM) { const int c = im.blk_comp[tid]; T.dc_slot[tid] = (uint8_t)im.td[c]; T.ac_slot[tid] = (uint8_t)(4 + im.ta[c]); }
+    if (tid == 0) { T.bpm = im.bpm; T.ri = im.ri; T.nrst = (int)im.nrst; T.total_blocks = im.total_blocks; T.clean_len = im.clean_len; }
+    const int bpm = im.bpm, ri = im.ri, total_blocks = im.total_blocks, mcus_all = im.mx * im.my;
+    uint8_t comp_of[JPG_MAX_BPM];
+#pragma unroll
+    for (int j = 0; j < JPG_MAX_BPM; j++) comp_of[j] = im.blk_comp[j];
     const uint8_t* clean = clean_all + im.clean_off;
     const uint32_t* rst = rst_all + im.rst_off;
     int16_t* coef = coef_all + (size_t)im.coef_blk * 64;
@@ -420,7 +456,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, 
     // 1. cold start: assume a block starts at the subsequence boundary (true for thread 0)
     JState mine; mine.bit = b0; mine.bk = 0;
     int cnt = 0;
-    if (live) cnt = jpg_span<false>(im, T, clean, rst, mine, b1, nullptr, 0);
+    if (live) cnt = jpg_span<false>(T, clean, rst, mine, b1, nullptr, 0);
     s_st[tid] = mine; s_cnt[tid] = cnt;
     __syncthreads();
     // 2. propagate end states until they are stable: thread i restarts from thread i-1's end state
@@ -434,11 +470,11 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, 
         bool changed = false;
         if (redo) {
             JState st = prev;
-            const int c = jpg_span<false>(im, T, clean, rst, st, b1, nullptr, 0);
+            const int c = jpg_span<false>(T, clean, rst, st, b1, nullptr, 0);
             changed = st.bit != s_st[tid].bit || st.bk != s_st[tid].bk;
             s_st[tid] = st; s_cnt[tid] = c; used = prev;
         }
-        if (!__syncthreads_or(changed ? 1 : 0)) break;
+        if (!__syncthreads_or(changed ? 1 : 0)) { if (tid == 0) imgs[blockIdx.x].sync_rounds = (uint32_t)round + 1; break; }
     }
     __syncthreads();
     // 3. first coefficient block of every subsequence; 4. decode once more, writing
@@ -447,20 +483,20 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, 
     if (live) {
         JState st; st.bit = 0; st.bk = 0;
         if (tid > 0) st = s_st[tid - 1];
-        jpg_span<true>(im, T, clean, rst, st, b1, coef, (uint32_t)first);
+        jpg_span<true>(T, clean, rst, st, b1, coef, (uint32_t)first);
     }
     // 4b. a file whose data ends early (truncated, or cut by a stray marker): libjpeg decodes the MCU in which the data
     //     ran out from zero bits and leaves every later MCU all-zero (jdhuff.c: insufficient_data) — the last
     //     subsequence's owner finishes that MCU from the zero padding, the MCUs after it keep their cleared coefficients
-    if (tid == 0) s_valid_mcus = im.mx * im.my;
+    if (tid == 0) s_valid_mcus = mcus_all;
     __syncthreads();
-    if (total_cnt < im.total_blocks) {
+    if (total_cnt < total_blocks) {
         const int last = (int)min((uint32_t)(JPG_NT - 1), (nbits ? (nbits - 1) / (sub * 8u) : 0u));
         if (tid == last) {
             JState st = s_st[last];
             if (nbits == 0) { st.bit = 0; st.bk = 0; }
-            const int mcu = total_cnt / im.bpm;
-            jpg_span<true>(im, T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, (mcu + 1) * im.bpm - total_cnt);
+            const int mcu = total_cnt / bpm;
+            jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, (mcu + 1) * bpm - total_cnt);
             s_valid_mcus = mcu + 1;
         }
     }
@@ -471,8 +507,13 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, 
     const int m0 = min(mcus, per * tid), m1 = min(mcus, m0 + per);
     int sum[3] = {0, 0, 0}, reset = 0;
     for (int m = m0; m < m1; m++) {
-        if (im.ri && m % im.ri == 0) { sum[0] = sum[1] = sum[2] = 0; reset = 1; }
-        for (int j = 0; j < im.bpm; j++) sum[im.blk_comp[j]] += coef[((size_t)m * im.bpm + j) * 64];
+        if (ri && m % ri == 0) { sum[0] = sum[1] = sum[2] = 0; reset = 1; }
+#pragma unroll
+        for (int j = 0; j < JPG_MAX_BPM; j++)
+            if (j < bpm) {
+                const int d = coef[((size_t)m * bpm + j) * 64], c = comp_of[j];
+                sum[0] += c == 0 ? d : 0; sum[1] += c == 1 ? d : 0; sum[2] += c == 2 ? d : 0;
+            }
     }
     s_dc[tid][0] = sum[0]; s_dc[tid][1] = sum[1]; s_dc[tid][2] = sum[2]; s_dc[tid][3] = reset;
     __syncthreads();
@@ -484,15 +525,18 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(const JpegImage* imgs, 
         if (has && !s_dc[tid][3]) { s_dc[tid][0] += a0; s_dc[tid][1] += a1; s_dc[tid][2] += a2; s_dc[tid][3] = ar; }
         __syncthreads();
     }
-    int pred[3] = {0, 0, 0};
-    if (tid > 0) { pred[0] = s_dc[tid - 1][0]; pred[1] = s_dc[tid - 1][1]; pred[2] = s_dc[tid - 1][2]; }
+    int p0 = 0, p1 = 0, p2 = 0;
+    if (tid > 0) { p0 = s_dc[tid - 1][0]; p1 = s_dc[tid - 1][1]; p2 = s_dc[tid - 1][2]; }
     for (int m = m0; m < m1; m++) {
-        if (im.ri && m % im.ri == 0) pred[0] = pred[1] = pred[2] = 0;
-        for (int j = 0; j < im.bpm; j++) {
-            int16_t* p = coef + ((size_t)m * im.bpm + j) * 64;
-            const int c = im.blk_comp[j];
-            pred[c] += *p; *p = (int16_t)pred[c];
-        }
+        if (ri && m % ri == 0) p0 = p1 = p2 = 0;
+#pragma unroll
+        for (int j = 0; j < JPG_MAX_BPM; j++)
+            if (j < bpm) {
+                int16_t* p = coef + ((size_t)m * bpm + j) * 64;
+                const int c = comp_of[j], d = *p;
+                p0 += c == 0 ? d : 0; p1 += c == 1 ? d : 0; p2 += c == 2 ? d : 0;
+                *p = (int16_t)(c == 0 ? p0 : c == 1 ? p1 : p2);
+            }
     }
 }
 
@@ -576,57 +620,82 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImage* imgs, const 
 }
 
 // ------------------------------------------------------------------ k_jpeg_color  (jdsample.c + jdcolor.c)
-__device__ __forceinline__ int up_h2v1(const uint8_t* in, int dw, int x)
+// Lane per 4 output pixels.  The chroma samples the four pixels need (columns i-1 .. i+2 of up to two rows, i = x / 2)
+// come from one unaligned dword per row and plane.
+__device__ __forceinline__ uint32_t ld4(const uint8_t* row, int i0, int dw)
 {
-    const int i = x >> 1;
-    if (dw <= 2 || x == 0 || x == 2 * dw - 1) return in[i];
-    return (x & 1) ? (in[i] * 3 + in[i + 1] + 2) >> 2 : (in[i] * 3 + in[i - 1] + 1) >> 2;
-}
-
-__device__ __forceinline__ int up_h2v2(const uint8_t* in0, const uint8_t* in1, int dw, int x)
-{
-    const int i = x >> 1;
-    if (dw <= 2) return in0[i];
-    const int cur = in0[i] * 3 + in1[i];
-    if (x == 0) return (cur * 4 + 8) >> 4;
-    if (x == 2 * dw - 1) return (cur * 4 + 7) >> 4;
-    return (x & 1) ? (cur * 3 + in0[i + 1] * 3 + in1[i + 1] + 7) >> 4 : (cur * 3 + in0[i - 1] * 3 + in1[i - 1] + 8) >> 4;
+    // bytes row[i0 .. i0+3] with indices clamped into [0, dw): the clamped ones are never used by the filters
+    const int a = max(i0, 0), sh = (a - i0) * 8;
+    uint32_t w = *(const u32_unaligned*)(row + a);           // rows are padded to whole blocks: a + 3 stays inside the plane
+    (void)dw;
+    return w << sh;
 }
 
 __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const uint8_t* planes, uint8_t* out_all)
 {
     const JpegImage& im = imgs[blockIdx.z];
     const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
-    if (y >= im.H || x4 >= im.W) return;
+    const int W = im.W, H = im.H;
+    if (y >= H || x4 >= W) return;
+    const int mode = im.mode, nc = im.nc, ycc = im.ycc;
     const uint8_t* yrow = planes + im.plane_off[0] + (size_t)y * (im.bw[0] * 8);
     uint8_t* o = out_all + im.out_off + (size_t)y * im.out_stride + (size_t)x4 * 3;
-    uint8_t px[12];
-    const int nx = min(4, im.W - x4);
-    if (im.nc == 1) {
-        for (int k = 0; k < nx; k++) px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = yrow[x4 + k];
-    } else {
+    const uint32_t yw = *(const uint32_t*)(yrow + x4);       // plane rows are multiples of 8 bytes, planes 256-byte aligned
+    int Cb[4], Cr[4];
+    if (nc == 3) {
         const int st = im.bw[1] * 8, dw = im.dw[1], dh = im.dh[1];
         const uint8_t* cbp = planes + im.plane_off[1]; const uint8_t* crp = planes + im.plane_off[2];
-        for (int k = 0; k < nx; k++) {
-            const int x = x4 + k;
-            int Cb, Cr;
-            if (im.mode == 0) { Cb = cbp[(size_t)y * st + x]; Cr = crp[(size_t)y * st + x]; }
-            else if (im.mode == 1) { Cb = up_h2v1(cbp + (size_t)y * st, dw, x); Cr = up_h2v1(crp + (size_t)y * st, dw, x); }
-            else {
-                const int r = y >> 1;
-                const int r1 = min(max((y & 1) ? r + 1 : r - 1, 0), dh - 1);        // the context row: above (even rows) / below (odd rows)
-                Cb = up_h2v2(cbp + (size_t)r * st, cbp + (size_t)r1 * st, dw, x);
-                Cr = up_h2v2(crp + (size_t)r * st, crp + (size_t)r1 * st, dw, x);
+        if (mode == 0) {
+            const uint32_t b = *(const uint32_t*)(cbp + (size_t)y * st + x4), r = *(const uint32_t*)(crp + (size_t)y * st + x4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { Cb[k] = (b >> (8 * k)) & 255; Cr[k] = (r >> (8 * k)) & 255; }
+        } else {
+            const int i = x4 >> 1;                             // pixels x4 .. x4+3 use chroma columns i-1 .. i+2
+            const int r0 = mode == 2 ? y >> 1 : y;
+            const int r1 = mode == 2 ? min(max((y & 1) ? r0 + 1 : r0 - 1, 0), dh - 1) : r0;   // h2v2 context row: above (even rows) / below (odd rows)
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++) {
+                const uint8_t* base = pl ? crp : cbp;
+                const uint32_t w0 = ld4(base + (size_t)r0 * st, i - 1, dw);
+                const uint32_t w1 = mode == 2 ? ld4(base + (size_t)r1 * st, i - 1, dw) : 0u;
+                int cs[4];                                     // column sums of columns i-1 .. i+2 (h2v1: the samples themselves)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int a = (w0 >> (8 * k)) & 255, bb = (w1 >> (8 * k)) & 255;
+                    cs[k] = mode == 2 ? 3 * a + bb : a;
+                }
+                int* dst = pl ? Cr : Cb;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int x = x4 + k, ci = 1 + (k >> 1);   // index of column x / 2 in cs
+                    int v;
+                    if (mode == 1) {
+                        if (dw <= 2 || x == 0 || x == 2 * dw - 1) v = cs[ci];
+                        else v = (x & 1) ? (cs[ci] * 3 + cs[ci + 1] + 2) >> 2 : (cs[ci] * 3 + cs[ci - 1] + 1) >> 2;
+                    } else {
+                        if (dw <= 2) v = (int)((w0 >> (8 * ci)) & 255);
+                        else if (x == 0) v = (cs[ci] * 4 + 8) >> 4;
+                        else if (x == 2 * dw - 1) v = (cs[ci] * 4 + 7) >> 4;
+                        else v = (x & 1) ? (cs[ci] * 3 + cs[ci + 1] + 7) >> 4 : (cs[ci] * 3 + cs[ci - 1] + 8) >> 4;
+                    }
+                    dst[k] = v;
+                }
             }
-            const int Y = yrow[x];
-            if (!im.ycc) { px[3 * k] = (uint8_t)Cr; px[3 * k + 1] = (uint8_t)Cb; px[3 * k + 2] = (uint8_t)Y; continue; }
-            const int xb = Cb - 128, xr = Cr - 128;
-            const int R = Y + ((91881 * xr + 32768) >> 16);
-            const int G = Y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
-            const int B = Y + ((116130 * xb + 32768) >> 16);
-            px[3 * k] = (uint8_t)min(max(B, 0), 255); px[3 * k + 1] = (uint8_t)min(max(G, 0), 255); px[3 * k + 2] = (uint8_t)min(max(R, 0), 255);
         }
     }
+    uint8_t px[12];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int Y = (yw >> (8 * k)) & 255;
+        if (nc == 1) { px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (uint8_t)Y; continue; }
+        if (!ycc) { px[3 * k] = (uint8_t)Cr[k]; px[3 * k + 1] = (uint8_t)Cb[k]; px[3 * k + 2] = (uint8_t)Y; continue; }   // stored R, G, B
+        const int xb = Cb[k] - 128, xr = Cr[k] - 128;          // jdcolor.c build_ycc_rgb_table
+        const int R = Y + ((91881 * xr + 32768) >> 16);
+        const int G = Y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
+        const int B = Y + ((116130 * xb + 32768) >> 16);
+        px[3 * k] = (uint8_t)min(max(B, 0), 255); px[3 * k + 1] = (uint8_t)min(max(G, 0), 255); px[3 * k + 2] = (uint8_t)min(max(R, 0), 255);
+    }
+    const int nx = min(4, W - x4);
     if (nx == 4 && (((size_t)(o - out_all)) & 3) == 0) {
         uint32_t* o32 = (uint32_t*)o;
         o32[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);

@@ -1677,7 +1677,9 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     for (int k = 0; k < n; k++) {
         const char* why = "";
         const size_t o = (size_t)offsets[f0 + k], len = (size_t)(offsets[f0 + k + 1] - offsets[f0 + k]);
-        const int rc = jpeg_parse(blob + o, len, &imgs[k], &tabs[k], &why);
+        const int rc = k == 0 ? jpeg_parse(blob + o, len, &imgs[k], &tabs[k], &why)
+                              : jpeg_parse(blob + o, len, &imgs[k], &tabs[k], &why, blob + (size_t)offsets[f0 + k - 1], imgs[k - 1].hdr_len,
+                                           &imgs[k - 1], &tabs[k - 1]);
         if (rc) FAIL(rc, "JPEG %d: %s", f0 + k, why);
         JpegImage& im = imgs[k];
         if (im.H != out_h || im.W != out_w) FAIL(VO_ERR_INVALID, "JPEG %d is %d x %d, the batch expects %d x %d", f0 + k, im.W, im.H, out_w, out_h);
@@ -1712,6 +1714,12 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));                  // the host vectors must outlive their copies
+    if (getenv("VO_DEBUG")) {
+        HIPCHK(hipMemcpy(imgs.data(), ctx->jpg_img, (size_t)n * sizeof(JpegImage), hipMemcpyDeviceToHost));
+        uint32_t mx = 0; double sum = 0;
+        for (int k = 0; k < n; k++) { mx = imgs[k].sync_rounds > mx ? imgs[k].sync_rounds : mx; sum += imgs[k].sync_rounds; }
+        fprintf(stderr, "jpeg: %d files, synchronisation rounds mean %.2f max %u (clean bytes of file 0: %u)\n", n, sum / n, mx, imgs[0].clean_len);
+    }
     return VO_OK;
 }
 

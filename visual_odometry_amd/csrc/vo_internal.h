@@ -175,13 +175,14 @@ void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride,
                         int isx, int isy, const int* xsi, const float* xal, const int* xst, const int* ysi, const float* yal, const int* yst);
 // ---- JPEG decode (jpeg_kernels.hip): cv2.imread in front of the path
 #define JPG_NT 512               // threads of the two entropy kernels = subsequences per image
-#define JPG_LOOK 9               // bits of Huffman look-ahead table
+#define JPG_LOOK 10              // bits of Huffman look-ahead table
 #define JPG_PAD 16               // zero bytes after every clean stream
 #define JPG_MAX_BPM 10           // blocks per MCU (T.81 limit)
 struct JpegImage {               // one file of a batch: geometry from the headers + where its data lives in the batch buffers
     uint32_t raw_off, raw_len, hdr_len;          // entropy-coded bytes in the blob (from the end of the SOS header to the end of the file)
     uint32_t clean_off, clean_len;               // the same without stuffing / restart markers (written by k_jpeg_unstuff)
     uint32_t rst_off, rst_cap, nrst;             // restart positions (clean-stream byte offsets)
+    uint32_t sync_rounds;                        // diagnostic: propagation rounds k_jpeg_huffman needed
     uint32_t coef_blk;                           // first 8x8 block in the coefficient buffer
     uint32_t out_stride;
     uint64_t plane_off[3], out_off;
@@ -196,7 +197,8 @@ struct JpegTables {
     uint8_t vals[8][256];
 };
 int jpeg_info(const uint8_t* d, size_t n, int* h, int* w, int* ncomp, int* sampling, int* orientation);
-int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why);
+int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why, const uint8_t* prev_hdr = nullptr,
+               size_t prev_hdr_len = 0, const JpegImage* prev_img = nullptr, const JpegTables* prev_T = nullptr);
 void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
                         int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h);
 
