@@ -74,7 +74,10 @@ static int decode_sym(bits_t* b, const huff_t* h)
         code = (code << 1) | next_bit(b);
         if (h->maxcode[l] >= 0 && code <= h->maxcode[l] && code >= h->mincode[l]) return h->vals[h->valptr[l] + code - h->mincode[l]];
     }
-    return -1;
+    /* garbage (damaged or zero-filled data): jdhuff.c jpeg_huff_decode runs on to its sentinel length 17 — one more bit is
+     * consumed — and "fakes a zero as the safest result" */
+    (void)next_bit(b);
+    return 0;
 }
 
 static int build_huff(huff_t* h)

@@ -122,3 +122,41 @@ def test_ingest_jpeg_equals_decode_resize_gray(oracle, ctx):
         o = oracle.orb_detect_and_compute(resized[k], p)
         f = fe.features(k)
         assert np.array_equal(f["desc"], o["desc"]) and np.array_equal(f["xy"], o["xy"]), k
+
+
+def test_corrupt_entropy_data_is_survived(oracle, ctx):
+    """Random damage inside the entropy-coded segment (flipped bytes, spliced markers, random tails): whatever comes out,
+    every access of the kernels stays inside its buffers and the call returns an image of the right shape; damage that
+    only ENDS the data early (a marker spliced into the stream) has defined behaviour and must equal the oracle."""
+    from visual_odometry_amd import ingest
+    rng = np.random.default_rng(17)
+    files = [encode(scene(300 + k, 90, 150, "boxes"), quality=40 + 20 * k, subsampling=k % 3,
+                    **({"restart_marker_blocks": 3} if k == 1 else {})) for k in range(3)]
+    for it in range(60):
+        fb = bytearray(files[it % 3])
+        sos = bytes(fb).index(b"\xff\xda")
+        start = sos + 2 + ((fb[sos + 2] << 8) | fb[sos + 3])
+        kind = it % 3
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                fb[int(rng.integers(start, len(fb) - 2))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            i0 = int(rng.integers(start, len(fb) - 2)); fb[i0:] = bytes(rng.integers(0, 256, len(fb) - i0, dtype=np.uint8))
+        else:
+            i0 = int(rng.integers(start, len(fb) - 4)); fb[i0:i0 + 2] = b"\xff\xd9"
+        got = ingest.imdecode(bytes(fb), ctx)
+        assert got.shape == (90, 150, 3)
+        if kind == 2 and it % 3 != 1:                                        # (restart files resynchronise differently in libjpeg)
+            assert np.array_equal(got, oracle.jpeg_decode(bytes(fb))), it
+
+
+def test_data_cut_at_every_offset_equals_oracle(oracle, ctx):
+    """An EOI spliced into the entropy-coded segment at every byte offset (data ending inside codes, values, at block and
+    MCU boundaries, in the last block of an MCU, after a stuffed FF): kernel and oracle apply the same zero-fill rule."""
+    from visual_odometry_amd import ingest
+    for ss, step in ((2, 1), (0, 3), (1, 3)):
+        f = encode(scene(302, 90, 150, "boxes"), quality=80, subsampling=ss)
+        sos = f.index(b"\xff\xda"); start = sos + 2 + ((f[sos + 2] << 8) | f[sos + 3])
+        for i0 in range(start, len(f) - 4, step):
+            fb = bytearray(f); fb[i0:i0 + 2] = b"\xff\xd9"
+            assert np.array_equal(ingest.imdecode(bytes(fb), ctx), oracle.jpeg_decode(bytes(fb))), (ss, i0)

@@ -106,9 +106,27 @@ def test_header_info_and_rejections(oracle):
             assert np.array_equal(oracle.jpeg_decode(cut), want), (frac, ss)
 
 
-def test_exif_orientation_is_reported(oracle):
-    img = scene(3, 24, 40, "boxes")
-    ex = Image.Exif(); ex[0x0112] = 6
-    b = io.BytesIO(); Image.fromarray(img).save(b, "JPEG", exif=ex)
-    assert oracle.jpeg_info(b.getvalue())[4] == 6
-    assert oracle.jpeg_info(encode(img))[4] == 0
+def test_data_cut_by_a_marker_at_every_offset(oracle):
+    """An EOI spliced into the entropy-coded segment at EVERY byte offset of a small 4:2:0 file: the data then ends inside a
+    DC code, DC value, AC code or AC value of a luma or chroma block, at block and MCU boundaries, after a stuffed FF ...
+    The restated rule (jdhuff.c): the request that runs out is zero-filled, that MCU is finished from zero bits (a
+    zero-filled code no table entry matches consumes 17 bits and yields symbol 0), the later MCUs stay grey.  Pillow is
+    the witness: identical everywhere except, for 2 % of the offsets, INSIDE the one MCU in which the data ran out
+    (its libjpeg-turbo build leaves different garbage coefficients in the block that was cut inside an AC code)."""
+    from PIL import ImageFile
+    f = encode(scene(302, 90, 150, "boxes"), quality=80, subsampling=2)
+    sos = f.index(b"\xff\xda"); start = sos + 2 + ((f[sos + 2] << 8) | f[sos + 3])
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    exact = 0
+    try:
+        for i0 in range(start, len(f) - 4):
+            fb = bytearray(f); fb[i0:i0 + 2] = b"\xff\xd9"
+            got, want = oracle.jpeg_decode(bytes(fb)), pil_bgr(bytes(fb))
+            d = np.argwhere((got != want).any(2))
+            exact += len(d) == 0
+            if len(d):                                                   # confined to one 16x16 MCU (+ the upsampling filter's reach)
+                (y0, x0), (y1, x1) = d.min(0), d.max(0)
+                assert y1 - y0 <= 17 and x1 - x0 <= 17 and y0 // 16 * 16 - 1 <= y0 and x1 <= (x0 + 1) // 16 * 16 + 17, (i0, y0, x0, y1, x1)
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = False
+    assert exact >= 0.97 * (len(f) - 4 - start)

@@ -65,6 +65,37 @@ for (h, w) in ((70, 70), (97, 131), (64, 200)):
     img = rng.integers(0, 256, (h, w), dtype=np.uint8)
     O.orb_detect_and_compute(img, O.orb_params(nfeatures=50, nlevels=3))
     O.fast_score_nms(img, 20); O.gaussian_blur7(img); O.pyramid(img, O.orb_params(nlevels=4))
+# JPEG decode: valid files of every layout, then 400 corrupted ones (random byte flips, truncations, spliced headers): any
+# result is acceptable except a memory error
+try:
+    import io
+    from PIL import Image
+    jr = np.random.default_rng(9)
+    files = []
+    for ss in (0, 1, 2):
+        for kw in ({}, {"optimize": True}, {"restart_marker_blocks": 2}):
+            im = jr.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+            b = io.BytesIO(); Image.fromarray(im).save(b, "JPEG", quality=int(jr.integers(5, 100)), subsampling=ss, **kw); files.append(b.getvalue())
+    gb = io.BytesIO(); Image.fromarray(jr.integers(0, 256, (20, 31), dtype=np.uint8)).save(gb, "JPEG"); files.append(gb.getvalue())
+    for fbytes in files:
+        O.jpeg_decode(fbytes)
+    for it in range(400):
+        fb = bytearray(files[it % len(files)])
+        kind = it % 4
+        if kind == 0:
+            for _ in range(int(jr.integers(1, 6))): fb[int(jr.integers(2, len(fb)))] = int(jr.integers(0, 256))
+        elif kind == 1:
+            fb = fb[:int(jr.integers(2, len(fb)))]
+        elif kind == 2:
+            i0 = int(jr.integers(2, len(fb) - 8)); fb[i0:i0 + 2] = bytes([0xFF, int(jr.integers(0xC0, 0xFF))])
+        else:
+            i0 = int(jr.integers(20, len(fb))); fb[i0:] = bytes(jr.integers(0, 256, len(fb) - i0, dtype=np.uint8))
+        try:
+            O.jpeg_decode(bytes(fb))
+        except (ValueError, NotImplementedError):
+            pass
+except ImportError:
+    pass
 print("sanitized run OK")
 '''
 

@@ -353,7 +353,7 @@ __device__ __forceinline__ int jpg_symbol(JReader& r, const JLocal& T, int slot)
     if (e) { r.skip((int)(e >> 8)); return (int)(e & 255u); }
     int l = JPG_LOOK + 1;
     while (l <= 16 && (int)(top >> (16 - l)) > T.maxcode[slot][l]) l++;
-    if (l > 16) { r.skip(16); return 0; }                                 // no such code: corrupt data
+    if (l > 16) { r.skip(17); return 0; }                                 // no such code (damaged data): libjpeg reads on to its sentinel length 17 and returns 0
     const int sym = T.vals[slot][(T.valoff[slot][l] + (int)(top >> (16 - l))) & 255];
     r.skip(l);
     return sym;
@@ -496,8 +496,11 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
             JState st = s_st[last];
             if (nbits == 0) { st.bit = 0; st.bk = 0; }
             const int mcu = total_cnt / bpm;
-            jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, (mcu + 1) * bpm - total_cnt);
-            s_valid_mcus = mcu + 1;
+            if (st.bk == 0 && st.bit > nbits) s_valid_mcus = mcu;       // the MCU just completed already took bits past the end: it was the one
+            else {
+                jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, (mcu + 1) * bpm - total_cnt);
+                s_valid_mcus = mcu + 1;
+            }
         }
     }
     __threadfence_block();
