@@ -250,6 +250,23 @@ int vo_resize_linear(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channe
  * src/image_and_keypoints.py:42 (ImageAndKeypoints.set_image).  VO_ERR_UNSUPPORTED: enlargement. */
 int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels, int row_stride,
                    uint8_t* dst, int dh, int dw, int dst_stride);
+/* cv2.SIFT_create(...).detectAndCompute(img, None) — the reference's LIVE detector, /root/reference/src/visual_slam.py:17
+ * (FrameGenerator.make_frame, src/frame_generator.py:25-26); its descriptors go to vo_match_l2 (visual_slam.py:19).
+ * OpenCV 4.7's sift.dispatch.cpp / sift.simd.hpp stage for stage: doubled base image, Gaussian and DoG pyramids, scale-space
+ * extrema with sub-pixel refinement, contrast and edge tests, orientation histograms, 4 x 4 x 8 descriptors (float, values
+ * 0..255), keypoints in removeDuplicatedSorted's order, octave packed as cv2 packs it.  nfeatures must be 0 (cv2's
+ * default: keep everything).  VO_WARN_CAPACITY: more than `cap` keypoints (n_out = the number found). */
+typedef struct {
+    int32_t nfeatures;            /* 0 */
+    int32_t n_octave_layers;      /* 3 */
+    double  contrast_threshold;   /* 0.04 */
+    double  edge_threshold;       /* 10 */
+    double  sigma;                /* 1.6 */
+} vo_sift_params;
+int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride, const vo_sift_params* params,
+                               float* kp_xy /*cap x 2*/, float* kp_size, float* kp_angle, float* kp_response, int32_t* kp_octave,
+                               float* desc /*cap x 128*/, int cap, int32_t* n_out);
+
 /* cv2.imread(filename) for a .jpg — /root/reference/src/visual_slam.py:346 (also triangulate_points_from_images.py:14-15,
  * feature_detection.py:5,10).  What cv2 does with such a file is libjpeg-turbo's default decompression: baseline Huffman
  * decoding, the 13-bit integer IDCT (JDCT_ISLOW), triangle-filter ("fancy") chroma upsampling, fixed-point YCbCr -> RGB,

@@ -310,6 +310,40 @@ def resize_area(src, dw, dh):
     return dst
 
 
+def sift_pyramid_image(gray, which, octave, layer, n_layers=3, sigma=1.6):
+    """Image `layer` of octave `octave` of SIFT's Gaussian (which=0) or DoG (which=1) pyramid (voo_sift.c)."""
+    g = _u8(gray)
+    h, w = g.shape
+    ow = C.c_int32(0); oh = C.c_int32(0)
+    f = lib().voo_sift_pyramid_image
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    out = np.empty((2 * h, 2 * w), np.float32)
+    rc = f(g.ctypes.data, h, w, n_layers, sigma, which, octave, layer, out.ctypes.data, C.addressof(ow), C.addressof(oh))
+    assert rc == 0
+    return out.ravel()[:ow.value * oh.value].reshape(oh.value, ow.value).copy()
+
+
+def sift_detect_and_compute(img, n_layers=3, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6, cap=None):
+    """cv2.SIFT_create().detectAndCompute(img, None) -> dict(xy, size, angle, response, octave, desc [N, 128] float32)."""
+    a = _u8(img)
+    h, w = a.shape[:2]
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    f = lib().voo_sift_detect_and_compute
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    n = C.c_int32(0)
+    if cap is None:
+        rc = f(a.ctypes.data, h, w, cn, a.strides[0], n_layers, contrast_threshold, edge_threshold, sigma, None, None, None, None, None, None, 0, C.addressof(n))
+        assert rc == 0
+        cap = n.value
+    xy = np.zeros((cap, 2), np.float32); size = np.zeros(cap, np.float32); ang = np.zeros(cap, np.float32); resp = np.zeros(cap, np.float32)
+    octv = np.zeros(cap, np.int32); desc = np.zeros((cap, 128), np.float32)
+    rc = f(a.ctypes.data, h, w, cn, a.strides[0], n_layers, contrast_threshold, edge_threshold, sigma, xy.ctypes.data, size.ctypes.data,
+           ang.ctypes.data, resp.ctypes.data, octv.ctypes.data, desc.ctypes.data, cap, C.addressof(n))
+    assert rc == 0
+    k = min(n.value, cap)
+    return dict(xy=xy[:k], size=size[:k], angle=ang[:k], response=resp[:k], octave=octv[:k], desc=desc[:k], n_found=n.value)
+
+
 JPEG_ERRORS = {-1: "corrupt", -2: "unsupported", -3: "output too small"}
 
 

@@ -116,6 +116,16 @@ int voo_resize_area_tab(int ssize, int dsize, int32_t* si, float* alpha, int32_t
 int voo_resize_area(const uint8_t* src, int sw, int sh, int cn, int sstride,
                     uint8_t* dst, int dw, int dh, int dstride);
 
+/* the reference's live detector: cv2.SIFT_create().detectAndCompute(img, None), visual_slam.py:17 (voo_sift.c; unpinned) */
+int voo_sift_octaves(int h, int w);
+int voo_sift_gauss_kernel(double sigma, float* k);
+float voo_cv_expf(float x);
+int voo_sift_pyramid_image(const uint8_t* gray, int h, int w, int nLayers, double sigma, int which /*0 Gaussian, 1 DoG*/, int o, int layer,
+                           float* out, int32_t* ow, int32_t* oh);
+int voo_sift_detect_and_compute(const uint8_t* img, int h, int w, int channels, int row_stride, int nLayers, double contrastThreshold,
+                                double edgeThreshold, double sigma, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                                int32_t* kp_octave, float* desc /*cap x 128*/, int cap, int32_t* n_out);
+
 /* the JPEG decode of cv2.imread(filename), visual_slam.py:346 (voo_jpeg.c; pinned against Pillow's libjpeg-turbo) */
 #define VOO_OK 0
 #define VOO_JPEG_CORRUPT (-1)

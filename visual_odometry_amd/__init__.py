@@ -12,13 +12,13 @@ from .frame import Frame  # noqa: F401
 from .frame_generator import FrameGenerator  # noqa: F401
 
 __all__ = ["KeyPoint", "DMatch", "Feature", "Match", "Match3D", "MatchWithMap", "Frame", "FrameGenerator",
-           "OrbDetector", "ORB_create", "HammingMatcher", "L2Matcher", "BFMatcher", "NORM_HAMMING", "NORM_L2", "ImagePair", "ImageAndKeypoints",
+           "OrbDetector", "ORB_create", "SiftDetector", "SIFT_create", "HammingMatcher", "L2Matcher", "BFMatcher", "NORM_HAMMING", "NORM_L2", "ImagePair", "ImageAndKeypoints",
            "TriangulatePointsFromTwoImages", "FrontEnd"]
 
 
 def __getattr__(name):
     # lazily import the modules that bind libvo_hip.so
-    if name in ("OrbDetector", "ORB_create"):
+    if name in ("OrbDetector", "ORB_create", "SiftDetector", "SIFT_create"):
         from . import detector
         return getattr(detector, name)
     if name in ("HammingMatcher", "L2Matcher", "BFMatcher", "NORM_HAMMING", "NORM_L2"):

@@ -26,6 +26,11 @@ class OrbParams(C.Structure):
                 ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32)]
 
 
+class SiftParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("n_octave_layers", C.c_int32), ("contrast_threshold", C.c_double),
+                ("edge_threshold", C.c_double), ("sigma", C.c_double)]
+
+
 class PairOpts(C.Structure):
     _fields_ = [("match_mode", C.c_int32), ("ratio", C.c_double), ("ransac_prob", C.c_double),
                 ("ransac_thresh", C.c_double), ("ransac_max_iters", C.c_int32), ("ransac_seed", C.c_uint64),
@@ -84,6 +89,7 @@ _SIGS = {
     "vo_resize_linear": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vo_resize_area": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vo_frames_ingest": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _P]),
+    "vo_sift_detect_and_compute": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "vo_jpeg_info": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
     "vo_jpeg_decode": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P]),
     "vo_jpeg_decode_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int]),

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 #define MAX_EVENTS 96
 
@@ -30,6 +31,7 @@ struct vo_ctx {
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
     uint8_t* desc_x = nullptr;            // descriptors expanded to +1 / -1 bytes for the MFMA matcher
     uint8_t* ingest_out = nullptr; size_t ingest_out_bytes = 0;      // resized frames (frame ingest)
+    uint8_t *sift_buf = nullptr; size_t sift_buf_n = 0;              // SIFT: pyramids, scratch, candidate / keypoint lists, descriptors
     // JPEG decode: the batch's files, clean streams, restart lists, coefficients, component planes, B G R output, descriptors
     uint8_t *jpg_blob = nullptr, *jpg_clean = nullptr, *jpg_rst = nullptr, *jpg_coef = nullptr, *jpg_planes = nullptr, *jpg_out = nullptr,
             *jpg_img = nullptr, *jpg_tab = nullptr;
@@ -335,7 +337,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     free_config(ctx);
     free_pairbuf(ctx->raw_pb);
     void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab, ctx->raw_desc_x,
-                    ctx->ingest_out, ctx->ingest_tab, ctx->jpg_blob, ctx->jpg_clean, ctx->jpg_rst, ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out,
+                    ctx->ingest_out, ctx->ingest_tab, ctx->sift_buf, ctx->jpg_blob, ctx->jpg_clean, ctx->jpg_rst, ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out,
                     ctx->jpg_img, ctx->jpg_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
@@ -1654,6 +1656,146 @@ extern "C" int vo_frames_ingest(vo_ctx* ctx, const uint8_t* frames, int F, int s
     return VO_OK;
 }
 
+
+// ------------------------------------------------------------------ "next" row: SIFT, the reference's live detector (visual_slam.py:17)
+// getGaussianKernel(n, sigma, CV_32F) with n = cvRound(sigma * 8 + 1) | 1
+static int sift_gauss_taps(double sigma, float* k)
+{
+    const int n = (int)lrint(sigma * 4 * 2 + 1) | 1;
+    if (n > SIFT_MAX_TAPS) return -1;
+    double t[SIFT_MAX_TAPS], sum = 0;
+    const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; i++) { const double x = i - (n - 1) * 0.5; t[i] = exp(s2 * x * x); sum += t[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) k[i] = (float)(t[i] * sum);
+    return n;
+}
+
+extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride, const vo_sift_params* p,
+                                          float* kp_xy, float* kp_size, float* kp_angle, float* kp_response, int32_t* kp_octave, float* desc,
+                                          int cap, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    vo_sift_params def = {0, 3, 0.04, 10.0, 1.6};
+    if (!p) p = &def;
+    if (!img || !n_out || h < 2 || w < 2 || (channels != 1 && channels != 3 && channels != 4) || row_stride < w * channels || cap < 0)
+        FAIL(VO_ERR_INVALID, "bad arguments");
+    if (p->n_octave_layers < 1 || p->n_octave_layers > 8 || !(p->sigma > 0.5) || p->nfeatures != 0)
+        FAIL(VO_ERR_UNSUPPORTED, "SIFT: nOctaveLayers 1..8, sigma > 0.5 and nfeatures = 0 (keep every keypoint) are built");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int L = p->n_octave_layers, per = L + 3;
+    SiftPyr P; memset(&P, 0, sizeof(P));
+    P.nLayers = L;
+    int nOct = (int)lrint(log((double)(2 * (w < h ? w : h))) / log(2.) - 2) + 1;
+    if (nOct < 1) nOct = 1;
+    if (nOct > SIFT_MAX_OCT) nOct = SIFT_MAX_OCT;
+    size_t gtot = 0, dtot = 0;
+    for (int o = 0; o < nOct; o++) {
+        P.w[o] = o ? P.w[o - 1] / 2 : 2 * w; P.h[o] = o ? P.h[o - 1] / 2 : 2 * h;
+        if (P.w[o] < 1 || P.h[o] < 1) { nOct = o; break; }
+        P.goff[o] = gtot; P.doff[o] = dtot;
+        gtot += (size_t)per * P.w[o] * P.h[o]; dtot += (size_t)(L + 2) * P.w[o] * P.h[o];
+    }
+    P.nOct = nOct;
+    // Gaussian taps of the incremental blurs (buildGaussianPyramid) and of the base image (createInitialImage)
+    float taps[16][SIFT_MAX_TAPS]; int ntaps[16];
+    {
+        const double k = pow(2., 1. / L);
+        const float sd = sqrtf(fmaxf((float)(p->sigma * p->sigma - 0.5 * 0.5 * 4), 0.01f));
+        ntaps[0] = sift_gauss_taps((double)sd, taps[0]);
+        for (int i = 1; i < per; i++) {
+            const double sp = pow(k, (double)(i - 1)) * p->sigma, st = sp * k;
+            ntaps[i] = sift_gauss_taps(sqrt(st * st - sp * sp), taps[i]);
+        }
+        for (int i = 0; i < per; i++) if (ntaps[i] < 0) FAIL(VO_ERR_UNSUPPORTED, "SIFT: blur kernel wider than %d taps", SIFT_MAX_TAPS);
+    }
+    SiftExpTab E;
+    for (int i = 0; i < 64; i++) E.tab[i] = (float)pow(2.0, i / 64.0);
+    const size_t base_px = (size_t)4 * w * h, img_bytes = ((size_t)row_stride * h + 255) & ~(size_t)255;
+    const int cand_cap = 1 << 20, kp_cap = 1 << 18;
+    // layout: [gauss][dog][tmp (one base-size image)][up-sampled base][candidates][keypoints][2 counters][image bytes][descriptors]
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_g = take(gtot * 4), o_d = take(dtot * 4), o_tmp = take(base_px * 4), o_up = take(base_px * 4),
+                 o_cand = take((size_t)cand_cap * sizeof(SiftCand)), o_kp = take((size_t)kp_cap * sizeof(SiftKp)), o_cnt = take(256),
+                 o_img = take(img_bytes), o_desc = take((size_t)kp_cap * 128 * 4);
+    int rc = ensure_bytes(ctx, &ctx->sift_buf, &ctx->sift_buf_n, off); if (rc) return rc;
+    uint8_t* B = ctx->sift_buf;
+    float *G = (float*)(B + o_g), *Dg = (float*)(B + o_d), *tmp = (float*)(B + o_tmp), *up = (float*)(B + o_up), *ddesc = (float*)(B + o_desc);
+    SiftCand* dcand = (SiftCand*)(B + o_cand); SiftKp* dkp = (SiftKp*)(B + o_kp); int* dcnt = (int*)(B + o_cnt);
+    P.gauss = G; P.dog = Dg;
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemcpyAsync(B + o_img, img, (size_t)row_stride * h, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(dcnt, 0, 256, s));
+    {
+        StageTimer t(ctx, ST_MISC);
+        launch_sift_base(s, B + o_img, channels, row_stride, w, h, up);
+        for (int o = 0; o < nOct; o++) {
+            const size_t plane = (size_t)P.w[o] * P.h[o];
+            float* g0 = G + P.goff[o];
+            if (o == 0) launch_sift_blur(s, up, tmp, g0, P.w[0], P.h[0], taps[0], ntaps[0]);
+            else launch_sift_half(s, G + P.goff[o - 1] + (size_t)L * P.w[o - 1] * P.h[o - 1], P.w[o - 1], P.h[o - 1], g0, P.w[o], P.h[o]);
+            for (int i = 1; i < per; i++) launch_sift_blur(s, g0 + (size_t)(i - 1) * plane, tmp, g0 + (size_t)i * plane, P.w[o], P.h[o], taps[i], ntaps[i]);
+            launch_sift_dog(s, g0, g0 + plane, Dg + P.doff[o], (size_t)(L + 2) * plane);       // every DoG image of the octave in one launch
+        }
+        const float threshold = (float)(int)floor(0.5 * p->contrast_threshold / L * 255);
+        for (int o = 0; o < nOct; o++) launch_sift_extrema(s, Dg + P.doff[o], P.w[o], P.h[o], L, o, threshold, dcand, dcnt, cand_cap);
+    }
+    HIPCHK(hipGetLastError());
+    int counts[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(counts, dcnt, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    int warn = VO_OK;
+    int ncand = counts[0];
+    if (ncand > cand_cap) { ncand = cand_cap; warn = VO_WARN_CAPACITY; }
+    { StageTimer t(ctx, ST_MISC); launch_sift_refine(s, P, dcand, ncand, (float)p->contrast_threshold, (float)p->edge_threshold, (float)p->sigma, E, dkp, dcnt + 1, kp_cap); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(counts + 1, dcnt + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    int nk = counts[1];
+    if (nk > kp_cap) { nk = kp_cap; warn = VO_WARN_CAPACITY; }
+    std::vector<SiftKp> kps((size_t)nk);
+    if (nk) HIPCHK(hipMemcpy(kps.data(), dkp, (size_t)nk * sizeof(SiftKp), hipMemcpyDeviceToHost));
+    // KeyPointsFilter::removeDuplicatedSorted: KeyPoint_LessThan order, then drop repeats of (pt, size, angle).  The kernel
+    // appends keypoints in no fixed order; the comparator's last key (the index) only separates identical records.
+    std::sort(kps.begin(), kps.end(), [](const SiftKp& a, const SiftKp& b) {
+        if (a.x != b.x) return a.x < b.x;
+        if (a.y != b.y) return a.y < b.y;
+        if (a.size != b.size) return a.size > b.size;
+        if (a.angle != b.angle) return a.angle < b.angle;
+        if (a.response != b.response) return a.response > b.response;
+        if (a.octave != b.octave) return a.octave > b.octave;
+        return false;
+    });
+    int m = 0;
+    for (int i = 0; i < nk; i++) {
+        if (m > 0 && kps[i].x == kps[m - 1].x && kps[i].y == kps[m - 1].y && kps[i].size == kps[m - 1].size && kps[i].angle == kps[m - 1].angle) continue;
+        kps[m++] = kps[i];
+    }
+    for (int i = 0; i < m; i++) {                                 // firstOctave = -1: back to the coordinates of the input image
+        kps[i].octave = (kps[i].octave & ~255) | ((kps[i].octave - 1) & 255);
+        kps[i].x *= 0.5f; kps[i].y *= 0.5f; kps[i].size *= 0.5f;
+    }
+    *n_out = m;
+    const int nw = m < cap ? m : cap;
+    if (nw > 0 && desc) {
+        HIPCHK(hipMemcpyAsync(dkp, kps.data(), (size_t)nw * sizeof(SiftKp), hipMemcpyHostToDevice, s));
+        { StageTimer t(ctx, ST_BRIEF); launch_sift_descriptor(s, P, dkp, nw, E, ddesc); }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(desc, ddesc, (size_t)nw * 128 * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    for (int i = 0; i < nw; i++) {
+        if (kp_xy) { kp_xy[2 * i] = kps[i].x; kp_xy[2 * i + 1] = kps[i].y; }
+        if (kp_size) kp_size[i] = kps[i].size;
+        if (kp_angle) kp_angle[i] = kps[i].angle;
+        if (kp_response) kp_response[i] = kps[i].response;
+        if (kp_octave) kp_octave[i] = kps[i].octave;
+    }
+    if (ctx->prof) prof_collect(ctx);
+    if (m > cap) warn = VO_WARN_CAPACITY;
+    return warn;
+}
 
 // ------------------------------------------------------------------ "next" row: JPEG decode (cv2.imread, visual_slam.py:346)
 extern "C" int vo_jpeg_info(const uint8_t* data, size_t nbytes, int32_t* h, int32_t* w, int32_t* ncomp, int32_t* sampling, int32_t* orientation)

@@ -173,6 +173,29 @@ void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, in
                           const int* xofs, const void* xa, const int* yofs, const void* yb, int area2, int F);
 void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride, uint8_t* dst, int dw, int dh, int dstride,
                         int isx, int isy, const int* xsi, const float* xal, const int* xst, const int* ysi, const float* yal, const int* yst);
+// ---- SIFT (sift_kernels.hip): the reference's live detector, cv2.SIFT_create()
+#define SIFT_IMG_BORDER 5
+#define SIFT_MAX_INTERP_STEPS 5
+#define SIFT_MAX_OCT 16
+#define SIFT_MAX_TAPS 64
+struct SiftPyr {                 // one frame's Gaussian and DoG pyramids: octave o holds nLayers + 3 / nLayers + 2 images of w[o] x h[o]
+    const float* gauss; const float* dog;
+    int nOct, nLayers;
+    int w[SIFT_MAX_OCT], h[SIFT_MAX_OCT];
+    size_t goff[SIFT_MAX_OCT], doff[SIFT_MAX_OCT];      // float offsets of the octave's first image
+};
+struct SiftCand { int o, layer, r, c; };
+struct SiftKp { float x, y, size, angle, response; int octave; };
+struct SiftExpTab { float tab[64]; };                   // 2^(i/64), the table of cv::hal::exp32f
+void launch_sift_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int sw, int sh, float* dst);
+void launch_sift_blur(hipStream_t s, const float* src, float* tmp, float* dst, int w, int h, const float* taps, int ntaps);
+void launch_sift_half(hipStream_t s, const float* src, int sw, int sh, float* dst, int dw, int dh);
+void launch_sift_dog(hipStream_t s, const float* a, const float* b, float* d, size_t n);
+void launch_sift_extrema(hipStream_t s, const float* dog_octave, int w, int h, int nLayers, int o, float threshold, SiftCand* cand, int* ncand, int cap);
+void launch_sift_refine(hipStream_t s, const SiftPyr& P, const SiftCand* cand, int ncand, float contrastThr, float edgeThr, float sigma,
+                        const SiftExpTab& E, SiftKp* kps, int* nkp, int cap);
+void launch_sift_descriptor(hipStream_t s, const SiftPyr& P, const SiftKp* kps, int nkp, const SiftExpTab& E, float* desc);
+
 // ---- JPEG decode (jpeg_kernels.hip): cv2.imread in front of the path
 #define JPG_NT 512               // threads of the two entropy kernels = subsequences per image
 #define JPG_LOOK 10              // bits of Huffman look-ahead table

@@ -107,3 +107,63 @@ def ORB_create(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firs
     """cv2.ORB_create look-alike.  keypoint_order='cv2' returns the keypoints in cv2's own list order."""
     return OrbDetector(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize,
                        fastThreshold, keypoint_order=keypoint_order)
+
+
+class SiftDetector:
+    """cv2.SIFT_create(...) with cv2's call surface — the detector the reference actually runs (src/visual_slam.py:17),
+    injected into FrameGenerator (:21) and paired with BFMatcher(NORM_L2, crossCheck=True) (:19, matcher.L2Matcher).
+    detectAndCompute(image, None) -> (keypoints, descriptors [N, 128] float32 with values 0..255), keypoints in the order
+    cv2 returns them, .octave packed as cv2 packs it (octave | layer << 8 | round((xi + 0.5) * 255) << 16)."""
+
+    def __init__(self, nfeatures=0, nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6, ctx: _lib.Context | None = None):
+        if nfeatures != 0:
+            raise NotImplementedError("nfeatures > 0 (retainBest on the SIFT keypoints) is not built; cv2's default 0 keeps every keypoint")
+        self.params = _lib.SiftParams(0, int(nOctaveLayers), float(contrastThreshold), float(edgeThreshold), float(sigma))
+        self._ctx = ctx
+        self.truncated = False
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
+
+    def detect_arrays(self, image, cap=1 << 16):
+        img = np.ascontiguousarray(image)
+        if img.dtype != np.uint8 or img.ndim not in (2, 3):
+            raise TypeError("image must be a uint8 array of shape HxW, HxWx3 (BGR) or HxWx4 (BGRA)")
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        ctx = self.ctx
+        while True:
+            xy = np.empty((cap, 2), np.float32); size = np.empty(cap, np.float32); ang = np.empty(cap, np.float32)
+            resp = np.empty(cap, np.float32); octv = np.empty(cap, np.int32); desc = np.empty((cap, 128), np.float32)
+            n = C.c_int32(0)
+            rc = ctx.lib.vo_sift_detect_and_compute(ctx.handle, img.ctypes.data, h, w, ch, img.strides[0], C.addressof(self.params),
+                                                    xy.ctypes.data, size.ctypes.data, ang.ctypes.data, resp.ctypes.data, octv.ctypes.data,
+                                                    desc.ctypes.data, cap, C.addressof(n))
+            if rc == _lib.VO_ERR_UNSUPPORTED:
+                raise NotImplementedError(ctx.last_error())
+            ctx.check(rc)
+            if n.value <= cap or cap >= (1 << 18):
+                break
+            cap = 1 << 18                                      # the device lists' own capacity
+        k = min(n.value, cap)
+        return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=ang[:k].copy(), response=resp[:k].copy(), octave=octv[:k].copy(),
+                    desc=desc[:k].copy(), truncated=(rc == _lib.VO_WARN_CAPACITY))
+
+    def detectAndCompute(self, image, mask=None):
+        if mask is not None:
+            raise NotImplementedError("detection masks are not supported (the reference always passes None)")
+        a = self.detect_arrays(image)
+        self.truncated = a["truncated"]
+        if a["truncated"]:
+            warnings.warn("SIFT candidate / keypoint capacity reached: the keypoint list was truncated", RuntimeWarning, stacklevel=2)
+        kps = tuple(KeyPoint(x, y, s, an, r, o) for (x, y), s, an, r, o in
+                    zip(a["xy"].tolist(), a["size"].tolist(), a["angle"].tolist(), a["response"].tolist(), a["octave"].tolist()))
+        return kps, a["desc"]
+
+
+def SIFT_create(nfeatures=0, nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6) -> SiftDetector:
+    """cv2.SIFT_create look-alike (src/visual_slam.py:17)."""
+    return SiftDetector(nfeatures, nOctaveLayers, contrastThreshold, edgeThreshold, sigma)
