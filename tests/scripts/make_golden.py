@@ -75,6 +75,11 @@ def main():
     rc, rv, tv, mk, ni = O.solve_pnp_ransac(Xp, uvp, Kp)
     np.savez_compressed(os.path.join(OUT, "pnp_240.npz"), K=Kp, obj=Xp, img=uvp, R_true=Rp, t_true=tp, rc=rc, rvec=rv, tvec=tv,
                         mask=mk, n_inl=ni)
+    # SIFT (the reference's live detector): a 96 x 128 crop of the synthetic frame, every keypoint and descriptor
+    simg = np.ascontiguousarray(frames[0][60:156, 90:218])
+    sr = O.sift_detect_and_compute(simg)
+    np.savez_compressed(os.path.join(OUT, "sift_96x128.npz"), img=simg, n=sr["n_found"], xy=sr["xy"], size=sr["size"], angle=sr["angle"],
+                        response=sr["response"], octave=sr["octave"], desc=sr["desc"].astype(np.uint8))
     print("wrote", os.listdir(OUT))
 
 

@@ -29,6 +29,18 @@ def test_sift_equals_oracle(oracle, ctx, h, w):
     assert got["desc"].min() >= 0 and got["desc"].max() <= 255 and np.all(np.abs(n - 512) < 40)
 
 
+def test_sift_golden_vectors(ctx):
+    """The committed fixture (tests/golden/sift_96x128.npz, written by the oracle): needs nothing but the HIP library."""
+    import os
+    from visual_odometry_amd.detector import SiftDetector
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sift_96x128.npz"))
+    r = SiftDetector(ctx=ctx).detect_arrays(g["img"])
+    assert len(r["xy"]) == int(g["n"])
+    for k in ("xy", "size", "angle", "response", "octave"):
+        assert np.array_equal(r[k], g[k]), k
+    assert np.array_equal(r["desc"].astype(np.uint8), g["desc"])
+
+
 def test_sift_colour_input_and_parameters(oracle, ctx):
     g = random_image(11, 200, 260)
     bgr = np.stack([g, np.roll(g, 2, 0), np.roll(g, 3, 1)], axis=2)

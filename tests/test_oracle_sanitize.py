@@ -65,6 +65,11 @@ for (h, w) in ((70, 70), (97, 131), (64, 200)):
     img = rng.integers(0, 256, (h, w), dtype=np.uint8)
     O.orb_detect_and_compute(img, O.orb_params(nfeatures=50, nlevels=3))
     O.fast_score_nms(img, 20); O.gaussian_blur7(img); O.pyramid(img, O.orb_params(nlevels=4))
+# SIFT: small and odd shapes, colour input, other parameters, a flat image
+for (h, w) in ((40, 52), (97, 131), (33, 200)):
+    O.sift_detect_and_compute(rng.integers(0, 256, (h, w), dtype=np.uint8))
+O.sift_detect_and_compute(rng.integers(0, 256, (60, 70, 3), dtype=np.uint8), n_layers=4, sigma=1.4)
+O.sift_detect_and_compute(np.full((50, 50), 9, np.uint8)); O.sift_pyramid_image(f[0][:64, :80].copy(), 1, 2, 3)
 # JPEG decode: valid files of every layout, then 400 corrupted ones (random byte flips, truncations, spliced headers): any
 # result is acceptable except a memory error
 try:

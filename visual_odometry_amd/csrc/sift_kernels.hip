@@ -9,10 +9,11 @@
 //   k_sift_half        INTER_NEAREST half-size (first image of the next octave)
 //   k_sift_dog         differences of neighbouring Gaussian images
 //   k_sift_extrema     26-neighbour extrema of the DoG stack above the contrast pre-threshold -> candidate list
-//   k_sift_refine      lane per candidate: adjustLocalExtrema (<= 5 steps, Matx33f::solve closed form), contrast and edge
-//                      tests, calcOrientationHist with cv::exp32f's table algorithm and cv::fastAtan2, peak selection
-//   k_sift_descriptor  lane per keypoint: calcSIFTDescriptor; the 6 x 6 x 10 histogram of every lane lives in LDS
-//                      (bin-major, so the 64 lanes of a wave hit 64 different banks)
+//   k_sift_refine      lane per candidate: adjustLocalExtrema (<= 5 steps, Matx33f::solve closed form), contrast and edge tests
+//   k_sift_orient      WAVE per refined extremum: calcOrientationHist with cv::exp32f's table algorithm and cv::fastAtan2
+//                      (64 samples in parallel, added by the lanes that own the 36 bins, in order), peak selection
+//   k_sift_descriptor  WAVE per keypoint: calcSIFTDescriptor; 64 samples computed in parallel, then added into the 6 x 6 x 10
+//                      histogram by the lanes that own its 36 spatial cells, in the reference's order
 // Sorting and duplicate removal (KeyPointsFilter::removeDuplicatedSorted) run on the host between the last two kernels: a
 // few thousand 24-byte records.
 #include "vo_internal.h"
@@ -157,13 +158,9 @@ __global__ __launch_bounds__(256) void k_sift_extrema(const float* dog /*octave 
 // ------------------------------------------------------------------ refinement + orientation
 #define SO_BINS 36
 __global__ __launch_bounds__(64) void k_sift_refine(SiftPyr P, const SiftCand* cand, int ncand, float contrastThr, float edgeThr, float sigma,
-                                                    SiftExpTab E, SiftKp* kps, int* nkp, int cap)
+                                                    SiftSurv* surv, int* nsurv, int cap)
 {
-    __shared__ float s_hist[(SO_BINS + 4) * 64];          // temphist with two wrap-around entries each side, bin-major
-    __shared__ float s_tab[64];
     const int lane = threadIdx.x, id = blockIdx.x * 64 + lane;
-    s_tab[lane] = E.tab[lane];
-    __syncthreads();
     if (id >= ncand) return;
     SiftCand cd = cand[id];
     const int o = cd.o, nLayers = P.nLayers, w = P.w[o], h = P.h[o];
@@ -213,67 +210,111 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyr P, const SiftCand* c
         if (det <= 0 || tr * tr * edgeThr >= (edgeThr + 1) * (edgeThr + 1) * det) return;
     }
 #undef D
-    SiftKp kp;
-    kp.x = ((float)c + xc) * (float)(1 << o); kp.y = ((float)r + xr) * (float)(1 << o);
-    kp.octave = o + (layer << 8) + (__double2int_rn(((double)xi + 0.5) * 255) << 16);
-    kp.size = sigma * (float)pow(2.0, (double)(((float)layer + xi) / (float)nLayers)) * (float)(1 << o) * 2;
-    kp.response = fabsf(contr);
-    // calcOrientationHist on the Gaussian image of the keypoint's layer
-    const float scl_octv = kp.size * 0.5f / (float)(1 << o);
-    const int radius = __float2int_rn(3 * 1.5f * scl_octv), n = SO_BINS;
+    SiftSurv sv;
+    sv.kp.x = ((float)c + xc) * (float)(1 << o); sv.kp.y = ((float)r + xr) * (float)(1 << o);
+    sv.kp.octave = o + (layer << 8) + (__double2int_rn(((double)xi + 0.5) * 255) << 16);
+    sv.kp.size = sigma * (float)pow(2.0, (double)(((float)layer + xi) / (float)nLayers)) * (float)(1 << o) * 2;
+    sv.kp.response = fabsf(contr);
+    sv.kp.angle = 0.f;
+    sv.o = o; sv.layer = layer; sv.r = r; sv.c = c;
+    const int slot = atomicAdd(nsurv, 1);
+    if (slot < cap) surv[slot] = sv;
+}
+
+// calcOrientationHist + the peak selection of findScaleSpaceExtremaT, one WAVEFRONT per refined extremum.  The 36-bin
+// histogram receives w * mag of every window sample in row-major order; per batch of 64 samples the lanes compute one
+// sample each, then lane b (b < 36) adds, in order, the samples that fell into bin b.
+__global__ __launch_bounds__(64) void k_sift_orient(SiftPyr P, const SiftSurv* surv, const int* nsurv, int cap_surv, SiftExpTab E,
+                                                    SiftKp* kps, int* nkp, int cap)
+{
+    __shared__ float s_tab[64];
+    __shared__ float s_val[64];
+    __shared__ int s_bin[64];
+    __shared__ float s_th[SO_BINS + 4];
+    const int lane = threadIdx.x, id = blockIdx.x;
+    if (id >= min(*nsurv, cap_surv)) return;
+    s_tab[lane] = E.tab[lane];
+    const SiftSurv sv = surv[id];
+    const int o = sv.o, w = P.w[o], h = P.h[o], r = sv.r, c = sv.c, n = SO_BINS;
+    const float scl_octv = sv.kp.size * 0.5f / (float)(1 << o);
+    const int radius = __float2int_rn(3 * 1.5f * scl_octv);
     const float osigma = 1.5f * scl_octv, expf_scale = -1.f / (2.f * osigma * osigma);
-    const float* g = P.gauss + P.goff[o] + (size_t)layer * plane;
-    float* th = s_hist + 2 * 64 + lane;                   // th[bin * 64]
-    for (int b = -2; b < n + 2; b++) th[b * 64] = 0.f;
-    for (int ii = -radius; ii <= radius; ii++) {
-        const int y = r + ii;
-        if (y <= 0 || y >= h - 1) continue;
-        for (int jj = -radius; jj <= radius; jj++) {
-            const int x = c + jj;
-            if (x <= 0 || x >= w - 1) continue;
-            const float dx = g[(size_t)y * w + x + 1] - g[(size_t)y * w + x - 1], dy = g[(size_t)(y - 1) * w + x] - g[(size_t)(y + 1) * w + x];
-            const float wgt = sift_expf((float)(ii * ii + jj * jj) * expf_scale, s_tab);
-            const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
-            int bin = __float2int_rn((n / 360.f) * ori);
-            if (bin >= n) bin -= n;
-            if (bin < 0) bin += n;
-            th[bin * 64] += wgt * mag;
+    const float* g = P.gauss + P.goff[o] + (size_t)sv.layer * ((size_t)w * h);
+    const int side = 2 * radius + 1, total = side * side;
+    float acc = 0.f;                                         // temphist[lane] for lane < 36
+    __syncthreads();
+    for (int q0 = 0; q0 < total; q0 += 64) {
+        const int q = q0 + lane;
+        int bin = -1; float val = 0.f;
+        if (q < total) {
+            const int ii = q / side - radius, jj = q % side - radius, y = r + ii, x = c + jj;
+            if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
+                const float dx = g[(size_t)y * w + x + 1] - g[(size_t)y * w + x - 1], dy = g[(size_t)(y - 1) * w + x] - g[(size_t)(y + 1) * w + x];
+                const float wgt = sift_expf((float)(ii * ii + jj * jj) * expf_scale, s_tab);
+                const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                bin = __float2int_rn((n / 360.f) * ori);
+                if (bin >= n) bin -= n;
+                if (bin < 0) bin += n;
+                val = wgt * mag;
+            }
         }
+        s_bin[lane] = bin; s_val[lane] = val;
+        __syncthreads();
+        if (lane < n) {
+            const int cnt = min(64, total - q0);
+            for (int t = 0; t < cnt; t++) if (s_bin[t] == lane) acc += s_val[t];
+        }
+        __syncthreads();
     }
-    th[-1 * 64] = th[(n - 1) * 64]; th[-2 * 64] = th[(n - 2) * 64]; th[n * 64] = th[0]; th[(n + 1) * 64] = th[64];
-    float hist[SO_BINS];
-    float maxval = 0;
-#pragma unroll
-    for (int b = 0; b < SO_BINS; b++) {
-        hist[b] = (th[(b - 2) * 64] + th[(b + 2) * 64]) * (1.f / 16.f) + (th[(b - 1) * 64] + th[(b + 1) * 64]) * (4.f / 16.f) + th[b * 64] * (6.f / 16.f);
-        if (b == 0 || hist[b] > maxval) maxval = hist[b];
+    if (lane < n) s_th[2 + lane] = acc;
+    __syncthreads();
+    if (lane == 0) { s_th[1] = s_th[2 + n - 1]; s_th[0] = s_th[2 + n - 2]; s_th[2 + n] = s_th[2]; s_th[2 + n + 1] = s_th[3]; }
+    __syncthreads();
+    float hj = 0.f;
+    if (lane < n) {
+        const float* th = s_th + 2 + lane;
+        hj = (th[-2] + th[2]) * (1.f / 16.f) + (th[-1] + th[1]) * (4.f / 16.f) + th[0] * (6.f / 16.f);
     }
+    __syncthreads();
+    if (lane < n) s_val[lane] = hj;
+    __syncthreads();
+    if (lane >= n) return;
+    float maxval = s_val[0];
+    for (int b = 1; b < n; b++) maxval = s_val[b] > maxval ? s_val[b] : maxval;
     const float mag_thr = maxval * 0.8f;
-#pragma unroll
-    for (int j = 0; j < SO_BINS; j++) {
-        const int l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
-        if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
-            float bin = (float)j + 0.5f * (hist[l] - hist[r2]) / (hist[l] - 2 * hist[j] + hist[r2]);
-            bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
-            kp.angle = 360.f - (float)((360.f / n) * bin);
-            if (fabsf(kp.angle - 360.f) < FLT_EPSILON) kp.angle = 0.f;
-            const int slot = atomicAdd(nkp, 1);
-            if (slot < cap) kps[slot] = kp;
-        }
+    const int j = lane, l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
+    const float hl = s_val[l], hr = s_val[r2];
+    if (hj > hl && hj > hr && hj >= mag_thr) {
+        float bin = (float)j + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+        bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
+        SiftKp kp = sv.kp;
+        kp.angle = 360.f - (float)((360.f / n) * bin);
+        if (fabsf(kp.angle - 360.f) < FLT_EPSILON) kp.angle = 0.f;
+        const int slot = atomicAdd(nkp, 1);
+        if (slot < cap) kps[slot] = kp;
     }
 }
 
 // ------------------------------------------------------------------ descriptors
+// One WAVEFRONT per keypoint.  calcSIFTDescriptor adds every sample of the (2 radius + 1)^2 window, in row-major order, into 8
+// bins of a 6 x 6 x 10 histogram; float addition is not associative, so each bin must receive its contributions in that
+// order.  Per batch of 64 consecutive samples: (1) the 64 lanes compute one sample each (gradient, fastAtan2, exp32f weight,
+// trilinear split) and leave it in LDS; (2) lanes 0..35 each OWN one spatial cell (10 orientation bins) and walk the 64
+// samples in order, adding the two values of a sample that touches their cell.  Same additions, same order, 64 x the
+// parallelism of a lane-per-keypoint loop.
 #define SD_D 4
 #define SD_N 8
 #define SD_HIST ((SD_D + 2) * (SD_D + 2) * (SD_N + 2))     // 360
+struct SdSample { float v[8]; int cell; int o0; };          // v[(dr * 2 + dc) * 2 + dori]; cell = (r0 + 1) * 6 + (c0 + 1), -1 = no contribution
+
 __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr P, const SiftKp* kps, int nkp, SiftExpTab E, float* desc)
 {
-    extern __shared__ float s_mem[];                        // [SD_HIST][64] histograms + 64 table entries
-    float* s_tab = s_mem + SD_HIST * 64;
-    const int lane = threadIdx.x, id = blockIdx.x * 64 + lane;
+    __shared__ float s_hist[SD_HIST];
+    __shared__ float s_tab[64];
+    __shared__ SdSample s_smp[64];
+    const int lane = threadIdx.x, id = blockIdx.x;
     s_tab[lane] = E.tab[lane];
-    __syncthreads();
+    for (int b = lane; b < SD_HIST; b += 64) s_hist[b] = 0.f;
     if (id >= nkp) return;
     const SiftKp kp = kps[id];                              // already in input-image coordinates (firstOctave = -1 applied)
     int octave = kp.octave & 255; const int layer = (kp.octave >> 8) & 255;
@@ -293,58 +334,84 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr P, const SiftKp*
     const int rmax = (int)sqrt((double)w * w + (double)h * h);
     if (radius > rmax) radius = rmax;
     cos_t /= hist_width; sin_t /= hist_width;
-    float* hist = s_mem + lane;                             // hist[bin * 64]
-    for (int b = 0; b < SD_HIST; b++) hist[b * 64] = 0.f;
-    for (int i = -radius; i <= radius; i++)
-        for (int j = -radius; j <= radius; j++) {
+    const int side = 2 * radius + 1, total = side * side;
+    const int my_cell = lane < 36 ? lane : -1;               // (rr, cc) = (lane / 6, lane % 6)
+    __syncthreads();
+    for (int q0 = 0; q0 < total; q0 += 64) {
+        // (1) one sample per lane
+        const int q = q0 + lane;
+        SdSample sm; sm.cell = -1; sm.o0 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sm.v[k] = 0.f;
+        if (q < total) {
+            const int i = q / side - radius, j = q % side - radius;
             const float c_rot = (float)j * cos_t - (float)i * sin_t, r_rot = (float)j * sin_t + (float)i * cos_t;
             float rbin = r_rot + (float)(d / 2) - 0.5f, cbin = c_rot + (float)(d / 2) - 0.5f;
             const int r = py + i, c = px + j;
-            if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
-            const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1], dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
-            const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
-            const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
-            float obin = (Ori - ori) * bins_per_rad;
-            const float mag = Mag * Wq;
-            const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-            int o0 = (int)floorf(obin);
-            rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
-            if (o0 < 0) o0 += n;
-            if (o0 >= n) o0 -= n;
-            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            hist[idx * 64] += v_rco000; hist[(idx + 1) * 64] += v_rco001;
-            hist[(idx + (n + 2)) * 64] += v_rco010; hist[(idx + (n + 3)) * 64] += v_rco011;
-            hist[(idx + (d + 2) * (n + 2)) * 64] += v_rco100; hist[(idx + (d + 2) * (n + 2) + 1) * 64] += v_rco101;
-            hist[(idx + (d + 3) * (n + 2)) * 64] += v_rco110; hist[(idx + (d + 3) * (n + 2) + 1) * 64] += v_rco111;
-        }
-    float* dst = desc + (size_t)id * 128;
-    float nrm2 = 0;
-    for (int i = 0; i < d; i++)
-        for (int j = 0; j < d; j++) {
-            const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-            hist[idx * 64] += hist[(idx + n) * 64]; hist[(idx + 1) * 64] += hist[(idx + n + 1) * 64];
-            for (int q = 0; q < n; q++) { const float v = hist[(idx + q) * 64]; nrm2 += v * v; }
-        }
-    const float thr = sqrtf(nrm2) * 0.2f;
-    nrm2 = 0;
-    for (int i = 0; i < d; i++)
-        for (int j = 0; j < d; j++) {
-            const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-            for (int q = 0; q < n; q++) { float v = hist[(idx + q) * 64]; v = v < thr ? v : thr; hist[(idx + q) * 64] = v; nrm2 += v * v; }
-        }
-    nrm2 = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
-    for (int i = 0; i < d; i++)
-        for (int j = 0; j < d; j++) {
-            const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-            for (int q = 0; q < n; q++) {
-                const int v = __float2int_rn(hist[(idx + q) * 64] * nrm2);
-                dst[(i * d + j) * n + q] = (float)min(max(v, 0), 255);
+            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1) {
+                const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1], dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
+                const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
+                const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
+                float obin = (Ori - ori) * bins_per_rad;
+                const float mag = Mag * Wq;
+                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                int o0 = (int)floorf(obin);
+                rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                sm.v[0] = v_rco000; sm.v[1] = v_rco001; sm.v[2] = v_rco010; sm.v[3] = v_rco011;
+                sm.v[4] = v_rco100; sm.v[5] = v_rco101; sm.v[6] = v_rco110; sm.v[7] = v_rco111;
+                sm.cell = (r0 + 1) * (d + 2) + c0 + 1; sm.o0 = o0;
             }
         }
+        s_smp[lane] = sm;
+        __syncthreads();
+        // (2) the owner of each spatial cell takes its share of the 64 samples, in order
+        if (my_cell >= 0) {
+            const int cnt = min(64, total - q0);
+            for (int t = 0; t < cnt; t++) {
+                const int cell = s_smp[t].cell;
+                const int off = my_cell - cell;              // 0, 1, d + 2, d + 3 <=> (dr, dc) = (0,0), (0,1), (1,0), (1,1)
+                if (cell < 0 || !(off == 0 || off == 1 || off == d + 2 || off == d + 3)) continue;
+                const int sel = off == 0 ? 0 : off == 1 ? 2 : off == d + 2 ? 4 : 6;
+                const int o0 = s_smp[t].o0;
+                float* hb = s_hist + my_cell * (n + 2) + o0;
+                hb[0] += s_smp[t].v[sel]; hb[1] += s_smp[t].v[sel + 1];
+            }
+        }
+        __syncthreads();
+    }
+    // finalisation on one lane: a strictly sequential chain of 128-element reductions
+    if (lane == 0) {
+        float* dst = desc + (size_t)id * 128;
+        float nrm2 = 0;
+        for (int i = 0; i < d; i++)
+            for (int j = 0; j < d; j++) {
+                const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+                s_hist[idx] += s_hist[idx + n]; s_hist[idx + 1] += s_hist[idx + n + 1];
+                for (int q = 0; q < n; q++) { const float v = s_hist[idx + q]; nrm2 += v * v; }
+            }
+        const float thr = sqrtf(nrm2) * 0.2f;
+        nrm2 = 0;
+        for (int i = 0; i < d; i++)
+            for (int j = 0; j < d; j++) {
+                const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+                for (int q = 0; q < n; q++) { float v = s_hist[idx + q]; v = v < thr ? v : thr; s_hist[idx + q] = v; nrm2 += v * v; }
+            }
+        nrm2 = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
+        for (int i = 0; i < d; i++)
+            for (int j = 0; j < d; j++) {
+                const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+                for (int q = 0; q < n; q++) {
+                    const int v = __float2int_rn(s_hist[idx + q] * nrm2);
+                    dst[(i * d + j) * n + q] = (float)min(max(v, 0), 255);
+                }
+            }
+    }
 }
 
 // ------------------------------------------------------------------ launchers
@@ -379,17 +446,16 @@ void launch_sift_extrema(hipStream_t s, const float* dog_octave, int w, int h, i
 }
 
 void launch_sift_refine(hipStream_t s, const SiftPyr& P, const SiftCand* cand, int ncand, float contrastThr, float edgeThr, float sigma,
-                        const SiftExpTab& E, SiftKp* kps, int* nkp, int cap)
+                        const SiftExpTab& E, SiftSurv* surv, int* nsurv, int cap_surv, SiftKp* kps, int* nkp, int cap)
 {
     if (ncand <= 0) return;
-    hipLaunchKernelGGL(k_sift_refine, dim3((ncand + 63) / 64), dim3(64), 0, s, P, cand, ncand, contrastThr, edgeThr, sigma, E, kps, nkp, cap);
+    hipLaunchKernelGGL(k_sift_refine, dim3((ncand + 63) / 64), dim3(64), 0, s, P, cand, ncand, contrastThr, edgeThr, sigma, surv, nsurv, cap_surv);
+    // every refined extremum gets a wavefront; their number is only known on the device (at most one per candidate)
+    hipLaunchKernelGGL(k_sift_orient, dim3(ncand < cap_surv ? ncand : cap_surv), dim3(64), 0, s, P, surv, nsurv, cap_surv, E, kps, nkp, cap);
 }
 
 void launch_sift_descriptor(hipStream_t s, const SiftPyr& P, const SiftKp* kps, int nkp, const SiftExpTab& E, float* desc)
 {
     if (nkp <= 0) return;
-    const size_t lds = (size_t)(SD_HIST * 64 + 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_sift_descriptor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(k_sift_descriptor, dim3((nkp + 63) / 64), dim3(64), lds, s, P, kps, nkp, E, desc);
+    hipLaunchKernelGGL(k_sift_descriptor, dim3(nkp), dim3(64), 0, s, P, kps, nkp, E, desc);
 }

@@ -1718,11 +1718,12 @@ extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_g = take(gtot * 4), o_d = take(dtot * 4), o_tmp = take(base_px * 4), o_up = take(base_px * 4),
                  o_cand = take((size_t)cand_cap * sizeof(SiftCand)), o_kp = take((size_t)kp_cap * sizeof(SiftKp)), o_cnt = take(256),
+                 o_surv = take((size_t)kp_cap * sizeof(SiftSurv)),
                  o_img = take(img_bytes), o_desc = take((size_t)kp_cap * 128 * 4);
     int rc = ensure_bytes(ctx, &ctx->sift_buf, &ctx->sift_buf_n, off); if (rc) return rc;
     uint8_t* B = ctx->sift_buf;
     float *G = (float*)(B + o_g), *Dg = (float*)(B + o_d), *tmp = (float*)(B + o_tmp), *up = (float*)(B + o_up), *ddesc = (float*)(B + o_desc);
-    SiftCand* dcand = (SiftCand*)(B + o_cand); SiftKp* dkp = (SiftKp*)(B + o_kp); int* dcnt = (int*)(B + o_cnt);
+    SiftCand* dcand = (SiftCand*)(B + o_cand); SiftKp* dkp = (SiftKp*)(B + o_kp); int* dcnt = (int*)(B + o_cnt); SiftSurv* dsurv = (SiftSurv*)(B + o_surv);
     P.gauss = G; P.dog = Dg;
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemcpyAsync(B + o_img, img, (size_t)row_stride * h, hipMemcpyHostToDevice, s));
@@ -1748,7 +1749,7 @@ extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h
     int warn = VO_OK;
     int ncand = counts[0];
     if (ncand > cand_cap) { ncand = cand_cap; warn = VO_WARN_CAPACITY; }
-    { StageTimer t(ctx, ST_MISC); launch_sift_refine(s, P, dcand, ncand, (float)p->contrast_threshold, (float)p->edge_threshold, (float)p->sigma, E, dkp, dcnt + 1, kp_cap); }
+    { StageTimer t(ctx, ST_MISC); launch_sift_refine(s, P, dcand, ncand, (float)p->contrast_threshold, (float)p->edge_threshold, (float)p->sigma, E, dsurv, dcnt + 2, kp_cap, dkp, dcnt + 1, kp_cap); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(counts + 1, dcnt + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -186,6 +186,7 @@ struct SiftPyr {                 // one frame's Gaussian and DoG pyramids: octav
 };
 struct SiftCand { int o, layer, r, c; };
 struct SiftKp { float x, y, size, angle, response; int octave; };
+struct SiftSurv { SiftKp kp; int o, layer, r, c; };      // a refined extremum awaiting its orientation(s)
 struct SiftExpTab { float tab[64]; };                   // 2^(i/64), the table of cv::hal::exp32f
 void launch_sift_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int sw, int sh, float* dst);
 void launch_sift_blur(hipStream_t s, const float* src, float* tmp, float* dst, int w, int h, const float* taps, int ntaps);
@@ -193,7 +194,7 @@ void launch_sift_half(hipStream_t s, const float* src, int sw, int sh, float* ds
 void launch_sift_dog(hipStream_t s, const float* a, const float* b, float* d, size_t n);
 void launch_sift_extrema(hipStream_t s, const float* dog_octave, int w, int h, int nLayers, int o, float threshold, SiftCand* cand, int* ncand, int cap);
 void launch_sift_refine(hipStream_t s, const SiftPyr& P, const SiftCand* cand, int ncand, float contrastThr, float edgeThr, float sigma,
-                        const SiftExpTab& E, SiftKp* kps, int* nkp, int cap);
+                        const SiftExpTab& E, SiftSurv* surv, int* nsurv, int cap_surv, SiftKp* kps, int* nkp, int cap);
 void launch_sift_descriptor(hipStream_t s, const SiftPyr& P, const SiftKp* kps, int nkp, const SiftExpTab& E, float* desc);
 
 // ---- JPEG decode (jpeg_kernels.hip): cv2.imread in front of the path
