@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+LIB_PATH = os.environ.get("VO_HIP_LIBRARY") or os.path.join(_HERE, "libvo_hip.so")   # VO_HIP_LIBRARY: an experimental build of the same ABI
 
 VO_OK, VO_WARN_CAPACITY = 0, 1
 VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL, VO_ERR_NOT_CONFIGURED, VO_ERR_AMBIGUOUS = -1, -2, -3, -4, -5, -6

@@ -314,7 +314,9 @@ __device__ __forceinline__ void dk_iterate(const double* c, int n, double* rr, d
 // (x2^T E x1 = 0, unit Frobenius norm) to Eout and returns their number.
 // cm: this lane's slice of the 10x20 elimination matrix in LDS, element (r, k) at cm[(r*20 + k) * FP_LANES]
 // (consecutive lanes hold consecutive doubles: conflict-free ds_read/write_b64).
-#define FP_LANES 32
+#ifndef FP_LANES
+#define FP_LANES 64          // samples solved per round = lanes of the solver wave; 32 -> 51 KB of LDS, 64 -> 102 KB (measured: -1 % on
+#endif                     // the easy bench sequence, ransac -27 % / +5.7 % pairs/s once pairs need 80 iterations)
 #define CM(r, k) cm[((r) * 20 + (k)) * FP_LANES]
 typedef __attribute__((address_space(3))) double lds_double;
 __device__ __noinline__ int five_point_solve(const double* x1, const double* x2, double* Eout, lds_double* cm, bool dk_early)
@@ -598,9 +600,9 @@ __device__ __forceinline__ int count_inliers(const double* E, const double* x1, 
 }
 
 // ------------------------------------------------------------------ RANSACPointSetRegistrator::run, one workgroup (4 waves) per pair
-// Round = RS_ROUND (32) minimal samples — the adaptive count ends at 9..30 on textured pairs, so one round is the
-// common case; the elimination matrices (51 KB) are the only large LDS user and the models live in global memory
-// (L2), so the other context's streaming kernels keep most of the CU's LDS while this latency-bound kernel runs.  (1) sample indices: the RNG stream (OpenCV's MWC, data independent) is read
+// Round = RS_ROUND (64) minimal samples, one per lane of the solver wave — the adaptive count ends at 9..30 on textured
+// pairs (one round), 50..1000 on wide-baseline or low-inlier pairs, where a 64-sample round halves the number of
+// rounds; the elimination matrices (102 KB) are the only large LDS user and the models live in global memory (L2).  (1) sample indices: the RNG stream (OpenCV's MWC, data independent) is read
 // from a table, `% M` is taken by all threads in parallel, thread 0 only applies the repeat rejection;
 // (2) wave 0 solves the samples, one per lane, elimination matrices in LDS; (3) the models
 // are scored four at a time (one per wave, ballot + popcount over the correspondences) and consumed strictly
@@ -609,7 +611,7 @@ __device__ __forceinline__ int count_inliers(const double* E, const double* x1, 
 #define RS_ROUND FP_LANES
 
 struct RansacShared {
-    double cm[200 * FP_LANES];          // 51200 B
+    double cm[200 * FP_LANES];          // 102400 B
     uint32_t stream[RS_STREAM];
     int sub[64][5];
     int nm[64];
@@ -621,7 +623,8 @@ struct RansacShared {
 
 __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp, const uint32_t* rng_tab, int rng_n)
 {
-    __shared__ RansacShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // dynamic: FP_LANES = 64 needs more than the static 64 KB
+    RansacShared& sh = *(RansacShared*)s_dyn;
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = pb.m_count[p];
     const double* x1 = pb.xn1 + (size_t)p * kp_cap * 2;
@@ -783,7 +786,9 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
 
 void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp, const uint32_t* rng_tab, int rng_n)
 {
-    hipLaunchKernelGGL(k_ransac, dim3(P), dim3(256), 0, s, pb, kp_cap, rp, rng_tab, rng_n);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_ransac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RansacShared)); attr = true; }
+    hipLaunchKernelGGL(k_ransac, dim3(P), dim3(256), sizeof(RansacShared), s, pb, kp_cap, rp, rng_tab, rng_n);
 }
 
 // ------------------------------------------------------------------ triangulation (DLT, 4x4 SVD per point)
@@ -1038,13 +1043,15 @@ void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp)
 // ------------------------------------------------------------------ single five-point sample (stage test)
 __global__ __launch_bounds__(64) void k_five_point_raw(const double* x1, const double* x2, double* E, int* nm, int dk_early)
 {
-    __shared__ double s_cm[200 * FP_LANES];
-    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E, (lds_double*)s_cm, dk_early != 0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    if (threadIdx.x == 0 && blockIdx.x == 0) *nm = five_point_solve(x1, x2, E, (lds_double*)s_dyn, dk_early != 0);
 }
 
 void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, double* E, int* nm, int dk_early)
 {
-    hipLaunchKernelGGL(k_five_point_raw, dim3(1), dim3(64), 0, s, x1, x2, E, nm, dk_early);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_five_point_raw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(200 * FP_LANES * sizeof(double))); attr = true; }
+    hipLaunchKernelGGL(k_five_point_raw, dim3(1), dim3(64), 200 * FP_LANES * sizeof(double), s, x1, x2, E, nm, dk_early);
 }
 
 // ------------------------------------------------------------------ reprojection-error filter
