@@ -81,35 +81,67 @@ __global__ __launch_bounds__(256) void k_sift_base(const uint8_t* src, int chann
 // ------------------------------------------------------------------ Gaussian blur
 struct SiftTaps { int n; float k[SIFT_MAX_TAPS]; };
 
+// Four outputs per lane: the windows of a lane's four neighbouring outputs overlap in all but three samples, so the loads
+// per output drop from n to (n + 3) / 4; every output is still its own left-to-right (row) / centre-then-pairs (column) sum.
+// The tap count is a template parameter so that the window lives in registers (N = 0: any size, one output per lane).
+#define SB_PER 4
+template <int N>
 __global__ __launch_bounds__(256) void k_sift_blur_row(const float* src, float* dst, int w, int h, SiftTaps t)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const float* s = src + (size_t)y * w;
-    const int r = t.n / 2;
-    float acc;
-    if (x >= r && x + r < w) {
-        acc = t.k[0] * s[x - r];
-        for (int i = 1; i < t.n; i++) acc += t.k[i] * s[x - r + i];
-    } else {
-        acc = t.k[0] * s[reflect101(x - r, w)];
-        for (int i = 1; i < t.n; i++) acc += t.k[i] * s[reflect101(x - r + i, w)];
+    const float* s = src + (size_t)blockIdx.y * w;
+    if (N == 0) {
+        const int x = blockIdx.x * 256 + threadIdx.x, n = t.n, r = n / 2;
+        if (x >= w) return;
+        float acc = t.k[0] * s[reflect101(x - r, w)];
+        for (int i = 1; i < n; i++) acc += t.k[i] * s[reflect101(x - r + i, w)];
+        dst[(size_t)blockIdx.y * w + x] = acc;
+        return;
     }
-    dst[(size_t)y * w + x] = acc;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * SB_PER, r = N / 2;
+    if (x0 >= w) return;
+    float win[(N > 0 ? N : 1) + SB_PER - 1];
+    const bool inner = x0 >= r && x0 + SB_PER - 1 + r < w;
+#pragma unroll
+    for (int i = 0; i < N + SB_PER - 1; i++) win[i] = inner ? s[x0 - r + i] : s[reflect101(x0 - r + i, w)];
+    float acc[SB_PER];
+#pragma unroll
+    for (int q = 0; q < SB_PER; q++) acc[q] = t.k[0] * win[q];
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+#pragma unroll
+        for (int q = 0; q < SB_PER; q++) acc[q] += t.k[i] * win[i + q];
+    }
+#pragma unroll
+    for (int q = 0; q < SB_PER; q++) if (x0 + q < w) dst[(size_t)blockIdx.y * w + x0 + q] = acc[q];
 }
 
+template <int N>
 __global__ __launch_bounds__(256) void k_sift_blur_col(const float* src, float* dst, int w, int h, SiftTaps t)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= w) return;
-    const int r = t.n / 2;
-    float acc = t.k[r] * src[(size_t)y * w + x];
-    if (y >= r && y + r < h) {
-        for (int i = 1; i <= r; i++) acc += t.k[r + i] * (src[(size_t)(y + i) * w + x] + src[(size_t)(y - i) * w + x]);
-    } else {
+    if (N == 0) {
+        const int y = blockIdx.y, r = t.n / 2;
+        float acc = t.k[r] * src[(size_t)y * w + x];
         for (int i = 1; i <= r; i++) acc += t.k[r + i] * (src[(size_t)reflect101(y + i, h) * w + x] + src[(size_t)reflect101(y - i, h) * w + x]);
+        dst[(size_t)y * w + x] = acc;
+        return;
     }
-    dst[(size_t)y * w + x] = acc;
+    const int y0 = blockIdx.y * SB_PER, r = N / 2;
+    float win[(N > 0 ? N : 1) + SB_PER - 1];                // rows y0 - r .. y0 + SB_PER - 1 + r of this column
+    const bool inner = y0 >= r && y0 + SB_PER - 1 + r < h;
+#pragma unroll
+    for (int i = 0; i < N + SB_PER - 1; i++) win[i] = src[(size_t)(inner ? y0 - r + i : reflect101(y0 - r + i, h)) * w + x];
+    float acc[SB_PER];
+#pragma unroll
+    for (int q = 0; q < SB_PER; q++) acc[q] = t.k[r] * win[r + q];
+#pragma unroll
+    for (int i = 1; i <= N / 2; i++) {
+#pragma unroll
+        for (int q = 0; q < SB_PER; q++) acc[q] += t.k[r + i] * (win[r + q + i] + win[r + q - i]);
+    }
+#pragma unroll
+    for (int q = 0; q < SB_PER; q++) if (y0 + q < h) dst[(size_t)(y0 + q) * w + x] = acc[q];
 }
 
 __global__ __launch_bounds__(256) void k_sift_half(const float* src, int sw, int sh, float* dst, int dw, int dh)
@@ -370,16 +402,25 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr P, const SiftKp*
         }
         s_smp[lane] = sm;
         __syncthreads();
-        // (2) the owner of each spatial cell takes its share of the 64 samples, in order
+        // (2) the owner of each spatial cell takes its share of the 64 samples, in order.  Which samples touch cell L is a
+        //     wavefront ballot (a sample touches the 2 x 2 block of cells starting at its own); the owner then walks only
+        //     the set bits of its mask, lowest first = sample order.
+        unsigned long long mine = 0;
+        const int cell_here = sm.cell;
+#pragma unroll
+        for (int L = 0; L < 36; L++) {
+            const int off = L - cell_here;
+            const unsigned long long m = __ballot(cell_here >= 0 && (off == 0 || off == 1 || off == d + 2 || off == d + 3));
+            if (lane == L) mine = m;
+        }
         if (my_cell >= 0) {
-            const int cnt = min(64, total - q0);
-            for (int t = 0; t < cnt; t++) {
-                const int cell = s_smp[t].cell;
-                const int off = my_cell - cell;              // 0, 1, d + 2, d + 3 <=> (dr, dc) = (0,0), (0,1), (1,0), (1,1)
-                if (cell < 0 || !(off == 0 || off == 1 || off == d + 2 || off == d + 3)) continue;
+            float* hcell = s_hist + my_cell * (n + 2);
+            while (mine) {
+                const int t = __ffsll((long long)mine) - 1;
+                mine &= mine - 1;
+                const int off = my_cell - s_smp[t].cell;
                 const int sel = off == 0 ? 0 : off == 1 ? 2 : off == d + 2 ? 4 : 6;
-                const int o0 = s_smp[t].o0;
-                float* hb = s_hist + my_cell * (n + 2) + o0;
+                float* hb = hcell + s_smp[t].o0;
                 hb[0] += s_smp[t].v[sel]; hb[1] += s_smp[t].v[sel + 1];
             }
         }
@@ -420,12 +461,24 @@ void launch_sift_base(hipStream_t s, const uint8_t* src, int channels, int row_s
     hipLaunchKernelGGL(k_sift_base, dim3((2 * sw + 255) / 256, 2 * sh), dim3(256), 0, s, src, channels, row_stride, sw, sh, dst);
 }
 
+template <int N>
+static void sift_blur_n(hipStream_t s, const float* src, float* tmp, float* dst, int w, int h, const SiftTaps& t)
+{
+    const int per = N ? SB_PER : 1;
+    hipLaunchKernelGGL(k_sift_blur_row<N>, dim3((w + 256 * per - 1) / (256 * per), h), dim3(256), 0, s, src, tmp, w, h, t);
+    hipLaunchKernelGGL(k_sift_blur_col<N>, dim3((w + 255) / 256, (h + per - 1) / per), dim3(256), 0, s, tmp, dst, w, h, t);
+}
+
 void launch_sift_blur(hipStream_t s, const float* src, float* tmp, float* dst, int w, int h, const float* taps, int ntaps)
 {
     SiftTaps t; t.n = ntaps;
     for (int i = 0; i < SIFT_MAX_TAPS; i++) t.k[i] = i < ntaps ? taps[i] : 0.f;
-    hipLaunchKernelGGL(k_sift_blur_row, dim3((w + 255) / 256, h), dim3(256), 0, s, src, tmp, w, h, t);
-    hipLaunchKernelGGL(k_sift_blur_col, dim3((w + 255) / 256, h), dim3(256), 0, s, tmp, dst, w, h, t);
+    switch (ntaps) {                                        // the sizes cv2's defaults produce are 11, 13, 17, 21, 27
+#define SB_CASE(N) case N: sift_blur_n<N>(s, src, tmp, dst, w, h, t); break;
+        SB_CASE(7) SB_CASE(9) SB_CASE(11) SB_CASE(13) SB_CASE(15) SB_CASE(17) SB_CASE(19) SB_CASE(21) SB_CASE(23) SB_CASE(25) SB_CASE(27) SB_CASE(29) SB_CASE(31)
+#undef SB_CASE
+        default: sift_blur_n<0>(s, src, tmp, dst, w, h, t);
+    }
 }
 
 void launch_sift_half(hipStream_t s, const float* src, int sw, int sh, float* dst, int dw, int dh)
