@@ -367,7 +367,7 @@ void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count,
 // One lane per query row (its elements stay in registers for DIM = 128), train rows broadcast from LDS tiles.
 #define L2_TILE 32
 template <int DIM>
-__global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist)
+__global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const float* B, int nb, int dim, unsigned long long* key, int split_rows)
 {
     extern __shared__ float s_t[];                       // [L2_TILE][dim]
     const int row = blockIdx.x * 64 + threadIdx.x;
@@ -380,8 +380,12 @@ __global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const floa
     }
     float best = FLT_MAX;
     int bi = -1;
-    for (int base = 0; base < nb; base += L2_TILE) {
-        const int rows = min(L2_TILE, nb - base);
+    // blockIdx.y: this workgroup's share of the train rows; the shares meet in a 64-bit atomic minimum of
+    // (distance bits << 32 | train index) — non-negative floats order like their bit patterns, so the minimum is the
+    // smallest distance and, among equals, the lowest index: the ascending scan with strict `<`
+    const int b_lo = blockIdx.y * split_rows, b_hi = min(nb, b_lo + split_rows);
+    for (int base = b_lo; base < b_hi; base += L2_TILE) {
+        const int rows = min(L2_TILE, b_hi - base);
         __syncthreads();
         for (int i = threadIdx.x; i < rows * dim; i += 64) s_t[i] = B[(size_t)base * dim + i];
         __syncthreads();
@@ -417,13 +421,33 @@ __global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const floa
             if (d < best) { best = d; bi = base + r; }
         }
     }
-    if (live) { idx[row] = bi; dist[row] = best; }
+    if (live && bi >= 0) atomicMin(&key[row], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi);
 }
 
-void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist)
+__global__ void k_nn_l2_decode(const unsigned long long* key, int na, int* idx, float* dist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= na) return;
+    const unsigned long long k = key[i];
+    idx[i] = k == ~0ULL ? -1 : (int)(k & 0xffffffffu);
+    dist[i] = k == ~0ULL ? FLT_MAX : __uint_as_float((unsigned)(k >> 32));
+}
+
+void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist, unsigned long long* key)
 {
     if (na <= 0) return;
     const size_t shmem = (size_t)L2_TILE * dim * sizeof(float);
-    if (dim == 128) hipLaunchKernelGGL(k_nn_l2<128>, dim3((na + 63) / 64), dim3(64), shmem, s, A, na, B, nb, dim, idx, dist);
-    else hipLaunchKernelGGL(k_nn_l2<0>, dim3((na + 63) / 64), dim3(64), shmem, s, A, na, B, nb, dim, idx, dist);
+    const int gx = (na + 63) / 64;
+    // enough workgroups to fill the chip: the train rows are cut into shares of whole LDS tiles
+    int nsplit = (2048 + gx - 1) / gx;
+    const int max_split = (nb + 4 * L2_TILE - 1) / (4 * L2_TILE);
+    nsplit = nsplit < 1 ? 1 : nsplit > max_split ? max_split : nsplit;
+    if (nsplit < 1) nsplit = 1;
+    int split_rows = (nb + nsplit - 1) / nsplit;
+    split_rows = (split_rows + L2_TILE - 1) / L2_TILE * L2_TILE;
+    nsplit = nb > 0 ? (nb + split_rows - 1) / split_rows : 1;
+    (void)hipMemsetAsync(key, 0xFF, (size_t)na * sizeof(unsigned long long), s);
+    if (dim == 128) hipLaunchKernelGGL(k_nn_l2<128>, dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, key, split_rows);
+    else hipLaunchKernelGGL(k_nn_l2<0>, dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, key, split_rows);
+    hipLaunchKernelGGL(k_nn_l2_decode, dim3((na + 255) / 256), dim3(256), 0, s, key, na, idx, dist);
 }

@@ -1117,18 +1117,19 @@ extern "C" int vo_match_l2(vo_ctx* ctx, const float* q, int nq, const float* t, 
     if (nq == 0 || nt == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nf = (size_t)(nq + nt) * dim, ni = (size_t)2 * (nq + nt);
-    int rc = ensure_raw_d(ctx, (nf + ni) / 2 + 64);
+    int rc = ensure_raw_d(ctx, (nf + ni) / 2 + 64 + (size_t)(nq + nt));
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     float* dq = (float*)ctx->raw_d; float* dt = dq + (size_t)nq * dim;
     int* fi = (int*)(dt + (size_t)nt * dim); int* ri = fi + nq;
     float* fd = (float*)(ri + nt); float* rd = fd + nq;
+    unsigned long long* fkey = (unsigned long long*)((double*)ctx->raw_d + (nf + ni) / 2 + 32); unsigned long long* rkey = fkey + nq;
     HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dt, t, (size_t)nt * dim * sizeof(float), hipMemcpyHostToDevice, s));
     {
         StageTimer tm(ctx, ST_MATCH_NN);
-        if (cross_check != 1) launch_nn_l2(s, dq, nq, dt, nt, dim, fi, fd);
-        if (cross_check != 0) launch_nn_l2(s, dt, nt, dq, nq, dim, ri, rd);
+        if (cross_check != 1) launch_nn_l2(s, dq, nq, dt, nt, dim, fi, fd, fkey);
+        if (cross_check != 0) launch_nn_l2(s, dt, nt, dq, nq, dim, ri, rd, rkey);
     }
     HIPCHK(hipGetLastError());
     std::vector<int> hfi(nq, -1), hri(nt, -1);

@@ -253,7 +253,7 @@ void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
                          int mode, double ratio, const double* K);
 
-void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist);
+void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist, unsigned long long* key);
 
 void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp, const uint32_t* rng_tab, int rng_n);
 void launch_pose(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp);

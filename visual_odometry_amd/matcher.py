@@ -72,8 +72,7 @@ class HammingMatcher:
 
 class L2Matcher:
     """cv2.BFMatcher(cv2.NORM_L2, crossCheck) on float32 descriptors — the reference's live matcher
-    (src/visual_slam.py:19; SIFT rows, 128 floats).  The SIFT detector itself is not built: this matcher takes any
-    float descriptor rows."""
+    (src/visual_slam.py:19; SIFT rows, 128 floats: detector.SiftDetector).  Takes any float descriptor rows."""
 
     def __init__(self, crossCheck: bool = False, legacy_crosscheck: bool = False, ctx: _lib.Context | None = None):
         self.crossCheck = bool(crossCheck)
