@@ -69,6 +69,18 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* cyc,
         if (OP == 29) { BODY("v_pk_lshrrev_b16 %0, 3, %0") BODY("v_pk_ashrrev_i16 %0, 3, %0") }
         if (OP == 30) { BODY("v_add3_u32 %0, %0, %1, %3") BODY("v_or3_b32 %0, %0, %1, %3") }
         if (OP == 31) { BODY("v_cmp_gt_u16_sdwa vcc, %0, %3 src0_sel:BYTE_0 src1_sel:BYTE_1") BODY("v_and_b32_sdwa %0, %0, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD") }
+        if (OP == 32) { BODY("v_pk_min_f16 %0, %0, %3") BODY("v_pk_max_f16 %0, %0, %3") }
+        if (OP == 33) { BODY("v_pk_add_f16 %0, %0, %3") BODY("v_pk_add_f16 %0, %0, %3 neg_lo:[0,1] neg_hi:[0,1]") }
+        if (OP == 34) { BODY("v_pk_minimum3_f16 %0, %0, %1, %3") BODY("v_pk_maximum3_f16 %0, %0, %1, %3") }
+        if (OP == 35) { BODY("v_min_f16 %0, %0, %3") BODY("v_max_f16 %0, %0, %3") }
+        if (OP == 36) { BODY("v_min_f32 %0, %0, %3") BODY("v_max_f32 %0, %0, %3") }
+        if (OP == 37) { BODY("v_min3_f32 %0, %0, %1, %3") BODY("v_max3_f32 %0, %0, %1, %3") }
+        if (OP == 38) { BODY("v_and_b32 %0, %0, %3") BODY("v_or_b32 %0, %0, %3") }
+        if (OP == 39) { BODY("v_lshlrev_b32 %0, 3, %0") BODY("v_lshrrev_b32 %0, 3, %0") }
+        if (OP == 40) { BODY("v_pk_fma_f16 %0, %0, %1, %3") BODY("v_pk_mul_f16 %0, %0, %3") }
+        if (OP == 41) { BODY("v_sub_u32 %0, %0, %3") BODY("v_subrev_u32 %0, %0, %3") }
+        if (OP == 42) { BODY("v_min3_f16 %0, %0, %1, %3") BODY("v_max3_f16 %0, %0, %1, %3") }
+        if (OP == 43) { BODY("v_pk_min_u16 %0, %0, %3") BODY("v_pk_max_u16 %0, %0, %3") }
 #undef BODY
 #undef ONE
     }
@@ -141,6 +153,10 @@ int main()
     RUN(2, "v_pk_sub_i16"); RUN(18, "v_pk_add_u16"); RUN(3, "v_pk_min_i16"); RUN(4, "v_pk_max_i16"); RUN(17, "v_pk_mul_lo_u16"); RUN(29, "v_pk_lshrrev_b16 / v_pk_ashrrev_i16");
     RUN(16, "v_cndmask_b32 (vcc)"); RUN(28, "v_cmp_gt_u32 / v_cmp_gt_i32 -> vcc"); RUN(31, "v_cmp_gt_u16_sdwa / v_and_b32_sdwa");
     RUN(21, "v_add_f32"); RUN(22, "v_fma_f32");
+    RUN(38, "v_and_b32 / v_or_b32"); RUN(39, "v_lshlrev_b32 / v_lshrrev_b32"); RUN(41, "v_sub_u32 / v_subrev_u32");
+    RUN(36, "v_min_f32 / v_max_f32"); RUN(37, "v_min3_f32 / v_max3_f32"); RUN(35, "v_min_f16 / v_max_f16"); RUN(42, "v_min3_f16 / v_max3_f16");
+    RUN(32, "v_pk_min_f16 / v_pk_max_f16"); RUN(33, "v_pk_add_f16 (+ neg modifier)"); RUN(34, "v_pk_minimum3_f16 / v_pk_maximum3_f16");
+    RUN(40, "v_pk_fma_f16 / v_pk_mul_f16"); RUN(43, "v_pk_min_u16 / v_pk_max_u16");
     measure("v_pk_fma_f32", [](int blocks) { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(256), 0, 0, (float*)g_out, g_cyc, 1.5f); });
     RUN(24, "ds_read_b32 (conflict-free)"); RUN(25, "ds_read_u8 (scattered bytes)");
     return 0;

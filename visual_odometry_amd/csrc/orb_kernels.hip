@@ -441,8 +441,97 @@ void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride,
 #define FT_QCAP 1024                     // candidate queue; a tile that overflows it takes the dense path
 #endif
 
-// cornerScore<16> with the corner decision folded in: 0 if the pixel at c (centre in the LDS pixel tile) is
-// no FAST-9 corner, else max(A, B) - 1.  Q[k] holds the ring differences (d[k], d[k+8]) as two int16.
+// cornerScore<16> with the corner decision folded in: 0 if the pixel at c (centre in the LDS pixel tile) is no FAST-9
+// corner, else max(A, B) - 1, A / B = best 9-arc minimum of (v - ring) / (ring - v).
+//
+// Two ring differences per register, (d[k], d[k + 8]), held as packed FP16: an integer 0..255 read as an FP16 bit pattern
+// is the subnormal n * 2^-24, sums and differences of such values are exact, and gfx950 has three-input packed
+// minimum / maximum (v_pk_minimum3_f16 / v_pk_maximum3_f16) at the issue cost of the two-input integer forms.  The
+// minimum over 9 consecutive differences is then min3 of min3s: t3[k] = min3(d[k], d[k+1], d[k+2]),
+// w9[k] = min3(t3[k], t3[k+3], t3[k+6]) — 16 instructions for all 16 arcs (the integer ladder of windows 2, 4, 8, 9
+// needs 40), and the VOP3P op_sel bits read "index + 8" (the same register with its halves exchanged) without a
+// separate swap instruction.
+#ifndef FAST_SCORE_I16
+#define PKF_SEL_000 ""
+#define PKF_SEL_001 " op_sel:[0,0,1] op_sel_hi:[1,1,0]"
+#define PKF_SEL_010 " op_sel:[0,1,0] op_sel_hi:[1,0,1]"
+#define PKF_SEL_011 " op_sel:[0,1,1] op_sel_hi:[1,0,0]"
+#define PKF3(name, sel)                                                                                     \
+    __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b, uint32_t c)                           \
+    { uint32_t d; asm("v_pk_" sel : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// min3 / max3 with the halves of operands 2 / 3 exchanged as the suffix says (x = exchanged)
+PKF3(pkf_min3, "minimum3_f16 %0, %1, %2, %3" PKF_SEL_000)   PKF3(pkf_min3_x3, "minimum3_f16 %0, %1, %2, %3" PKF_SEL_001)
+PKF3(pkf_min3_x23, "minimum3_f16 %0, %1, %2, %3" PKF_SEL_011)
+PKF3(pkf_max3, "maximum3_f16 %0, %1, %2, %3" PKF_SEL_000)   PKF3(pkf_max3_x3, "maximum3_f16 %0, %1, %2, %3" PKF_SEL_001)
+PKF3(pkf_max3_x23, "maximum3_f16 %0, %1, %2, %3" PKF_SEL_011)
+#undef PKF3
+__device__ __forceinline__ uint32_t pkf_sub(uint32_t a, uint32_t b)
+{ uint32_t d; asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pkf_max(uint32_t a, uint32_t b)
+{ uint32_t d; asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pkf_min(uint32_t a, uint32_t b)
+{ uint32_t d; asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pkf_max_x2(uint32_t a, uint32_t b)       // max(a, b with halves exchanged)
+{ uint32_t d; asm("v_pk_max_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pkf_min_x2(uint32_t a, uint32_t b)
+{ uint32_t d; asm("v_pk_min_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
+// The 16 ring bytes of a candidate as eight (ring[k], ring[k + 8]) pairs.  (ds_read_u8_d16 / _d16_hi would load a byte
+// straight into one half of a register, but with SRAM ECC on — as on MI355X — a D16 load clears the other half instead of
+// preserving it, so the pairs are packed with one v_lshl_or_b32 each.)
+__device__ __forceinline__ void fast_ring_pairs(const uint8_t* c, uint32_t (&R)[8])
+{
+#define RD(k, o0, o8) R[k] = (uint32_t)c[o0] | ((uint32_t)c[o8] << 16)
+    RD(0, 3 * FT_PXW, -3 * FT_PXW);         RD(1, 3 * FT_PXW + 1, -3 * FT_PXW - 1);
+    RD(2, 2 * FT_PXW + 2, -2 * FT_PXW - 2); RD(3, FT_PXW + 3, -FT_PXW - 3);
+    RD(4, 3, -3);                           RD(5, -FT_PXW + 3, FT_PXW - 3);
+    RD(6, -2 * FT_PXW + 2, 2 * FT_PXW - 2); RD(7, -3 * FT_PXW + 1, 3 * FT_PXW - 1);
+#undef RD
+}
+
+// score from the centre value and the eight (ring[k], ring[k + 8]) pairs
+__device__ __forceinline__ int fast_score_from_ring(uint32_t v, const uint32_t (&R)[8], int t)
+{
+    const uint32_t vv = v | (v << 16);
+    uint32_t Q[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) Q[k] = pkf_sub(vv, R[k]);
+    // windows of 3 consecutive differences; d[k + 8] = Q[k] with its halves exchanged
+    uint32_t n3[8], x3[8];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { n3[k] = pkf_min3(Q[k], Q[k + 1], Q[k + 2]); x3[k] = pkf_max3(Q[k], Q[k + 1], Q[k + 2]); }
+    n3[6] = pkf_min3_x3(Q[6], Q[7], Q[0]);   x3[6] = pkf_max3_x3(Q[6], Q[7], Q[0]);
+    n3[7] = pkf_min3_x23(Q[7], Q[0], Q[1]);  x3[7] = pkf_max3_x23(Q[7], Q[0], Q[1]);
+    // windows of 9 = three windows of 3
+    uint32_t n9[8], x9[8];
+    n9[0] = pkf_min3(n3[0], n3[3], n3[6]);      x9[0] = pkf_max3(x3[0], x3[3], x3[6]);
+    n9[1] = pkf_min3(n3[1], n3[4], n3[7]);      x9[1] = pkf_max3(x3[1], x3[4], x3[7]);
+    n9[2] = pkf_min3_x3(n3[2], n3[5], n3[0]);   x9[2] = pkf_max3_x3(x3[2], x3[5], x3[0]);
+    n9[3] = pkf_min3_x3(n3[3], n3[6], n3[1]);   x9[3] = pkf_max3_x3(x3[3], x3[6], x3[1]);
+    n9[4] = pkf_min3_x3(n3[4], n3[7], n3[2]);   x9[4] = pkf_max3_x3(x3[4], x3[7], x3[2]);
+    n9[5] = pkf_min3_x23(n3[5], n3[0], n3[3]);  x9[5] = pkf_max3_x23(x3[5], x3[0], x3[3]);
+    n9[6] = pkf_min3_x23(n3[6], n3[1], n3[4]);  x9[6] = pkf_max3_x23(x3[6], x3[1], x3[4]);
+    n9[7] = pkf_min3_x23(n3[7], n3[2], n3[5]);  x9[7] = pkf_max3_x23(x3[7], x3[2], x3[5]);
+    // A = the largest arc minimum, -B = the smallest arc maximum (both halves of all eight registers)
+    uint32_t A2 = pkf_max3(pkf_max3(n9[0], n9[1], n9[2]), pkf_max3(n9[3], n9[4], n9[5]), pkf_max(n9[6], n9[7]));
+    uint32_t B2 = pkf_min3(pkf_min3(x9[0], x9[1], x9[2]), pkf_min3(x9[3], x9[4], x9[5]), pkf_min(x9[6], x9[7]));
+    A2 = pkf_max_x2(A2, A2); B2 = pkf_min_x2(B2, B2);
+    // back to integers: an FP16 subnormal pattern is sign | magnitude
+    const int A = (A2 & 0x8000u) ? -(int)(A2 & 0x7fffu) : (int)(A2 & 0x7fffu);
+    const int B = (B2 & 0x8000u) ? (int)(B2 & 0x7fffu) : -(int)(B2 & 0x7fffu);
+    const int m = max(A, B);
+    return m > t ? m - 1 : 0;
+}
+
+__device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)                 // one candidate (dense fallback path)
+{
+    uint32_t R[8];
+    fast_ring_pairs(c, R);
+    return fast_score_from_ring(c[0], R, t);
+}
+#define FAST_SCORE_PAIR 1
+#else
+// the packed-int16 form (windows of 2, 4, 8, 9): Q[k] holds the ring differences (d[k], d[k+8]) as two int16
 __device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)
 {
     const uint32_t v = c[0], vv = v | (v << 16);
@@ -476,6 +565,8 @@ __device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)
     const int m = max(A, B);
     return m > t ? m - 1 : 0;
 }
+
+#endif
 
 // DENSE = true writes the score map (the stage API / tests); false (the pipeline) writes, per tile, the list of NMS
 // winners inside the border as (score << 16 | row in tile << 8 | column in tile) and their number: retainBest then
@@ -631,8 +722,16 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
             const int ea = e0 + lane, eb = ea + 64;
             const bool ha = ea < qn, hb = eb < qn;
             const int qa = s_q[ha ? ea : 0], qb = s_q[hb ? eb : 0];
+#ifdef FAST_SCORE_PAIR
+            const uint8_t* ca = s_px + ((qa >> 8) + 3) * FT_PXW + 12 + (qa & 255); const uint8_t* cb = s_px + ((qb >> 8) + 3) * FT_PXW + 12 + (qb & 255);
+            uint32_t Ra[8], Rb[8];
+            fast_ring_pairs(ca, Ra); fast_ring_pairs(cb, Rb);
+            int sa = fast_score_from_ring(ca[0], Ra, t);
+            int sb = fast_score_from_ring(cb[0], Rb, t);
+#else
             int sa = fast_score_or_zero(s_px + ((qa >> 8) + 3) * FT_PXW + 12 + (qa & 255), t);
             int sb = fast_score_or_zero(s_px + ((qb >> 8) + 3) * FT_PXW + 12 + (qb & 255), t);
+#endif
             sa = ha ? sa : 0; sb = hb ? sb : 0;
             const unsigned long long ma = __ballot(sa != 0), mb = __ballot(sb != 0);
             const int pa = nc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
