@@ -489,19 +489,17 @@ __device__ __forceinline__ void fast_ring_pairs(const uint8_t* c, uint32_t (&R)[
 #undef RD
 }
 
-// score from the centre value and the eight (ring[k], ring[k + 8]) pairs
+// score from the centre value and the eight (ring[k], ring[k + 8]) pairs.  The ring values themselves go through the
+// window ladder (no per-pair subtraction): best arc minimum of (v - ring) = v - smallest arc maximum of ring, best arc
+// minimum of (ring - v) = largest arc minimum of ring - v.
 __device__ __forceinline__ int fast_score_from_ring(uint32_t v, const uint32_t (&R)[8], int t)
 {
-    const uint32_t vv = v | (v << 16);
-    uint32_t Q[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) Q[k] = pkf_sub(vv, R[k]);
-    // windows of 3 consecutive differences; d[k + 8] = Q[k] with its halves exchanged
+    // windows of 3 consecutive ring values; ring[k + 8] = R[k] with its halves exchanged
     uint32_t n3[8], x3[8];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { n3[k] = pkf_min3(Q[k], Q[k + 1], Q[k + 2]); x3[k] = pkf_max3(Q[k], Q[k + 1], Q[k + 2]); }
-    n3[6] = pkf_min3_x3(Q[6], Q[7], Q[0]);   x3[6] = pkf_max3_x3(Q[6], Q[7], Q[0]);
-    n3[7] = pkf_min3_x23(Q[7], Q[0], Q[1]);  x3[7] = pkf_max3_x23(Q[7], Q[0], Q[1]);
+    for (int k = 0; k < 6; k++) { n3[k] = pkf_min3(R[k], R[k + 1], R[k + 2]); x3[k] = pkf_max3(R[k], R[k + 1], R[k + 2]); }
+    n3[6] = pkf_min3_x3(R[6], R[7], R[0]);   x3[6] = pkf_max3_x3(R[6], R[7], R[0]);
+    n3[7] = pkf_min3_x23(R[7], R[0], R[1]);  x3[7] = pkf_max3_x23(R[7], R[0], R[1]);
     // windows of 9 = three windows of 3
     uint32_t n9[8], x9[8];
     n9[0] = pkf_min3(n3[0], n3[3], n3[6]);      x9[0] = pkf_max3(x3[0], x3[3], x3[6]);
@@ -512,13 +510,12 @@ __device__ __forceinline__ int fast_score_from_ring(uint32_t v, const uint32_t (
     n9[5] = pkf_min3_x23(n3[5], n3[0], n3[3]);  x9[5] = pkf_max3_x23(x3[5], x3[0], x3[3]);
     n9[6] = pkf_min3_x23(n3[6], n3[1], n3[4]);  x9[6] = pkf_max3_x23(x3[6], x3[1], x3[4]);
     n9[7] = pkf_min3_x23(n3[7], n3[2], n3[5]);  x9[7] = pkf_max3_x23(x3[7], x3[2], x3[5]);
-    // A = the largest arc minimum, -B = the smallest arc maximum (both halves of all eight registers)
-    uint32_t A2 = pkf_max3(pkf_max3(n9[0], n9[1], n9[2]), pkf_max3(n9[3], n9[4], n9[5]), pkf_max(n9[6], n9[7]));
-    uint32_t B2 = pkf_min3(pkf_min3(x9[0], x9[1], x9[2]), pkf_min3(x9[3], x9[4], x9[5]), pkf_min(x9[6], x9[7]));
-    A2 = pkf_max_x2(A2, A2); B2 = pkf_min_x2(B2, B2);
-    // back to integers: an FP16 subnormal pattern is sign | magnitude
-    const int A = (A2 & 0x8000u) ? -(int)(A2 & 0x7fffu) : (int)(A2 & 0x7fffu);
-    const int B = (B2 & 0x8000u) ? (int)(B2 & 0x7fffu) : -(int)(B2 & 0x7fffu);
+    // the largest arc minimum and the smallest arc maximum over both halves of all eight registers
+    uint32_t N2 = pkf_max3(pkf_max3(n9[0], n9[1], n9[2]), pkf_max3(n9[3], n9[4], n9[5]), pkf_max(n9[6], n9[7]));
+    uint32_t X2 = pkf_min3(pkf_min3(x9[0], x9[1], x9[2]), pkf_min3(x9[3], x9[4], x9[5]), pkf_min(x9[6], x9[7]));
+    N2 = pkf_max_x2(N2, N2); X2 = pkf_min_x2(X2, X2);
+    // non-negative subnormals: the bit pattern is the integer
+    const int A = (int)v - (int)(X2 & 0xffffu), B = (int)(N2 & 0xffffu) - (int)v;
     const int m = max(A, B);
     return m > t ? m - 1 : 0;
 }
