@@ -105,11 +105,13 @@ void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_
 }
 
 // ------------------------------------------------------------------ Hamming matrix on the matrix cores
-// 256-bit Hamming distance is a dot product once the bits are written as +1 / -1 bytes:
-// sum_k a_k b_k = 256 - 2 * hamming, exact in int32.  The descriptor sets of a pair are a 2000 x 2000 x 256
+// 256-bit Hamming distance is a dot product once the bits are written as +e / -e bytes:
+// sum_k a_k b_k = e^2 (256 - 2 * hamming), exact in int32.  The descriptor sets of a pair are a 2000 x 2000 x 256
 // contraction, the one GEMM-shaped piece of the path (compute bound: 2 GOP per pair and direction against
-// 128 KB of operands), so it runs on v_mfma_i32_16x16x64_i8 and the VALU only folds the 16x16 accumulator
-// blocks into the running (distance, index) keys: 2 instructions per distance instead of the 16 of XOR+popcount.
+// 128 KB of operands), so it runs on v_mfma_i32_16x16x64_i8.  With e = 127 the products are multiples of
+// S = 16129 > any column index, so the accumulator can START at S * 256 + (S - 1 - column): what the matrix core
+// returns is already the (distance, index) selection key S * (dot + 256) + (S - 1 - j) — larger = nearer, then the
+// lower index — and the VALU folds a 16 x 16 block with ONE signed max per distance (XOR + popcount needs 16).
 //
 // Expanded layout (k_desc_expand, once per frame): [frame][group = row / 16][chunk 0..15][row % 16][16 B], i.e.
 // the 16 bytes lane l of an MFMA operand needs for k-step s (row l & 15, chunk 4 s + (l >> 4)) of 16 rows are one
@@ -117,7 +119,7 @@ void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_
 __device__ __forceinline__ uint32_t expand4(uint32_t nib)
 {
     const uint32_t m = (nib * 0x00204081u) & 0x01010101u;     // bit i -> byte i
-    return ~(m * 0xfeu);                                       // 1 -> 0x01 (+1), 0 -> 0xff (-1)
+    return 0x81818181u ^ (m * 0xfeu);                          // 1 -> 0x7f (+127), 0 -> 0x81 (-127)
 }
 
 __global__ __launch_bounds__(256) void k_desc_expand(const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x)
@@ -151,9 +153,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define MM_BLOCK_ROWS (MM_WAVES * MM_WAVE_ROWS)
 #define MM_LD (MM_STAGE_ROWS * 256 / 16 / MM_THREADS)   // 16-byte staging loads per thread and stage
 
-// Nearest (and second nearest) row of B for every row of A.  key = (dot + 256) << 16 | (65535 - j): a signed max
-// is OpenCV's ascending scan with strict `<` (smaller distance first, then the lower index); columns beyond nb
+// Nearest (and second nearest) row of B for every row of A.  key = S * (dot + 256) + (S - 1 - j), S = 127^2: a signed
+// max is OpenCV's ascending scan with strict `<` (smaller distance first, then the lower index); columns beyond nb
 // start from a large negative accumulator and can never win.
+#define MM_S 16129
 template <bool KNN2>
 __global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x,
                                                  PairBuf pb, int dir_first, int row_blocks)
@@ -180,7 +183,8 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, c
         for (int s = 0; s < 4; s++)
             a[rb][s] = wrow0 < na ? *(const v4i*)(A + ((size_t)((wrow0 >> 4) + rb) * 16 + 4 * s + lg) * 256 + li * 16) : (v4i){0, 0, 0, 0};
 
-    const v4i c_ok = {256, 256, 256, 256}, c_bad = {-16384, -16384, -16384, -16384};
+    const v4i c_bad = {-(1 << 30), -(1 << 30), -(1 << 30), -(1 << 30)};
+    const int c_lane = MM_S * 256 + (MM_S - 1) - li;              // accumulator start of column j0 + li, minus j0
     v4i best[MM_RB], best2[MM_RB];
 #pragma unroll
     for (int rb = 0; rb < MM_RB; rb++) { best[rb] = (v4i){INT_MIN, INT_MIN, INT_MIN, INT_MIN}; best2[rb] = best[rb]; }
@@ -204,7 +208,8 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, c
         const int ng = active ? min(4, (nb - sg * MM_STAGE_ROWS + 15) >> 4) : 0;
         for (int g = 0; g < ng; g++) {
             const int j0 = sg * MM_STAGE_ROWS + g * 16;
-            v4i cin = c_ok;
+            const int c0 = c_lane - j0;
+            v4i cin = {c0, c0, c0, c0};
             if (j0 + 16 > nb && j0 + li >= nb) cin = c_bad;
             v4i b[4], acc[MM_RB];
 #pragma unroll
@@ -215,12 +220,11 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, c
             for (int s = 1; s < 4; s++)
 #pragma unroll
                 for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][s], b[s], acc[rb], 0, 0, 0);
-            const uint32_t jr = 65535u - (uint32_t)(j0 + li);
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int key = (int)(((uint32_t)acc[rb][r] << 16) | jr);
+                    const int key = acc[rb][r];
                     if (KNN2) best2[rb][r] = max(best2[rb][r], min(best[rb][r], key));
                     best[rb][r] = max(best[rb][r], key);
                 }
@@ -242,11 +246,11 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, c
             }
             const int row = wrow0 + rb * 16 + lg * 4 + r;
             if (li == 0 && row < na) {
-                pb.nn_idx[o + row] = k0 >= 0 ? 65535 - (k0 & 0xffff) : -1;
-                pb.nn_dist[o + row] = k0 >= 0 ? (512 - (k0 >> 16)) >> 1 : INT_MAX;
+                pb.nn_idx[o + row] = k0 >= 0 ? MM_S - 1 - k0 % MM_S : -1;
+                pb.nn_dist[o + row] = k0 >= 0 ? (512 - k0 / MM_S) >> 1 : INT_MAX;
                 if (KNN2) {
-                    pb.nn_idx2[o2 + row] = k1 >= 0 ? 65535 - (k1 & 0xffff) : -1;
-                    pb.nn_dist2[o2 + row] = k1 >= 0 ? (512 - (k1 >> 16)) >> 1 : INT_MAX;
+                    pb.nn_idx2[o2 + row] = k1 >= 0 ? MM_S - 1 - k1 % MM_S : -1;
+                    pb.nn_dist2[o2 + row] = k1 >= 0 ? (512 - k1 / MM_S) >> 1 : INT_MAX;
                 }
             }
         }

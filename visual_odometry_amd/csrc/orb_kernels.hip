@@ -1361,12 +1361,12 @@ void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom
 
 // ------------------------------------------------------------------ steered BRIEF (orb.cpp computeOrbDescriptors, WTA_K = 2)
 // One wavefront per keypoint; lane j evaluates tests j, 64 + j, 128 + j, 192 + j; each ballot is 64
-// descriptor bits (8 bytes, LSB first).  Also writes the exported keypoint record and the descriptor's +1 / -1
+// descriptor bits (8 bytes, LSB first).  Also writes the exported keypoint record and the descriptor's +127 / -127
 // byte image for the MFMA matcher (layout: vo_internal.h desc_x_rows; lane c < 16 expands bits 16c .. 16c + 15).
 __device__ __forceinline__ uint32_t brief_expand4(uint32_t nib)
 {
     const uint32_t m = (nib * 0x00204081u) & 0x01010101u;
-    return ~(m * 0xfeu);
+    return 0x81818181u ^ (m * 0xfeu);                          // 1 -> 0x7f (+127), 0 -> 0x81 (-127): match_kernels.hip expand4
 }
 
 // cos / sin of the keypoint angle, one LANE per keypoint (in k_brief the same double-precision calls would run once

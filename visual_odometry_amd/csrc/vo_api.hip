@@ -63,7 +63,7 @@ struct vo_ctx {
     bool ev_ready = false;
     hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
     bool ev_det_set = false;
-    int matcher_kernel = 0;               // 0: int8 MFMA on +1/-1 bytes (default), 1: XOR + popcount
+    int matcher_kernel = 0;               // 0: int8 MFMA on +127/-127 bytes (default), 1: XOR + popcount
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;          // RCCL communicator of the trajectory gather
     double *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0;
     int kp_order = 0;                     // 0: canonical (octave, y, x) keypoint order, 1: cv2's retainBest order
@@ -848,7 +848,8 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t
         StageTimer t(ctx, ST_MATCH_NN);
         const int cx = desc_x_rows(cap);
         const int dirs = select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3;
-        if (ctx->matcher_kernel == 1) {                          // XOR + popcount on the packed descriptors
+        // (the matrix-core kernel carries the column index inside its accumulator: fewer than 127^2 = 16129 rows per set)
+        if (ctx->matcher_kernel == 1 || cap >= 16129) {          // XOR + popcount on the packed descriptors
             if (select_mode == 3) launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, 1, 1);
             else launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, dirs, 0);
         } else if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1);
