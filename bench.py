@@ -144,7 +144,7 @@ def main():
                     help="pair view k with view k + stride: a wider baseline lowers the inlier ratio and multiplies the RANSAC rounds")
     ap.add_argument("--matcher", choices=["crosscheck", "ratio", "crosscheck-legacy"], default="crosscheck")
     ap.add_argument("--ratio", type=float, default=0.8)
-    ap.add_argument("--matcher-kernel", choices=["mfma", "popcount"], default="mfma",
+    ap.add_argument("--matcher-kernel", choices=["mfma_fp4", "mfma", "popcount"], default="mfma_fp4",
                     help="Hamming NN kernel: int8 MFMA over +1/-1 bytes (default) or XOR + popcount (same results)")
     ap.add_argument("--keypoint-order", choices=["canonical", "cv2"], default="canonical")
     ap.add_argument("--poly-solver", choices=["fast", "opencv300"], default="fast")

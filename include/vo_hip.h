@@ -65,9 +65,10 @@ int vo_orb_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int
                               float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
                               int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out);
 
-/* Which kernel computes the Hamming nearest neighbours (same results, bit for bit): 0 = int8 MFMA over +1/-1
- * byte descriptors (default, 3x faster), 1 = XOR + popcount on the packed descriptors (the formulation
- * BASELINE.json's north_star names). */
+/* Which kernel computes the Hamming nearest neighbours (same results, bit for bit): 2 = block-scaled FP4 MFMA over
+ * e2m1 +1/-1 descriptors (default; sets of 8192 rows or more fall back to 0), 0 = int8 MFMA over +127/-127 bytes
+ * (16129 rows or more fall back to 1), 1 = XOR + popcount on the packed descriptors (the formulation BASELINE.json's
+ * north_star names).  Choose before detecting: the detector writes the operand image of the selected kernel. */
 int vo_set_matcher_kernel(vo_ctx* ctx, int kind);
 
 /* Order of the keypoint list (and therefore of every keypoint / match index): 0 (default) = canonical (octave, y, x);

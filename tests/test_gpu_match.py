@@ -104,13 +104,15 @@ def test_extreme_descriptors(oracle, ctx):
                                                         oracle.knn2_ratio_hamming(q, t, 0.9)))
 
 
-def test_popcount_kernel_gives_the_same_matches(oracle):
-    """The XOR + popcount kernel (north_star's formulation) and the default MFMA kernel are interchangeable."""
+@pytest.mark.parametrize("kernel", ["popcount", "mfma"])
+def test_popcount_kernel_gives_the_same_matches(oracle, kernel):
+    """The XOR + popcount kernel (north_star's formulation), the int8 matrix-core kernel and the default FP4 one are
+    interchangeable."""
     from visual_odometry_amd import _lib
     from visual_odometry_amd.matcher import HammingMatcher
     c = _lib.Context(0)
     try:
-        c.set_matcher_kernel("popcount")
+        c.set_matcher_kernel(kernel)
         for nq, nt in ((2000, 2000), (513, 31), (17, 900), (1, 1)):
             t = _descs(nq + 5, nt)
             q = _descs(nt + 9, nq, dup_from=t, flip_bits=40)
@@ -121,6 +123,40 @@ def test_popcount_kernel_gives_the_same_matches(oracle):
             assert all(np.array_equal(a, b) for a, b in zip(m.ratio_match_arrays(q, t, 0.8), oracle.knn2_ratio_hamming(q, t, 0.8)))
         with pytest.raises(Exception):
             c.check(c.lib.vo_set_matcher_kernel(c.handle, 7))
+    finally:
+        c.close()
+
+
+def test_fp4_matrix_core_kernel_gives_the_same_matches(oracle, seq_small):
+    """The block-scaled FP4 form (v_mfma_scale_f32_16x16x128_f8f6f4, index carried in the FP32 accumulator) against the oracle:
+    all modes, tile / stage / workgroup remainders, exact ties, and whole pairs through the batched path."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    from visual_odometry_amd.matcher import HammingMatcher
+    c = _lib.Context(0)
+    try:
+        c.set_matcher_kernel("mfma_fp4")
+        for nq, nt in ((2000, 2000), (2256, 2255), (513, 31), (17, 900), (1, 1), (64, 65), (1000, 15), (16, 16)):
+            t = _descs(nq + 5, nt)
+            q = _descs(nt + 9, nq, dup_from=t, flip_bits=40)
+            for mode in (0, 1, 2):
+                m = HammingMatcher(crossCheck=mode > 0, legacy_crosscheck=mode == 1, ctx=c)
+                assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, mode))), (nq, nt, mode)
+            m = HammingMatcher(ctx=c)
+            assert all(np.array_equal(a, b) for a, b in zip(m.ratio_match_arrays(q, t, 0.8), oracle.knn2_ratio_hamming(q, t, 0.8)))
+        z = np.zeros((40, 32), np.uint8); o = np.full((33, 32), 255, np.uint8)           # distances 0 and 256, every row a tie
+        for q, t in ((z, z), (z, o), (o, z)):
+            m = HammingMatcher(crossCheck=True, ctx=c)
+            assert all(np.array_equal(a, b) for a, b in zip(m.match_arrays(q, t), oracle.match_hamming(q, t, 2)))
+        frames, K = seq_small["frames"], seq_small["K"]
+        fe = FrontEnd(480, 640, max_frames=3, max_pairs=2, nfeatures=500, ctx=c)
+        fe.upload(frames[:3]); fe.detect(0, 3)
+        res = fe.run_pairs([[0, 1], [1, 2]], K)[0]
+        p = oracle.orb_params(nfeatures=500)
+        for i in range(2):
+            r = oracle.pair(frames[i], frames[i + 1], p, K, want_points=False)
+            assert (int(res["n_match"][i]), int(res["n_inl"][i])) == (r["n_match"], r["n_inl"])
+            assert np.allclose(res["R"][i].reshape(3, 3), r["R"], rtol=0, atol=1e-6)   # (the default root finder vs the oracle's 300 sweeps)
     finally:
         c.close()
 

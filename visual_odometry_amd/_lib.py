@@ -157,8 +157,9 @@ class Context:
             pass
 
     def set_matcher_kernel(self, kind):
-        """'mfma' (default) or 'popcount': which kernel computes the Hamming nearest neighbours (same results)."""
-        self.check(self.lib.vo_set_matcher_kernel(self.handle, {"mfma": 0, "popcount": 1}[kind]))
+        """'mfma_fp4' (default: block-scaled FP4 matrix cores), 'mfma' (int8 matrix cores) or 'popcount': which kernel computes
+        the Hamming nearest neighbours (same results).  Choose before detecting."""
+        self.check(self.lib.vo_set_matcher_kernel(self.handle, {"mfma": 0, "popcount": 1, "mfma_fp4": 2}[kind]))
 
     # ---- multi-GPU: the trajectory gather over RCCL (one communicator per context)
     def comm_unique_id(self) -> bytes:

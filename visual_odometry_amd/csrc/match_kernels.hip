@@ -122,10 +122,29 @@ __device__ __forceinline__ uint32_t expand4(uint32_t nib)
     return 0x81818181u ^ (m * 0xfeu);                          // 1 -> 0x7f (+127), 0 -> 0x81 (-127)
 }
 
-__global__ __launch_bounds__(256) void k_desc_expand(const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x)
+// FP4 (e2m1) image for the block-scaled matrix-core form: bit 1 -> +1.0 (0x2), bit 0 -> -1.0 (0xA), eight bits -> one dword
+__device__ __forceinline__ uint32_t expand8_fp4(uint32_t b)
+{
+    uint32_t w = (b | (b << 12)) & 0x000F000Fu;               // bit i -> bit 4 i in three shift-or-mask steps
+    w = (w | (w << 6)) & 0x03030303u;
+    w = (w | (w << 3)) & 0x11111111u;
+    return 0xAAAAAAAAu ^ (w << 3);
+}
+
+// FP4 layout: [frame (stride cap_x * 256 B)][group = row / 16][chunk 0..7 = 32 descriptor bits][row % 16][16 B]
+__global__ __launch_bounds__(256) void k_desc_expand(const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int fp4)
 {
     const int f = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;              // t = (group * 16 + chunk) * 16 + row % 16
+    if (fp4) {
+        if (t >= cap_x * 8) return;
+        const int i = t & 15, c = (t >> 4) & 7, row = (t >> 7) * 16 + i;
+        uint32_t bits = 0;
+        if (row < min(kp_count[f], kp_cap)) bits = *(const uint32_t*)(desc + ((size_t)f * kp_cap + row) * 32 + 4 * c);
+        const uint4 o = make_uint4(expand8_fp4(bits & 255u), expand8_fp4((bits >> 8) & 255u), expand8_fp4((bits >> 16) & 255u), expand8_fp4(bits >> 24));
+        *(uint4*)(desc_x + ((size_t)f * cap_x * 16 + t) * 16) = o;
+        return;
+    }
     if (t >= cap_x * 16) return;
     const int i = t & 15, c = (t >> 4) & 15, row = (t >> 8) * 16 + i;
     uint32_t bits = 0;
@@ -134,10 +153,10 @@ __global__ __launch_bounds__(256) void k_desc_expand(const uint8_t* desc, const 
     *(uint4*)(desc_x + ((size_t)f * cap_x * 16 + t) * 16) = o;
 }
 
-void launch_desc_expand(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int F)
+void launch_desc_expand(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int F, int fp4)
 {
     if (F <= 0) return;
-    hipLaunchKernelGGL(k_desc_expand, dim3((cap_x * 16 + 255) / 256, F), dim3(256), 0, s, desc, kp_count, kp_cap, cap_x, desc_x);
+    hipLaunchKernelGGL(k_desc_expand, dim3((cap_x * 16 + 255) / 256, F), dim3(256), 0, s, desc, kp_count, kp_cap, cap_x, desc_x, fp4);
 }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -256,13 +275,131 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_mfma(const uint8_t* desc_x, c
         }
 }
 
+// The same search on the BLOCK-SCALED FP4 matrix-core form (v_mfma_scale_f32_16x16x128_f8f6f4, gfx950 only): descriptor
+// bits as e2m1 +1.0 / -1.0, K = 128 per instruction — half the instructions, half the operand bytes (128 B per
+// descriptor) of the int8 form, at the same cycles per instruction.  Operand layout (tools/ubench/mfma_fp4_probe.hip):
+// lane l holds row / column l & 15 and k = 32 (l >> 4) + n, nibble n of its first four dwords, low nibble first.
+// The block scale of A is 2^13 (E8M0 140), so the FP32 accumulator holds S (dot + 256) + (S - 1 - j) with S = 8192
+// exactly (all values < 2^22), started from the column's index term like the int8 form; one v_max_f32 per distance.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define MF_S 8192
+#ifndef MF_STAGE_ROWS
+#define MF_STAGE_ROWS 128                 // rows of B per LDS stage (8 groups of 16, 16 KB), double buffered
+#endif                                    // (64 / 128 / 256 rows: 0.220 / 0.214 / 0.215 ms per 256 pairs)
+#define MF_LD (MF_STAGE_ROWS * 128 / 16 / MM_THREADS)   // 16-byte staging loads per thread and stage
+template <bool KNN2>
+__global__ __launch_bounds__(MM_THREADS) void k_nn_fp4(const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x,
+                                                PairBuf pb, int dir_first, int row_blocks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[2][MF_STAGE_ROWS * 128];
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int p = bid / row_blocks, dir = dir_first + blockIdx.z;
+    const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
+    const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
+    const int row0 = (bid % row_blocks) * MM_BLOCK_ROWS;
+    if (row0 >= na) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const uint8_t* A = desc_x + (size_t)fa * cap_x * 256;
+    const uint8_t* B = desc_x + (size_t)fb * cap_x * 256;
+    const int wrow0 = row0 + wave * MM_WAVE_ROWS;
+
+    v8i a[MM_RB][2];
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const v4i v = wrow0 < na ? *(const v4i*)(A + ((size_t)((wrow0 >> 4) + rb) * 8 + 4 * s + lg) * 256 + li * 16) : (v4i){0, 0, 0, 0};
+            a[rb][s] = __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1);   // FP4 reads the low four dwords only
+        }
+    const float c_bad = -1.0e9f;
+    const float c_lane = (float)(MF_S * 256 + (MF_S - 1) - li);
+    // keys are compared as the INTEGER patterns of the accumulator floats: non-negative floats order like their bits, every
+    // invalid key is a negative float = a negative integer, and v_max_i32 needs no NaN canonicalisation (fmaxf costs three)
+    v4i best[MM_RB], best2[MM_RB];
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++) { best[rb] = (v4i){INT_MIN, INT_MIN, INT_MIN, INT_MIN}; best2[rb] = best[rb]; }
+
+    const int nstages = (nb + MF_STAGE_ROWS - 1) / MF_STAGE_ROWS;
+    const bool active = wrow0 < na;
+#define MF_GLDS(stage, buf)                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < MF_LD; q++)                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)(stage) * (MF_STAGE_ROWS * 128) + (size_t)(q * MM_THREADS + tid) * 16), \
+                                         (__attribute__((address_space(3))) void*)(s_b[buf] + (q * MM_THREADS + wave * 64) * 16), 16, 0, 0)
+    if (nstages > 0) { MF_GLDS(0, 0); }
+    for (int sg = 0; sg < nstages; sg++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (sg + 1 < nstages) { MF_GLDS(sg + 1, (sg + 1) & 1); }
+        const uint8_t* sb = s_b[sg & 1];
+        const int ng = active ? min(MF_STAGE_ROWS / 16, (nb - sg * MF_STAGE_ROWS + 15) >> 4) : 0;
+        for (int g = 0; g < ng; g++) {
+            const int j0 = sg * MF_STAGE_ROWS + g * 16;
+            float c0 = c_lane - (float)j0;
+            if (j0 + 16 > nb && j0 + li >= nb) c0 = c_bad;
+            const v4f cin = {c0, c0, c0, c0};
+            v8i b[2];
+            v4f acc[MM_RB];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const v4i v = *(const v4i*)(sb + g * 2048 + (4 * s + lg) * 256 + li * 16);
+                b[s] = __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1);
+            }
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[rb][0], b[0], cin, 4, 4, 0, 140, 0, 127);
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[rb][1], b[1], acc[rb], 4, 4, 0, 140, 0, 127);
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int key = __float_as_int(acc[rb][r]);
+                    if (KNN2) best2[rb][r] = max(best2[rb][r], min(best[rb][r], key));
+                    best[rb][r] = max(best[rb][r], key);
+                }
+        }
+    }
+#undef MF_GLDS
+
+    const size_t o = ((size_t)p * 2 + dir) * kp_cap, o2 = (size_t)p * kp_cap;
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int k0 = best[rb][r], k1 = best2[rb][r];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int u0 = __shfl_xor(k0, d, 64), u1 = __shfl_xor(k1, d, 64);
+                if (KNN2) k1 = max(max(k1, u1), min(k0, u0));
+                k0 = max(k0, u0);
+            }
+            const int row = wrow0 + rb * 16 + lg * 4 + r;
+            if (li == 0 && row < na) {
+                const int i0 = k0 >= 0 ? (int)__int_as_float(k0) : -1, i1 = k1 >= 0 ? (int)__int_as_float(k1) : -1;
+                pb.nn_idx[o + row] = i0 >= 0 ? MF_S - 1 - (i0 & (MF_S - 1)) : -1;
+                pb.nn_dist[o + row] = i0 >= 0 ? (512 - (i0 >> 13)) >> 1 : INT_MAX;
+                if (KNN2) {
+                    pb.nn_idx2[o2 + row] = i1 >= 0 ? MF_S - 1 - (i1 & (MF_S - 1)) : -1;
+                    pb.nn_dist2[o2 + row] = i1 >= 0 ? (512 - (i1 >> 13)) >> 1 : INT_MAX;
+                }
+            }
+        }
+}
+
 // dirs_mask: bit 0 = forward (frame1 -> frame2), bit 1 = reverse. knn2 applies to the forward direction.
 void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,
-                     int dirs_mask, int knn2)
+                     int dirs_mask, int knn2, int fp4)
 {
     if (P <= 0) return;
     dim3 block(MM_THREADS);
     const int gx = (kp_cap + MM_BLOCK_ROWS - 1) / MM_BLOCK_ROWS;
+    if (fp4) {
+        if (knn2) hipLaunchKernelGGL(k_nn_fp4<true>, dim3(gx * P, 1, 1), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 0, gx);
+        else if (dirs_mask == 3) hipLaunchKernelGGL(k_nn_fp4<false>, dim3(gx * P, 1, 2), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 0, gx);
+        else hipLaunchKernelGGL(k_nn_fp4<false>, dim3(gx * P, 1, 1), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, dirs_mask == 2 ? 1 : 0, gx);
+        return;
+    }
     if (knn2) {
         hipLaunchKernelGGL(k_nn_mfma<true>, dim3(gx * P, 1, 1), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 0, gx);
         return;

@@ -1369,6 +1369,14 @@ __device__ __forceinline__ uint32_t brief_expand4(uint32_t nib)
     return 0x81818181u ^ (m * 0xfeu);                          // 1 -> 0x7f (+127), 0 -> 0x81 (-127): match_kernels.hip expand4
 }
 
+__device__ __forceinline__ uint32_t brief_expand8_fp4(uint32_t b)       // bit 1 -> e2m1 +1.0 (0x2), bit 0 -> -1.0 (0xA)
+{
+    uint32_t w = (b | (b << 12)) & 0x000F000Fu;               // bit i -> bit 4 i in three shift-or-mask steps
+    w = (w | (w << 6)) & 0x03030303u;
+    w = (w | (w << 3)) & 0x11111111u;
+    return 0xAAAAAAAAu ^ (w << 3);
+}
+
 // cos / sin of the keypoint angle, one LANE per keypoint (in k_brief the same double-precision calls would run once
 // per wavefront, 64 lanes wide for one value).  Parked in kp_xy, which k_brief overwrites with the exported position.
 __global__ __launch_bounds__(256) void k_brief_trig(PyrGeom g, FrameFeat ff)
@@ -1389,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_brief_trig(PyrGeom g, FrameFeat ff)
 #ifndef BR_KPW
 #define BR_KPW 2                          // keypoints per wavefront: their record -> window -> gather chains overlap
 #endif
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff, uint8_t* desc_x, int cap_x, int blocks_per_frame)
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, FrameFeat ff, uint8_t* desc_x, int cap_x, int blocks_per_frame, int fp4)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][BR_KPW][BR_ROWS * 64];
     const int bid = xcd_tile(blockIdx.x, gridDim.x);          // a contiguous run of keypoints per XCD (see k_angle)
@@ -1455,7 +1463,14 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
             uint64_t wv8 = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
             *(uint64_t*)(ff.desc + ki * 32 + lane * 8) = wv8;
         }
-        if (lane < 16) {
+        if (fp4) {                                             // FP4 image (match_kernels.hip k_nn_fp4): lane c < 8 expands bits 32c .. 32c + 31
+            if (lane < 8) {
+                const uint64_t wv8 = lane < 2 ? words[0] : lane < 4 ? words[1] : lane < 6 ? words[2] : words[3];
+                const uint32_t bits = (uint32_t)(wv8 >> (32 * (lane & 1)));
+                const uint4 o = make_uint4(brief_expand8_fp4(bits & 255u), brief_expand8_fp4((bits >> 8) & 255u), brief_expand8_fp4((bits >> 16) & 255u), brief_expand8_fp4(bits >> 24));
+                *(uint4*)(desc_x + ((size_t)f * cap_x * 16 + (size_t)(k & ~15) * 8 + (size_t)lane * 16 + (k & 15)) * 16) = o;
+            }
+        } else if (lane < 16) {
             const uint64_t wv8 = lane < 4 ? words[0] : lane < 8 ? words[1] : lane < 12 ? words[2] : words[3];
             const uint32_t bits = (uint32_t)(wv8 >> (16 * (lane & 3))) & 0xffffu;
             const uint4 o = make_uint4(brief_expand4(bits & 15u), brief_expand4((bits >> 4) & 15u), brief_expand4((bits >> 8) & 15u), brief_expand4(bits >> 12));
@@ -1469,9 +1484,9 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
 }
 
 // desc_x: this launch's first frame, cap_x rows of 256 B per frame
-void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x)
+void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x, int fp4)
 {
     hipLaunchKernelGGL(k_brief_trig, dim3((g.kp_cap + 255) / 256, F), dim3(256), 0, s, g, ff);
     const int bpf = (g.kp_cap + 4 * BR_KPW - 1) / (4 * BR_KPW);
-    hipLaunchKernelGGL(k_brief, dim3(bpf * F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x, bpf);
+    hipLaunchKernelGGL(k_brief, dim3(bpf * F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x, bpf, fp4);
 }

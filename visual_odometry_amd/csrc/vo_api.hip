@@ -63,7 +63,7 @@ struct vo_ctx {
     bool ev_ready = false;
     hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
     bool ev_det_set = false;
-    int matcher_kernel = 0;               // 0: int8 MFMA on +127/-127 bytes (default), 1: XOR + popcount
+    int matcher_kernel = 2;               // 2: block-scaled FP4 MFMA (default), 0: int8 MFMA on +127/-127 bytes, 1: XOR + popcount
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;          // RCCL communicator of the trajectory gather
     double *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0;
     int kp_order = 0;                     // 0: canonical (octave, y, x) keypoint order, 1: cv2's retainBest order
@@ -354,10 +354,13 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     delete ctx;
 }
 
+// which image of the descriptors the matrix-core matcher reads: FP4 (block-scaled MFMA, fewer than 8192 rows per set) or int8
+static int matcher_fp4(const vo_ctx* ctx, int cap) { return ctx->matcher_kernel == 2 && cap < 8192; }   // else the int8 image
+
 extern "C" int vo_set_matcher_kernel(vo_ctx* ctx, int kind)
 {
     if (!ctx) return VO_ERR_INVALID;
-    if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "matcher kernel must be 0 (MFMA) or 1 (XOR + popcount)");
+    if (kind < 0 || kind > 2) FAIL(VO_ERR_INVALID, "matcher kernel must be 0 (int8 MFMA), 1 (XOR + popcount) or 2 (block-scaled FP4 MFMA)");
     ctx->matcher_kernel = kind;
     return VO_OK;
 }
@@ -614,7 +617,7 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     {
         StageTimer t(ctx, ST_BRIEF);
         const int cx = desc_x_rows(g.kp_cap);
-        launch_brief(s, blur, g, ff, F, ctx->desc_x + (size_t)first_slot * cx * 256, cx);
+        launch_brief(s, blur, g, ff, F, ctx->desc_x + (size_t)first_slot * cx * 256, cx, matcher_fp4(ctx, g.kp_cap));
     }
     return VO_OK;
 }
@@ -852,8 +855,8 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t
         if (ctx->matcher_kernel == 1 || cap >= 16129) {          // XOR + popcount on the packed descriptors
             if (select_mode == 3) launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, 1, 1);
             else launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, dirs, 0);
-        } else if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1);
-        else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, dirs, 0);
+        } else if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1, matcher_fp4(ctx, cap));
+        else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, dirs, 0, matcher_fp4(ctx, cap));
     }
     { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
     if (!do_geometry) return VO_OK;
@@ -1081,7 +1084,7 @@ static int match_raw(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, in
     HIPCHK(hipMemcpyAsync(ctx->raw_pb.slots, slots, sizeof(slots), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->dK, Kid, sizeof(Kid), hipMemcpyHostToDevice, s));
     RansacParams rp{};
-    { StageTimer tm(ctx, ST_BRIEF); launch_desc_expand(s, ctx->raw_desc, ctx->raw_count, cap, desc_x_rows(cap), ctx->raw_desc_x, 2); }
+    { StageTimer tm(ctx, ST_BRIEF); launch_desc_expand(s, ctx->raw_desc, ctx->raw_count, cap, desc_x_rows(cap), ctx->raw_desc_x, 2, matcher_fp4(ctx, cap)); }
     rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc, ctx->raw_desc_x, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false);
     if (rc) return rc;
     HIPCHK(hipGetLastError());

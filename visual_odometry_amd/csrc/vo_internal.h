@@ -231,7 +231,7 @@ void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, cons
                        double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status);
 void launch_rodrigues(hipStream_t s, const double* in, int in_is_matrix, double* out);
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F);
-void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x);
+void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x, int fp4);
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8, each with its own L2).  Neighbouring
 // work items share data (image tiles: halo rows and 128-byte lines; the row blocks of a pair: the other frame's
@@ -245,9 +245,9 @@ __device__ __forceinline__ int xcd_tile(int b, int n)
 
 // expanded descriptors: [frame][cap_x / 16][16 chunks][16 rows][16 B] of +1 / -1 bytes, cap_x = desc_x_rows(kp_cap)
 static inline int desc_x_rows(int kp_cap) { return (kp_cap + 255) & ~255; }
-void launch_desc_expand(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int F);
+void launch_desc_expand(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, int cap_x, uint8_t* desc_x, int F, int fp4);
 void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,
-                     int dirs_mask, int knn2);
+                     int dirs_mask, int knn2, int fp4);
 void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb, int P,
                               int dirs_mask, int knn2);
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
