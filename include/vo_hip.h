@@ -68,7 +68,8 @@ int vo_orb_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int
 /* Which kernel computes the Hamming nearest neighbours (same results, bit for bit): 2 = block-scaled FP4 MFMA over
  * e2m1 +1/-1 descriptors (default; sets of 8192 rows or more fall back to 0), 0 = int8 MFMA over +127/-127 bytes
  * (16129 rows or more fall back to 1), 1 = XOR + popcount on the packed descriptors (the formulation BASELINE.json's
- * north_star names).  Choose before detecting: the detector writes the operand image of the selected kernel. */
+ * north_star names).  The detector writes the operand image of the matrix-core kernel selected at that time and the
+ * matcher reads that image in its own format, so a change between 0 and 2 takes effect with the next detection. */
 int vo_set_matcher_kernel(vo_ctx* ctx, int kind);
 
 /* Order of the keypoint list (and therefore of every keypoint / match index): 0 (default) = canonical (octave, y, x);

@@ -181,3 +181,26 @@ def test_l2_matcher_bit_exact(oracle, ctx, dim, nq, nt):
     assert ms[0].distance == 0.0 and ms[0].trainIdx == 0 and all(a.queryIdx < b.queryIdx for a, b in zip(ms, ms[1:]))
     e = np.zeros((0, dim), np.float32)
     assert L2Matcher(ctx=ctx).match(e, t) == [] and L2Matcher(ctx=ctx).match(q, e) == []
+
+
+def test_matcher_kernel_switch_after_detection_stays_consistent(oracle, seq_small):
+    """The detector writes the operand image of the matrix-core kernel selected at that time; switching the kernel
+    afterwards must not make the matcher read that image in the other format."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    frames, K = seq_small["frames"], seq_small["K"]
+    c = _lib.Context(0)
+    try:
+        fe = FrontEnd(480, 640, max_frames=2, max_pairs=1, nfeatures=500, ctx=c)
+        p = oracle.orb_params(nfeatures=500)
+        d = [oracle.orb_detect_and_compute(frames[i], p)["desc"] for i in range(2)]
+        want = oracle.match_hamming(d[0], d[1], 2)
+        for first, then in (("mfma_fp4", "mfma"), ("mfma", "mfma_fp4"), ("mfma_fp4", "popcount"), ("popcount", "mfma_fp4")):
+            c.set_matcher_kernel(first)
+            fe.upload(frames[:2]); fe.detect(0, 2)
+            c.set_matcher_kernel(then)
+            fe.run_pairs([[0, 1]], K)
+            qi, ti, dd, _ = fe.pair_matches(0)
+            assert np.array_equal(qi, want[0]) and np.array_equal(ti, want[1]) and np.array_equal(dd, want[2]), (first, then)
+    finally:
+        c.close()

@@ -63,6 +63,7 @@ struct vo_ctx {
     bool ev_ready = false;
     hipEvent_t ev_det = nullptr;          // end of the most recent vo_frames_detect_async (vo_detect_after waits on it)
     bool ev_det_set = false;
+    int descx_fp4 = 0;                    // operand image the resident frames' desc_x currently holds (written at detection)
     int matcher_kernel = 2;               // 2: block-scaled FP4 MFMA (default), 0: int8 MFMA on +127/-127 bytes, 1: XOR + popcount
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;          // RCCL communicator of the trajectory gather
     double *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0;
@@ -617,7 +618,8 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     {
         StageTimer t(ctx, ST_BRIEF);
         const int cx = desc_x_rows(g.kp_cap);
-        launch_brief(s, blur, g, ff, F, ctx->desc_x + (size_t)first_slot * cx * 256, cx, matcher_fp4(ctx, g.kp_cap));
+        ctx->descx_fp4 = matcher_fp4(ctx, g.kp_cap);
+        launch_brief(s, blur, g, ff, F, ctx->desc_x + (size_t)first_slot * cx * 256, cx, ctx->descx_fp4);
     }
     return VO_OK;
 }
@@ -843,7 +845,7 @@ static int ensure_rng(vo_ctx* ctx, uint64_t seed)
 static int map_select_mode(int match_mode) { return match_mode == 0 ? 2 : match_mode == 2 ? 1 : 3; }
 
 static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t* desc_x, const float* kp_xy, const int* kp_count, int cap,
-                     int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points)
+                     int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points, int descx_fp4)
 {
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemsetAsync(pb.res, 0, (size_t)P * sizeof(vo_pair_result), s));
@@ -855,8 +857,8 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t
         if (ctx->matcher_kernel == 1 || cap >= 16129) {          // XOR + popcount on the packed descriptors
             if (select_mode == 3) launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, 1, 1);
             else launch_match_nn_popcount(s, desc, kp_count, cap, pb, P, dirs, 0);
-        } else if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1, matcher_fp4(ctx, cap));
-        else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, dirs, 0, matcher_fp4(ctx, cap));
+        } else if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1, descx_fp4);   // the image that was written,
+        else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, dirs, 0, descx_fp4);                        // whatever the setter says now
     }
     { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
     if (!do_geometry) return VO_OK;
@@ -900,7 +902,7 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
     memcpy(rp.K, K, sizeof(rp.K));
     const bool wp = opts->want_points != 0;
     int rc = run_pairs(ctx, ctx->pb, ctx->ff.desc, ctx->desc_x, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
-                       map_select_mode(opts->match_mode), opts->ratio, rp, true, wp);
+                       map_select_mode(opts->match_mode), opts->ratio, rp, true, wp, ctx->descx_fp4);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results, ctx->pb.res, (size_t)B * sizeof(vo_pair_result), hipMemcpyDeviceToHost, s));
@@ -1085,7 +1087,7 @@ static int match_raw(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, in
     HIPCHK(hipMemcpyAsync(ctx->dK, Kid, sizeof(Kid), hipMemcpyHostToDevice, s));
     RansacParams rp{};
     { StageTimer tm(ctx, ST_BRIEF); launch_desc_expand(s, ctx->raw_desc, ctx->raw_count, cap, desc_x_rows(cap), ctx->raw_desc_x, 2, matcher_fp4(ctx, cap)); }
-    rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc, ctx->raw_desc_x, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false);
+    rc = run_pairs(ctx, ctx->raw_pb, ctx->raw_desc, ctx->raw_desc_x, ctx->raw_xy, ctx->raw_count, cap, 1, select_mode, ratio, rp, false, false, matcher_fp4(ctx, cap));
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     int n = 0;
