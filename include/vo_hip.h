@@ -256,10 +256,10 @@ int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels
  * (FrameGenerator.make_frame, src/frame_generator.py:25-26); its descriptors go to vo_match_l2 (visual_slam.py:19).
  * OpenCV 4.7's sift.dispatch.cpp / sift.simd.hpp stage for stage: doubled base image, Gaussian and DoG pyramids, scale-space
  * extrema with sub-pixel refinement, contrast and edge tests, orientation histograms, 4 x 4 x 8 descriptors (float, values
- * 0..255), keypoints in removeDuplicatedSorted's order, octave packed as cv2 packs it.  nfeatures must be 0 (cv2's
- * default: keep everything).  VO_WARN_CAPACITY: more than `cap` keypoints (n_out = the number found). */
+ * 0..255), keypoints in removeDuplicatedSorted's order, octave packed as cv2 packs it.  nfeatures > 0 applies
+ * KeyPointsFilter::retainBest (libstdc++'s nth_element + partition, ties kept) as cv2 does.  VO_WARN_CAPACITY: more than `cap` keypoints (n_out = the number found). */
 typedef struct {
-    int32_t nfeatures;            /* 0 */
+    int32_t nfeatures;            /* 0 = keep every keypoint */
     int32_t n_octave_layers;      /* 3 */
     double  contrast_threshold;   /* 0.04 */
     double  edge_threshold;       /* 10 */

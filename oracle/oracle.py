@@ -323,21 +323,21 @@ def sift_pyramid_image(gray, which, octave, layer, n_layers=3, sigma=1.6):
     return out.ravel()[:ow.value * oh.value].reshape(oh.value, ow.value).copy()
 
 
-def sift_detect_and_compute(img, n_layers=3, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6, cap=None):
+def sift_detect_and_compute(img, n_layers=3, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6, cap=None, nfeatures=0):
     """cv2.SIFT_create().detectAndCompute(img, None) -> dict(xy, size, angle, response, octave, desc [N, 128] float32)."""
     a = _u8(img)
     h, w = a.shape[:2]
     cn = 1 if a.ndim == 2 else a.shape[2]
     f = lib().voo_sift_detect_and_compute
-    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
     n = C.c_int32(0)
     if cap is None:
-        rc = f(a.ctypes.data, h, w, cn, a.strides[0], n_layers, contrast_threshold, edge_threshold, sigma, None, None, None, None, None, None, 0, C.addressof(n))
+        rc = f(a.ctypes.data, h, w, cn, a.strides[0], nfeatures, n_layers, contrast_threshold, edge_threshold, sigma, None, None, None, None, None, None, 0, C.addressof(n))
         assert rc == 0
         cap = n.value
     xy = np.zeros((cap, 2), np.float32); size = np.zeros(cap, np.float32); ang = np.zeros(cap, np.float32); resp = np.zeros(cap, np.float32)
     octv = np.zeros(cap, np.int32); desc = np.zeros((cap, 128), np.float32)
-    rc = f(a.ctypes.data, h, w, cn, a.strides[0], n_layers, contrast_threshold, edge_threshold, sigma, xy.ctypes.data, size.ctypes.data,
+    rc = f(a.ctypes.data, h, w, cn, a.strides[0], nfeatures, n_layers, contrast_threshold, edge_threshold, sigma, xy.ctypes.data, size.ctypes.data,
            ang.ctypes.data, resp.ctypes.data, octv.ctypes.data, desc.ctypes.data, cap, C.addressof(n))
     assert rc == 0
     k = min(n.value, cap)

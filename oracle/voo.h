@@ -122,7 +122,7 @@ int voo_sift_gauss_kernel(double sigma, float* k);
 float voo_cv_expf(float x);
 int voo_sift_pyramid_image(const uint8_t* gray, int h, int w, int nLayers, double sigma, int which /*0 Gaussian, 1 DoG*/, int o, int layer,
                            float* out, int32_t* ow, int32_t* oh);
-int voo_sift_detect_and_compute(const uint8_t* img, int h, int w, int channels, int row_stride, int nLayers, double contrastThreshold,
+int voo_sift_detect_and_compute(const uint8_t* img, int h, int w, int channels, int row_stride, int nfeatures, int nLayers, double contrastThreshold,
                                 double edgeThreshold, double sigma, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
                                 int32_t* kp_octave, float* desc /*cap x 128*/, int cap, int32_t* n_out);
 

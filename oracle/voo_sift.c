@@ -420,7 +420,7 @@ int voo_sift_pyramid_image(const uint8_t* gray, int h, int w, int nLayers, doubl
 
 /* cv2.SIFT_create(nfeatures = 0, nOctaveLayers, contrastThreshold, edgeThreshold, sigma).detectAndCompute(img, None).
  * Returns the number of keypoints found (n_out; at most cap are written). */
-int voo_sift_detect_and_compute(const uint8_t* img, int h, int w, int channels, int row_stride, int nLayers, double contrastThreshold,
+int voo_sift_detect_and_compute(const uint8_t* img, int h, int w, int channels, int row_stride, int nfeatures, int nLayers, double contrastThreshold,
                                 double edgeThreshold, double sigma, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
                                 int32_t* kp_octave, float* desc, int cap, int32_t* n_out)
 {
@@ -466,6 +466,17 @@ int voo_sift_detect_and_compute(const uint8_t* img, int h, int w, int channels, 
             if (a->x == b->x && a->y == b->y && a->size == b->size && a->angle == b->angle) continue;
         }
         idx[m++] = idx[i];
+    }
+    if (nfeatures > 0 && m > nfeatures) {                            /* KeyPointsFilter::retainBest(keypoints, nfeatures): libstdc++'s */
+        float* resp = (float*)malloc(sizeof(float) * (size_t)m);     /* nth_element + partition (voo_cv2order.cpp) on the sorted list */
+        int32_t* ord = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
+        int* idx2 = (int*)malloc(sizeof(int) * (size_t)m);
+        for (int i = 0; i < m; i++) resp[i] = kps.v[idx[i]].response;
+        const int keep = voo_retain_best_cv2(resp, m, nfeatures, ord);
+        for (int i = 0; i < keep; i++) idx2[i] = idx[ord[i]];
+        memcpy(idx, idx2, sizeof(int) * (size_t)keep);
+        m = keep;
+        free(resp); free(ord); free(idx2);
     }
     const int per = nLayers + 3;
     for (int i = 0; i < m; i++) {

@@ -14,7 +14,7 @@ def _check(oracle, ctx, img, **kw):
     det = SiftDetector(ctx=ctx, **kw)
     got = det.detect_arrays(img)
     want = oracle.sift_detect_and_compute(img, n_layers=kw.get("nOctaveLayers", 3), contrast_threshold=kw.get("contrastThreshold", 0.04),
-                                          edge_threshold=kw.get("edgeThreshold", 10.0), sigma=kw.get("sigma", 1.6))
+                                          edge_threshold=kw.get("edgeThreshold", 10.0), sigma=kw.get("sigma", 1.6), nfeatures=kw.get("nfeatures", 0))
     assert len(got["xy"]) == want["n_found"] and want["n_found"] > 0
     for key in ("xy", "size", "angle", "response", "octave"):
         assert np.array_equal(got[key], want[key]), key
@@ -47,6 +47,9 @@ def test_sift_colour_input_and_parameters(oracle, ctx):
     _check(oracle, ctx, bgr)
     _check(oracle, ctx, g, nOctaveLayers=4, contrastThreshold=0.03, edgeThreshold=8, sigma=1.4)
     _check(oracle, ctx, g, nOctaveLayers=2)
+    for nf in (1, 50, 400, 100000):                                       # retainBest: cv2's permutation of the sorted list, ties kept
+        got = _check(oracle, ctx, g, nfeatures=nf)
+        assert len(got["xy"]) >= min(nf, 1)
 
 
 def test_sift_smooth_and_flat_images(oracle, ctx):

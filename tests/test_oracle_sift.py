@@ -136,3 +136,20 @@ def test_sift_golden(oracle):
     for k in ("xy", "size", "angle", "response", "octave"):
         assert np.array_equal(r[k], g[k]), k
     assert np.array_equal(r["desc"].astype(np.uint8), g["desc"])
+
+
+def test_nfeatures_is_retain_best(oracle):
+    """nfeatures > 0: KeyPointsFilter::retainBest on the sorted list — the kept SET is everything at or above the n-th largest
+    response (ties kept), in the permutation libstdc++'s nth_element + partition leave (voo_retain_best_cv2 on the responses)."""
+    img = random_image(8, 120, 160)
+    full = oracle.sift_detect_and_compute(img)
+    for nf in (1, 37, 200, full["n_found"], full["n_found"] + 5):
+        r = oracle.sift_detect_and_compute(img, nfeatures=nf)
+        if nf >= full["n_found"]:
+            assert r["n_found"] == full["n_found"] and np.array_equal(r["xy"], full["xy"]); continue
+        thr = np.sort(full["response"])[::-1][nf - 1]
+        keep = np.nonzero(full["response"] >= thr)[0]
+        order = oracle.retain_best_cv2(full["response"], nf)
+        assert sorted(order.tolist()) == keep.tolist() and r["n_found"] == len(order)
+        for k in ("xy", "size", "angle", "response", "octave", "desc"):
+            assert np.array_equal(r[k], full[k][order]), k

@@ -1687,8 +1687,8 @@ extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h
     if (!p) p = &def;
     if (!img || !n_out || h < 2 || w < 2 || (channels != 1 && channels != 3 && channels != 4) || row_stride < w * channels || cap < 0)
         FAIL(VO_ERR_INVALID, "bad arguments");
-    if (p->n_octave_layers < 1 || p->n_octave_layers > 8 || !(p->sigma > 0.5) || p->nfeatures != 0)
-        FAIL(VO_ERR_UNSUPPORTED, "SIFT: nOctaveLayers 1..8, sigma > 0.5 and nfeatures = 0 (keep every keypoint) are built");
+    if (p->n_octave_layers < 1 || p->n_octave_layers > 8 || !(p->sigma > 0.5) || p->nfeatures < 0)
+        FAIL(VO_ERR_UNSUPPORTED, "SIFT: nOctaveLayers 1..8, sigma > 0.5 and nfeatures >= 0 are built");
     HIPCHK(hipSetDevice(ctx->device));
     const int L = p->n_octave_layers, per = L + 3;
     SiftPyr P; memset(&P, 0, sizeof(P));
@@ -1779,6 +1779,15 @@ extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h
     for (int i = 0; i < nk; i++) {
         if (m > 0 && kps[i].x == kps[m - 1].x && kps[i].y == kps[m - 1].y && kps[i].size == kps[m - 1].size && kps[i].angle == kps[m - 1].angle) continue;
         kps[m++] = kps[i];
+    }
+    if (p->nfeatures > 0 && m > p->nfeatures) {
+        // KeyPointsFilter::retainBest(keypoints, nfeatures): literally what cv2 runs — libstdc++'s nth_element on the response,
+        // then every tie with the n-th response kept by partition; the list stays in that permutation
+        auto greater = [](const SiftKp& a, const SiftKp& b) { return a.response > b.response; };
+        std::nth_element(kps.begin(), kps.begin() + p->nfeatures - 1, kps.begin() + m, greater);
+        const float amb = kps[(size_t)p->nfeatures - 1].response;
+        auto new_end = std::partition(kps.begin() + p->nfeatures, kps.begin() + m, [amb](const SiftKp& k) { return k.response >= amb; });
+        m = (int)(new_end - kps.begin());
     }
     for (int i = 0; i < m; i++) {                                 // firstOctave = -1: back to the coordinates of the input image
         kps[i].octave = (kps[i].octave & ~255) | ((kps[i].octave - 1) & 255);

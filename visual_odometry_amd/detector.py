@@ -116,9 +116,7 @@ class SiftDetector:
     cv2 returns them, .octave packed as cv2 packs it (octave | layer << 8 | round((xi + 0.5) * 255) << 16)."""
 
     def __init__(self, nfeatures=0, nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6, ctx: _lib.Context | None = None):
-        if nfeatures != 0:
-            raise NotImplementedError("nfeatures > 0 (retainBest on the SIFT keypoints) is not built; cv2's default 0 keeps every keypoint")
-        self.params = _lib.SiftParams(0, int(nOctaveLayers), float(contrastThreshold), float(edgeThreshold), float(sigma))
+        self.params = _lib.SiftParams(int(nfeatures), int(nOctaveLayers), float(contrastThreshold), float(edgeThreshold), float(sigma))
         self._ctx = ctx
         self.truncated = False
 
