@@ -607,7 +607,7 @@ __device__ __forceinline__ int count_inliers(const double* E, const double* x1, 
 // (2) wave 0 solves the samples, one per lane, elimination matrices in LDS; (3) the models
 // are scored four at a time (one per wave, ballot + popcount over the correspondences) and consumed strictly
 // in OpenCV's order, so the adaptive iteration count and the strict `>` rule behave as in the serial loop.
-#define RS_STREAM 256
+#define RS_STREAM 512                     // RNG numbers staged per round (64 subsets x 5 + rejections)
 #define RS_ROUND FP_LANES
 
 struct RansacShared {
@@ -667,33 +667,51 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
     double* gmodels = pb.models + (size_t)p * 64 * 90;
     for (int r0 = 0; r0 < niters; r0 += RS_ROUND) {
         const int nh = min(RS_ROUND, niters - r0);
-        // (1) sample indices
+        // (1) sample indices.  Subset h starts where subset h - 1 stopped in the RNG stream, and a subset that draws an
+        //     index twice uses extra numbers; that happens in well under 1 % of the subsets, so the 64 lanes of wave 0 draw
+        //     their subsets in parallel from assumed start positions (5 numbers per earlier subset), a prefix sum of the
+        //     numbers actually used gives the true starts, and the lanes repeat until the starts stop moving (one or two
+        //     passes; each pass fixes at least the first lane that was wrong, so it ends).
         for (int i = tid; i < RS_STREAM; i += 256) sh.stream[i] = pos + i < rng_n ? rng_tab[pos + i] % (uint32_t)M : 0u;
         __syncthreads();
-        if (tid == 0) {
-            int used = 0;
-            for (int h = 0; h < nh; h++) {
+        if (wave == 0) {
+            int start = 5 * lane, used = 5;
+            for (;;) {
                 int idx[5];
-                for (int i = 0; i < 5; i++) {
-                    int v; bool dup;
-                    do {
-                        if (used < RS_STREAM && pos + used < rng_n) v = (int)sh.stream[used];
-                        else {                              // beyond the staged window / table: recompute directly
-                            uint64_t st = rp.seed ? rp.seed : 0xffffffffULL;
-                            uint32_t x = 0;
-                            if (pos + used < rng_n) x = rng_tab[pos + used];
-                            else { for (int q = 0; q <= pos + used; q++) x = rng_next(st); }
-                            v = (int)(x % (uint32_t)M);
-                        }
-                        used++;
-                        dup = false;
-                        for (int k = 0; k < i; k++) dup |= idx[k] == v;
-                    } while (dup);
-                    idx[i] = v;
-                    sh.sub[h][i] = v;
+                used = 0;
+                if (lane < nh) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        int v; bool dup;
+                        do {
+                            const int at = start + used;
+                            if (at < RS_STREAM && pos + at < rng_n) v = (int)sh.stream[at];
+                            else {                          // beyond the staged window / table: recompute directly
+                                uint64_t st = rp.seed ? rp.seed : 0xffffffffULL;
+                                uint32_t x = 0;
+                                if (pos + at < rng_n) x = rng_tab[pos + at];
+                                else { for (int q = 0; q <= pos + at; q++) x = rng_next(st); }
+                                v = (int)(x % (uint32_t)M);
+                            }
+                            used++;
+                            dup = false;
+#pragma unroll
+                            for (int k = 0; k < 5; k++) dup |= k < i && idx[k] == v;
+                        } while (dup);
+                        idx[i] = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; i++) sh.sub[lane][i] = idx[i];
                 }
+                int inc = used;                              // inclusive prefix of the numbers used
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+                const int true_start = inc - used;
+                const bool moved = lane < nh && true_start != start;
+                start = true_start;
+                if (lane == 63) sh.used = inc;
+                if (!__any(moved)) break;
             }
-            sh.used = used;
         }
         __syncthreads();
         pos += sh.used;
