@@ -609,6 +609,7 @@ __device__ __forceinline__ int count_inliers(const double* E, const double* x1, 
 // in OpenCV's order, so the adaptive iteration count and the strict `>` rule behave as in the serial loop.
 #define RS_STREAM 512                     // RNG numbers staged per round (64 subsets x 5 + rejections)
 #define RS_ROUND FP_LANES
+#define RS_SCORE_G 4                       // models a wave scores at once
 
 struct RansacShared {
     double cm[200 * FP_LANES];          // 102400 B
@@ -617,7 +618,7 @@ struct RansacShared {
     int nm[64];
     int off[65];
     uint8_t eh[640];
-    int cnt[2][4];
+    int cnt[4 * RS_SCORE_G];
     int used;
 };
 
@@ -744,23 +745,46 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
 #ifdef VO_EXP_TIMING
         if (r0 == 0) tC = clock64();
 #endif
-        // (3) score four models at a time, consume in order
+        // (3) score sixteen models per step — four per wave, interleaved in one pass over the correspondences (one load
+        //     of a point serves four models, and four independent error chains keep the wave's f64 pipe busy) — then
+        //     consume the sixteen counts strictly in OpenCV's order
         const int T = sh.off[64];
         bool done = false;
         int last_h = -1;
-        for (int b = 0; b * 4 < T && !done; b++) {
-            const int e = b * 4 + wave;
-            if (e < T) {
-                const int h = sh.eh[e], m = e - sh.off[h];
-                double E[9];
+        for (int b0 = 0; b0 < T && !done; b0 += 4 * RS_SCORE_G) {
+            {
+                double E[RS_SCORE_G][9];
+                int ne = 0;
 #pragma unroll
-                for (int k = 0; k < 9; k++) E[k] = gmodels[h * 90 + m * 9 + k];
-                const int good = count_inliers(E, x1, x2, M, t, lane, 64, 0, nullptr);
-                if (lane == 0) sh.cnt[b & 1][wave] = good;
+                for (int gq = 0; gq < RS_SCORE_G; gq++) {
+                    const int e = b0 + gq * 4 + wave;
+                    const int ee = e < T ? e : (b0 + wave < T ? b0 + wave : 0);      // a dummy model keeps the lanes uniform
+                    const int h = sh.eh[ee], m = ee - sh.off[h];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) E[gq][k] = gmodels[h * 90 + m * 9 + k];
+                    ne += e < T;
+                }
+                if (ne > 0) {
+                    int good[RS_SCORE_G];
+#pragma unroll
+                    for (int gq = 0; gq < RS_SCORE_G; gq++) good[gq] = 0;
+                    for (int base = 0; base < M; base += 64) {
+                        const int i = base + lane;
+                        const bool in = i < M;
+                        const double u1 = in ? x1[2 * i] : 0.0, v1 = in ? x1[2 * i + 1] : 0.0, u2 = in ? x2[2 * i] : 0.0, v2 = in ? x2[2 * i + 1] : 0.0;
+#pragma unroll
+                        for (int gq = 0; gq < RS_SCORE_G; gq++)
+                            good[gq] += (int)__popcll(__ballot(in && sampson_err(E[gq], u1, v1, u2, v2) <= t));
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int gq = 0; gq < RS_SCORE_G; gq++) sh.cnt[gq * 4 + wave] = good[gq];
+                    }
+                }
             }
             __syncthreads();
-            for (int w = 0; w < 4; w++) {
-                const int e2 = b * 4 + w;
+            for (int q = 0; q < 4 * RS_SCORE_G; q++) {
+                const int e2 = b0 + q;
                 if (e2 >= T) break;
                 const int h = sh.eh[e2];
                 if (h != last_h) {               // `iter < niters` is tested once per sample; all models of a sample
@@ -768,7 +792,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                     last_h = h;
                     iters_done = r0 + h + 1;
                 }
-                const int good = sh.cnt[b & 1][w];
+                const int good = sh.cnt[q];
                 if (good > max(max_good, 4)) {
                     const int m = e2 - sh.off[h];
 #pragma unroll
@@ -777,6 +801,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                     niters = ransac_update_num_iters(rp.prob, (double)(M - good) / M, 5, niters);
                 }
             }
+            __syncthreads();
         }
         if (!done) iters_done = min(r0 + nh, niters);
         __syncthreads();
