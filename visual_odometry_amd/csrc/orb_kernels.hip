@@ -40,6 +40,10 @@ __device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vo_s16x2, a), __builtin_bit_cast(vo_s16x2, b)));
 }
+__device__ __forceinline__ uint32_t pk_lshr16_8(uint32_t a)           // both 16-bit halves >> 8 (v_pk_lshrrev_b16)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(vo_u16x2, a) >> (unsigned short)8);
+}
 __device__ __forceinline__ uint32_t swap16(uint32_t a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 
 // ------------------------------------------------------------------ block-wide exclusive scan (<= 1024 threads)
@@ -575,8 +579,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
     __shared__ uint16_t s_q[FT_QCAP + 1];            // + one spare slot for the branch-free push
-    uint16_t* s_g = (uint16_t*)s_sc;                  // group queue of phase B; dead before the score tile is cleared
-    static_assert(FT_GROUPS_X * FT_SCH * 2 <= FT_SCH * FT_SCW, "the group queue fits the score tile");
+    static_assert(FT_GROUPS_X * FT_SCH * 4 <= FT_SCH * FT_SCW, "the group queue of phase B (dead before the score tile is cleared) fits the score tile");
     const int f = blockIdx.y, lane = threadIdx.x;
     const int bid = xcd_tile(blockIdx.x, g.ftiles_total);
     int l = 0;
@@ -623,78 +626,84 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = s_px[lane * 7]; return;
 #endif
 
-    // B. compass pre-test on the tile + 1 ring.  Lane = (row parity, column group of 4 pixels): the wave sweeps the
-    //    18 rows two at a time, every LDS address is the lane's base plus a compile-time offset (no index
-    //    arithmetic); two pixels per packed 16-bit operation.  Groups with a survivor go to the group queue (one
-    //    ballot per step), which phase B' turns into the pixel queue.
-    static_assert(FT_GROUPS_X <= 32 && FT_SCH % 2 == 0, "two rows of groups per wavefront step");
-    const uint32_t T2 = (uint32_t)t * 0x00010001u;
+    // B. compass pre-test on the tile + 1 ring.  Lane = (band of 13 score-tile rows, column group of 4 pixels): a lane sweeps
+    //    its band top to bottom, so the row three below the centre is the only new one per step — its even / odd pixels
+    //    are widened to 16-bit lanes once and serve as "below", centre and "above" of three different steps out of
+    //    registers.  Two pixels per packed 16-bit min / max; the comparisons against v + t / v - t are plain 32-bit
+    //    adds and subtracts (full issue rate) on halves biased by 0x7fff, whose bit 15 is the per-pixel answer.  Groups
+    //    with a survivor go to the group queue (one ballot per step), which phase B' turns into the pixel queue.
+    static_assert(FT_GROUPS_X <= 32 && FT_SCH % 2 == 0, "two bands of groups per wavefront");
+    constexpr int FB_ROWS = FT_SCH / 2;                // steps per band
+    const uint32_t T2 = (uint32_t)t * 0x00010001u, K1 = 0x7fff7fffu - T2;
     const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
     const bool edge_tile = x0 < 4 || x0 + FAST_TW + 4 > lv.w || y0 < 4 || y0 + FAST_TH + 4 > lv.h;
-    const int hp = lane >> 5, gc = lane & 31;
+    const int band = lane >> 5, gc = lane & 31;
+    // answer bits of pixel 0..3 of a group: 15, 7, 31, 23
     uint32_t colmask;                                  // pixels of this lane's group where a corner is possible / needed
     if (edge_tile) {
         const int gx0 = x0 - 4 + 4 * gc;
         const int lo_b = max(xlo - gx0, 0), hi_b = min(xhi - gx0, 3);
-        colmask = hi_b >= lo_b ? ((2u << hi_b) - 1u) & ~((1u << lo_b) - 1u) : 0u;
+        colmask = (lo_b <= 0 && hi_b >= 0 ? 0x00008000u : 0u) | (lo_b <= 1 && hi_b >= 1 ? 0x00000080u : 0u) |
+                  (lo_b <= 2 && hi_b >= 2 ? 0x80000000u : 0u) | (lo_b <= 3 && hi_b >= 3 ? 0x00800000u : 0u);
     } else {
-        colmask = gc == 0 ? 8u : gc == FT_GROUPS_X - 1 ? 1u : 15u;          // ring columns x0-1 and x0+TW only
+        colmask = gc == 0 ? 0x00800000u : gc == FT_GROUPS_X - 1 ? 0x00008000u : 0x80808080u;   // ring columns x0-1 and x0+TW only
     }
     if (gc >= FT_GROUPS_X) colmask = 0;
-    const uint32_t* colp = (const uint32_t*)s_px + 3 + gc + hp * (FT_PXW / 4);   // dword of the group in pixel-tile row hp
-    uint32_t rowmask = 0xffffffffu;                    // bit st: this lane's row of step st can hold a corner
-    if (edge_tile) {
-        rowmask = 0;
-#pragma unroll
-        for (int st = 0; st < FT_SCH / 2; st++) {
-            const int gy = y0 - 1 + 2 * st + hp;
-            rowmask |= (gy >= 3 && gy < lv.h - 3) ? 1u << st : 0u;
-        }
-    }
-    const uint32_t entry0 = ((uint32_t)hp << 10) | ((uint32_t)gc << 4);
+    const uint32_t* colp = (const uint32_t*)s_px + 3 + gc + band * (FB_ROWS * (FT_PXW / 4));   // dword of the group, first pixel-tile row of the band
+    uint32_t* s_g32 = (uint32_t*)s_sc;
+    const uint32_t entry0 = (uint32_t)gc | ((uint32_t)(FB_ROWS * band) << 8);
     int gn = 0;                                        // wave-uniform group-queue length
+    uint32_t raw[FB_ROWS + 6], pe[FB_ROWS + 6], po[FB_ROWS + 6];     // band rows -3 .. +3 around the centres (compile-time indices)
 #pragma unroll
-    for (int st = 0; st < FT_SCH / 2; st++) {
-        const uint32_t* rowp = colp + (2 * st + 3) * (FT_PXW / 4);
-        const uint32_t c = rowp[0], wl = rowp[-1], wr = rowp[1];
-        const uint32_t up = rowp[-3 * (FT_PXW / 4)], dn = rowp[3 * (FT_PXW / 4)];
-        // even pixels (0, 2) / odd pixels (1, 3) widened to 16-bit lanes
-        const uint32_t c_e = c & 0x00ff00ffu, c_o = __builtin_amdgcn_perm(0u, c, 0x0c030c01u);      // bytes 1, 3 -> 16-bit lanes
-        const uint32_t hi_e = pk_add16(c_e, T2), hi_o = pk_add16(c_o, T2);
-        const uint32_t lo_e = pk_sub16(c_e, T2), lo_o = pk_sub16(c_o, T2);
-        // ring 0 (0,+3) and ring 8 (0,-3): aligned dwords; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
-        const uint32_t r0_e = dn & 0x00ff00ffu, r0_o = __builtin_amdgcn_perm(0u, dn, 0x0c030c01u);
-        const uint32_t r8_e = up & 0x00ff00ffu, r8_o = __builtin_amdgcn_perm(0u, up, 0x0c030c01u);
+    for (int j = 0; j < 6; j++) {
+        raw[j] = colp[j * (FT_PXW / 4)];
+        pe[j] = raw[j] & 0x00ff00ffu; po[j] = pk_lshr16_8(raw[j]);                                   // pixels 0, 2 / 1, 3 -> 16-bit lanes
+    }
+#pragma unroll
+    for (int st = 0; st < FB_ROWS; st++) {
+        const int j = st + 6, jc = st + 3;
+        raw[j] = colp[j * (FT_PXW / 4)];
+        pe[j] = raw[j] & 0x00ff00ffu; po[j] = pk_lshr16_8(raw[j]);
+        const uint32_t c = raw[jc], wl = colp[jc * (FT_PXW / 4) - 1], wr = colp[jc * (FT_PXW / 4) + 1];
+        const uint32_t c_e = pe[jc], c_o = po[jc];
+        // ring 0 (0,+3) and ring 8 (0,-3): the rows three below / above; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
+        const uint32_t r0_e = pe[j], r0_o = po[j], r8_e = pe[st], r8_o = po[st];
         const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, 0x0c050c03u), r4_o = __builtin_amdgcn_perm(wr, c, 0x0c060c04u);
         const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, 0x0c030c01u), r12_o = __builtin_amdgcn_perm(c, wl, 0x0c040c02u);
-        // two adjacent compass pixels both brighter than v + t  <=>  min(max(r0, r8), max(r4, r12)) > v + t, both darker
-        // <=> max(min(r0, r8), min(r4, r12)) < v - t; the sign bit of the packed difference is the per-pixel answer
-        const uint32_t br_e = pk_sub16(hi_e, pk_min16(pk_max16(r0_e, r8_e), pk_max16(r4_e, r12_e)));
-        const uint32_t br_o = pk_sub16(hi_o, pk_min16(pk_max16(r0_o, r8_o), pk_max16(r4_o, r12_o)));
-        const uint32_t dk_e = pk_sub16(pk_max16(pk_min16(r0_e, r8_e), pk_min16(r4_e, r12_e)), lo_e);
-        const uint32_t dk_o = pk_sub16(pk_max16(pk_min16(r0_o, r8_o), pk_min16(r4_o, r12_o)), lo_o);
-        // candidate bits: pixel 0 / 2 = bits 15 / 31 of the even word, pixel 1 / 3 of the odd word
-        const uint32_t tt = (((br_e | dk_e) & 0x80008000u) >> 15) | (((br_o | dk_o) & 0x80008000u) >> 14);
-        uint32_t bits = (tt | (tt >> 14)) & colmask & (uint32_t)((int32_t)(rowmask << (31 - st)) >> 31);
+        // two adjacent compass pixels both brighter than v + t  <=>  X = min(max(r0, r8), max(r4, r12)) > v + t, both darker
+        // <=> Y = max(min(r0, r8), min(r4, r12)) < v - t.  Per 16-bit half: 0x7fff - t + X - v has bit 15 set <=> X > v + t,
+        // 0x7fff - t + v - Y has it set <=> Y < v - t; no half borrows from or carries into its neighbour (|..| < 0x100).
+        const uint32_t X_e = pk_min16(pk_max16(r0_e, r8_e), pk_max16(r4_e, r12_e)), X_o = pk_min16(pk_max16(r0_o, r8_o), pk_max16(r4_o, r12_o));
+        const uint32_t Y_e = pk_max16(pk_min16(r0_e, r8_e), pk_min16(r4_e, r12_e)), Y_o = pk_max16(pk_min16(r0_o, r8_o), pk_min16(r4_o, r12_o));
+        const uint32_t br_e = (X_e + K1) - c_e, br_o = (X_o + K1) - c_o;
+        const uint32_t dk_e = (c_e + K1) - Y_e, dk_o = (c_o + K1) - Y_o;
+        // bytes 1 and 3 of the two words carry the answers (either polarity) in their top bits: gather them to bit 7 of
+        // each byte — pixel 1, 0, 3, 2 from byte 0 up
+        const uint32_t bits = __builtin_amdgcn_perm(br_e | dk_e, br_o | dk_o, 0x07030501u) & 0x80808080u & colmask;
         const unsigned long long m = __ballot(bits != 0);
         if (m) {                                                             // wave-uniform
-            const int slot = gn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (bits) s_g[slot] = (uint16_t)(entry0 + ((uint32_t)(2 * st) << 10) + bits);       // (row 2 st + hp) << 10 | gc << 4 | bits
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (bits) *(uint32_t*)((uint8_t*)s_g32 + ((slot << 2) + (uint32_t)(gn << 2))) = bits + entry0 + ((uint32_t)st << 8);   // answers | (score-tile row) << 8 | gc
             gn += (int)__popcll(m);
         }
     }
     __syncthreads();
 #if defined(FT_STOP_AFTER) && FT_STOP_AFTER == 2
-    if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = gn + s_g[0]; return;
+    if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = gn + s_g32[0]; return;
 #endif
-    // B'. group queue -> pixel queue (score-tile row, column relative to x0-4)
+    // B'. group queue -> pixel queue ((score-tile row) << 8 | column relative to x0-4)
     int qn = 0;                                       // wave-uniform queue length
     for (int e0 = 0; e0 < gn; e0 += 64) {
-        const uint32_t gq = e0 + lane < gn ? s_g[e0 + lane] : 0u;
-        const int entry = (int)(gq >> 10) * 256 + (int)((gq >> 4) & 63u) * 4;
+        uint32_t gq = e0 + lane < gn ? s_g32[e0 + lane] : 0u;
+        if (edge_tile) {                                                       // wave-uniform: rows that cannot hold a corner
+            const int gy = y0 - 1 + (int)((gq >> 8) & 31u);
+            gq = gy >= 3 && gy < lv.h - 3 ? gq : 0u;
+        }
+        const uint32_t entry = (gq & 0x1f00u) | ((gq & 31u) << 2);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const bool set = (gq >> i) & 1u;
+            constexpr uint32_t bpos[4] = {15, 7, 31, 23};
+            const bool set = (gq >> bpos[i]) & 1u;
             const unsigned long long m = __ballot(set);
             const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             s_q[set && slot < FT_QCAP ? slot : FT_QCAP] = (uint16_t)(entry + i);
