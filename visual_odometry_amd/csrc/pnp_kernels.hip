@@ -87,6 +87,84 @@ __device__ static void dp_jacobi_svd(double* At, int m, int n, double* W, double
     }
 }
 
+/* The same routine for the 12 x 12 eigen-problem of EPnP with its work arrays in LDS: element e of a lane's array is at
+ * w[e * DP_WS_LANES] (consecutive lanes -> consecutive banks).  Same operations in the same order as dp_jacobi_svd. */
+typedef __attribute__((address_space(3))) double dp_lds_double;
+#define DP_WS_LANES 64
+#define DP_WS_ELEMS (144 + 144 + 12)          /* At, Vt, W */
+__device__ static void dp_jacobi_svd12_lds(dp_lds_double* At, dp_lds_double* W, dp_lds_double* Vt)
+{
+    constexpr int m = 12, n = 12, L = DP_WS_LANES;
+    const double eps = DBL_EPSILON * 10;
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < m; k++) sd += At[(i * m + k) * L] * At[(i * m + k) * L];
+        W[i * L] = sd;
+#pragma unroll
+        for (int k = 0; k < n; k++) Vt[(i * n + k) * L] = 0;
+        Vt[(i * n + i) * L] = 1;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        int changed = 0;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                dp_lds_double *Ai = At + i * m * L, *Aj = At + j * m * L;
+                double ai[m], aj[m];
+#pragma unroll
+                for (int k = 0; k < m; k++) { ai[k] = Ai[k * L]; aj[k] = Aj[k * L]; }
+                double a = W[i * L], p = 0, b = W[j * L];
+#pragma unroll
+                for (int k = 0; k < m; k++) p += ai[k] * aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = dp_hypot(p, beta), c, s2;
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s2 = sqrt(delta / gamma);
+                    c = p / (gamma * s2 * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s2 = p / (gamma * c * 2);
+                }
+                a = b = 0;
+#pragma unroll
+                for (int k = 0; k < m; k++) {
+                    double t0 = c * ai[k] + s2 * aj[k];
+                    double t1 = -s2 * ai[k] + c * aj[k];
+                    Ai[k * L] = t0; Aj[k * L] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i * L] = a; W[j * L] = b;
+                changed = 1;
+                dp_lds_double *Vi = Vt + i * n * L, *Vj = Vt + j * n * L;
+#pragma unroll
+                for (int k = 0; k < n; k++) {
+                    const double vi = Vi[k * L], vj = Vj[k * L];
+                    double t0 = c * vi + s2 * vj;
+                    double t1 = -s2 * vi + c * vj;
+                    Vi[k * L] = t0; Vj[k * L] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < m; k++) sd += At[(i * m + k) * L] * At[(i * m + k) * L];
+        W[i * L] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j * L] < W[k * L]) j = k;
+        if (i != j) {
+            double t = W[i * L]; W[i * L] = W[j * L]; W[j * L] = t;
+            for (int k = 0; k < m; k++) { t = At[(i * m + k) * L]; At[(i * m + k) * L] = At[(j * m + k) * L]; At[(j * m + k) * L] = t; }
+            for (int k = 0; k < n; k++) { t = Vt[(i * n + k) * L]; Vt[(i * n + k) * L] = Vt[(j * n + k) * L]; Vt[(j * n + k) * L] = t; }
+        }
+    }
+}
+
 /* cvSolve(A, b, x, CV_SVD) for an m x n system, m >= n <= 5, m <= 6: SVD::backSubst with OpenCV's threshold */
 __device__ static void dp_svd_solve(const double* A, int m, int n, const double* b, double* x)
 {
@@ -219,7 +297,7 @@ __device__ static double dp_R_and_t(const double* v /*4 x 12, v[0] = smallest*/,
 }
 
 /* epnp::compute_pose for n <= DP_MAXN points: pws world points, us pixel coordinates */
-__device__ static void dp_epnp(const double* pws, const double* us, int n, dp_cam K, double* Rbest, double* tbest)
+__device__ static void dp_epnp(const double* pws, const double* us, int n, dp_cam K, double* Rbest, double* tbest, dp_lds_double* ws /* this lane's slice: element e at ws[e * DP_WS_LANES] */)
 {
     double cws[4][3];
     /* choose_control_points */
@@ -263,17 +341,17 @@ __device__ static void dp_epnp(const double* pws, const double* us, int n, dp_ca
             M2[3 * j] = 0.0; M2[3 * j + 1] = as[j] * K.fv; M2[3 * j + 2] = as[j] * (K.vc - us[2 * i + 1]);
         }
     }
-    double mtm[144], At[144], D[12], Vt[144];
+    dp_lds_double *At = ws, *Vt = ws + 144 * DP_WS_LANES, *D = ws + 288 * DP_WS_LANES;
     for (int r = 0; r < 12; r++)
         for (int c = 0; c < 12; c++) {
             double s = 0;
             for (int i = 0; i < 2 * n; i++) s += M[i * 12 + r] * M[i * 12 + c];
-            mtm[r * 12 + c] = s;
+            At[(c * 12 + r) * DP_WS_LANES] = s;            /* At = (M^T M)^T */
         }
-    for (int j = 0; j < 12; j++) for (int i = 0; i < 12; i++) At[j * 12 + i] = mtm[i * 12 + j];
-    dp_jacobi_svd(At, 12, 12, D, Vt);
+    dp_jacobi_svd12_lds(At, D, Vt);
     double v[4 * 12];                                      /* v[0] = smallest singular value's vector (ut + 12*11) ... */
-    for (int i = 0; i < 4; i++) memcpy(v + 12 * i, Vt + 12 * (11 - i), sizeof(double) * 12);
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 12; k++) v[12 * i + k] = Vt[(12 * (11 - i) + k) * DP_WS_LANES];
     /* compute_L_6x10, compute_rho */
     double l[60], rho[6];
     {
@@ -408,7 +486,7 @@ __device__ static int dp_update_num_iters(double p, double ep, int model_points,
 
 /* solvePnP(SOLVEPNP_EPNP) on the float32 sample: undistortPoints gives float32 normalised coordinates, which
  * epnp::init_points maps back to pixels in double */
-__device__ static void dp_minimal(const double* obj, const double* img, const int* idx, int n, dp_cam K, double* R, double* t)
+__device__ static void dp_minimal(const double* obj, const double* img, const int* idx, int n, dp_cam K, double* R, double* t, dp_lds_double* ws)
 {
     double pws[3 * DP_MAXN], us[2 * DP_MAXN];
     const double ifx = 1. / K.fu, ify = 1. / K.fv;
@@ -418,7 +496,7 @@ __device__ static void dp_minimal(const double* obj, const double* img, const in
         const float xn = (float)(((double)(float)img[2 * j] - K.uc) * ifx), yn = (float)(((double)(float)img[2 * j + 1] - K.vc) * ify);
         us[2 * i] = (double)xn * K.fu + K.uc; us[2 * i + 1] = (double)yn * K.fv + K.vc;
     }
-    dp_epnp(pws, us, n, K, R, t);
+    dp_epnp(pws, us, n, K, R, t, ws);
 }
 
 /* 3 x 3 rotation from an so(3) increment w: exp([w]x) (Rodrigues' formula) */
@@ -504,8 +582,12 @@ __device__ static int dp_count_inliers(const double* obj, const double* img, int
 #define PNP_STREAM 448
 struct PnpShared {
     double Rt[64][12];                  // hypotheses of the round
-    double red[DP_LANES][28];           // per-thread partial sums of the normal equations
+    union {
+        double red[DP_LANES][28];       // per-thread partial sums of the normal equations (refinement)
+        double ws[DP_WS_ELEMS * DP_WS_LANES];   // EPnP's 12 x 12 eigen-problem, one slice per lane (hypothesis rounds)
+    };
     double cand[12];                    // candidate (R, t) of the Levenberg-Marquardt step
+    double tot[28];                     // reduced normal equations
     uint32_t stream[PNP_STREAM];
     int sub[64][5];
     int cnt[2][4];
@@ -810,12 +892,16 @@ __device__ static int dq_solve(const double* obj, const double* img, dp_cam K, d
     return nb;
 }
 
-// sum of the 256 partials in thread order (the oracle's order); called by thread 0 after a barrier
-__device__ static void dp_reduce(const PnpShared& sh, double* tot)
+// sum of the 256 partials in thread order (the oracle's order), one of the 28 sums per thread: called by every thread
+// after the barrier that follows the writes of sh.red; ends with a barrier, after which sh.tot is valid
+__device__ static void dp_reduce(PnpShared& sh, int tid)
 {
-    for (int q = 0; q < 28; q++) tot[q] = 0;
-    for (int k = 0; k < DP_LANES; k++)
-        for (int q = 0; q < 28; q++) tot[q] += sh.red[k][q];
+    if (tid < 28) {
+        double a = 0;
+        for (int k = 0; k < DP_LANES; k++) a += sh.red[k][tid];
+        sh.tot[tid] = a;
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const double* img_all, const int* offsets, const double* Kd,
@@ -823,7 +909,8 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
                                                     const uint32_t* rng_tab, int rng_n,
                                                     double* rvec_out, double* tvec_out, uint8_t* mask_all, int* ninl_out, int* status_out)
 {
-    __shared__ PnpShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn_pnp[];   // 160 KB: more than the static limit
+    PnpShared& sh = *(PnpShared*)s_dyn_pnp;
     const int pb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int o0 = offsets[pb], n = offsets[pb + 1] - o0;
     const double* obj = obj_all + (size_t)o0 * 3; const double* img = img_all + (size_t)o0 * 2;
@@ -850,7 +937,7 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
     if (n == 5) {                       // model_points == npoints: one EPnP, every point an inlier
         if (tid == 0) {
             double R[9], t[3], r[3];
-            dp_minimal(obj, img, nullptr, 5, K, R, t);
+            dp_minimal(obj, img, nullptr, 5, K, R, t, (dp_lds_double*)sh.ws);
             dp_rodrigues_to_vec(R, r);
             for (int k = 0; k < 3; k++) { rvec_out[3 * pb + k] = r[k]; tvec_out[3 * pb + k] = t[k]; }
             status_out[pb] = VO_OK; ninl_out[pb] = 5;
@@ -868,30 +955,47 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
         const int nh = min(64, niters - r0);
         for (int i = tid; i < PNP_STREAM; i += 256) sh.stream[i] = pos + i < rng_n ? rng_tab[pos + i] % (uint32_t)n : 0u;
         __syncthreads();
-        if (tid == 0) {
-            int used = 0;
-            for (int h = 0; h < nh; h++) {
+        // subset h starts where subset h - 1 stopped in the RNG stream; a subset that draws an index twice uses extra
+        // numbers (rare), so the 64 lanes of wave 0 draw in parallel from assumed starts (5 numbers per earlier subset), a
+        // prefix sum of the numbers actually used gives the true starts, and the lanes repeat until the starts stop moving
+        if (wave == 0) {
+            int start = 5 * lane, used = 5;
+            for (;;) {
                 int idx[5];
-                for (int i = 0; i < 5; i++) {
-                    int v; bool dup;
-                    do {
-                        if (used < PNP_STREAM && pos + used < rng_n) v = (int)sh.stream[used];
-                        else {                              // beyond the staged window / table: recompute directly
-                            uint64_t st = seed ? seed : 0xffffffffULL;
-                            uint32_t x = 0;
-                            if (pos + used < rng_n) x = rng_tab[pos + used];
-                            else { for (int q = 0; q <= pos + used; q++) x = dp_rng_next(&st); }
-                            v = (int)(x % (uint32_t)n);
-                        }
-                        used++;
-                        dup = false;
-                        for (int k = 0; k < i; k++) dup |= idx[k] == v;
-                    } while (dup);
-                    idx[i] = v;
-                    sh.sub[h][i] = v;
+                used = 0;
+                if (lane < nh) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) {
+                        int v; bool dup;
+                        do {
+                            const int at = start + used;
+                            if (at < PNP_STREAM && pos + at < rng_n) v = (int)sh.stream[at];
+                            else {                          // beyond the staged window / table: recompute directly
+                                uint64_t st = seed ? seed : 0xffffffffULL;
+                                uint32_t x = 0;
+                                if (pos + at < rng_n) x = rng_tab[pos + at];
+                                else { for (int q = 0; q <= pos + at; q++) x = dp_rng_next(&st); }
+                                v = (int)(x % (uint32_t)n);
+                            }
+                            used++;
+                            dup = false;
+#pragma unroll
+                            for (int k = 0; k < 5; k++) dup |= k < i && idx[k] == v;
+                        } while (dup);
+                        idx[i] = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; i++) sh.sub[lane][i] = idx[i];
                 }
+                int inc = used;                              // inclusive prefix of the numbers used
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+                const int true_start = inc - used;
+                const bool moved = lane < nh && true_start != start;
+                start = true_start;
+                if (lane == 63) sh.used = inc;
+                if (!__any(moved)) break;
             }
-            sh.used = used;
         }
         __syncthreads();
         pos += sh.used;
@@ -900,13 +1004,16 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
 #pragma unroll
             for (int i = 0; i < 5; i++) idx[i] = sh.sub[lane][i];
             double R[9], t[3];
-            dp_minimal(obj, img, idx, 5, K, R, t);
+            dp_minimal(obj, img, idx, 5, K, R, t, (dp_lds_double*)sh.ws + lane);
 #pragma unroll
             for (int k = 0; k < 9; k++) sh.Rt[lane][k] = R[k];
 #pragma unroll
             for (int k = 0; k < 3; k++) sh.Rt[lane][9 + k] = t[k];
         }
         __syncthreads();
+#if defined(VO_PNP_STOP) && VO_PNP_STOP == 1
+        if (tid == 0) { status_out[pb] = VO_OK; ninl_out[pb] = (int)sh.Rt[0][0]; } return;
+#endif
         bool done = false;
         for (int b = 0; b * 4 < nh && !done; b++) {         // four hypotheses at a time, consumed in order
             const int h = b * 4 + wave;
@@ -940,6 +1047,9 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
     }
     dp_count_inliers(obj, img, n, bestRt, bestRt + 9, K, thr, tid, 256, mask);
     __syncthreads();                                        // the mask bytes are read back below (global, same workgroup)
+#if defined(VO_PNP_STOP) && VO_PNP_STOP == 2
+    if (tid == 0) { status_out[pb] = VO_OK; ninl_out[pb] = max_good; } return;
+#endif
 
     // solvePnP(SOLVEPNP_ITERATIVE) on the inliers: Levenberg-Marquardt on the pixel reprojection error
     double R[9], t[3];
@@ -958,10 +1068,11 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
         for (int q = 0; q < 28; q++) sh.red[tid][q] = acc[q];
         __syncthreads();
     };
-    double lambda = 1e-3, JtJ[36], Jte[6], cost = 0, tot[28];
+    double lambda = 1e-3, JtJ[36], Jte[6], cost = 0;
+    const double* tot = sh.tot;
     partials(R, t, 1);
+    dp_reduce(sh, tid);
     if (tid == 0) {
-        dp_reduce(sh, tot);
         cost = tot[0];
         int q = 7;
         for (int r = 0; r < 6; r++) { Jte[r] = tot[1 + r]; for (int s2 = r; s2 < 6; s2++) { JtJ[r * 6 + s2] = tot[q]; JtJ[s2 * 6 + r] = tot[q]; q++; } }
@@ -993,10 +1104,8 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
 #pragma unroll
         for (int k = 0; k < 3; k++) tn[k] = sh.cand[9 + k];
         partials(Rn, tn, 0);
-        if (tid == 0) {
-            dp_reduce(sh, tot);
-            sh.ctrl = tot[0] < cost ? 3 : 4;                // 3 = accepted
-        }
+        dp_reduce(sh, tid);
+        if (tid == 0) sh.ctrl = tot[0] < cost ? 3 : 4;      // 3 = accepted
         __syncthreads();
         const bool accepted = sh.ctrl == 3;
         __syncthreads();                                    // everyone has read the verdict before thread 0 reuses ctrl
@@ -1006,9 +1115,9 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
 #pragma unroll
             for (int k = 0; k < 3; k++) t[k] = tn[k];
             partials(R, t, 1);
+            dp_reduce(sh, tid);
             if (tid == 0) {
                 const double step = fabs(d[0]) + fabs(d[1]) + fabs(d[2]) + fabs(d[3]) + fabs(d[4]) + fabs(d[5]);
-                dp_reduce(sh, tot);
                 cost = tot[0];
                 int q = 7;
                 for (int r = 0; r < 6; r++) { Jte[r] = tot[1 + r]; for (int s2 = r; s2 < 6; s2++) { JtJ[r * 6 + s2] = tot[q]; JtJ[s2 * 6 + r] = tot[q]; q++; } }
@@ -1037,7 +1146,10 @@ void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, cons
                        double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status)
 {
     if (B <= 0) return;
-    hipLaunchKernelGGL(k_pnp_ransac, dim3(B), dim3(256), 0, s, obj, img, offsets, Kd, iterations, reproj_err, confidence, seed,
+    static_assert(sizeof(PnpShared) <= 160 * 1024, "one workgroup's LDS");
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_pnp_ransac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PnpShared)); attr = true; }
+    hipLaunchKernelGGL(k_pnp_ransac, dim3(B), dim3(256), sizeof(PnpShared), s, obj, img, offsets, Kd, iterations, reproj_err, confidence, seed,
                        rng_tab, rng_n, rvec, tvec, mask, ninl, status);
 }
 
