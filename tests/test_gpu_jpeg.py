@@ -122,6 +122,12 @@ def test_ingest_jpeg_equals_decode_resize_gray(oracle, ctx):
         o = oracle.orb_detect_and_compute(resized[k], p)
         f = fe.features(k)
         assert np.array_equal(f["desc"], o["desc"]) and np.array_equal(f["xy"], o["xy"]), k
+    # the same files packed back to back in page-locked memory (the DMA form of the call), also through decode_batch
+    from visual_odometry_amd import ingest
+    packed = ingest.PackedFiles(bufs)
+    assert len(packed) == 3 and bytes(packed.file(1)) == bufs[1]
+    assert np.array_equal(fe.ingest_jpeg(packed, want_resized=True), resized)
+    assert np.array_equal(ingest.decode_batch(packed, ctx), ingest.decode_batch(bufs, ctx))
 
 
 def test_corrupt_entropy_data_is_survived(oracle, ctx):

@@ -71,15 +71,16 @@ class FrontEnd:
         return out
 
     def ingest_jpeg(self, buffers, first_slot=0, want_resized=False):
-        """The reference's whole ingest (visual_slam.py:346-352) for JPEG files of one size: cv2.imread -> cv2.resize to this
+        """buffers: a sequence of bytes-like objects or an ingest.PackedFiles (files packed in page-locked memory).
+        The reference's whole ingest (visual_slam.py:346-352) for JPEG files of one size: cv2.imread -> cv2.resize to this
         front end's (w, h) -> gray into level 0 of the slots, all on the device (only the compressed bytes cross PCIe).
         Returns the resized B G R frames if want_resized (the reference keeps them as Frame.image)."""
-        bufs = [bytes(b) for b in buffers]
-        blob = np.frombuffer(b"".join(bufs), np.uint8)
-        offs = np.zeros(len(bufs) + 1, np.int64); offs[1:] = np.cumsum([len(b) for b in bufs])
-        out = np.empty((len(bufs), self.h, self.w, 3), np.uint8) if want_resized else None
+        from .ingest import _packed
+        blob, offs, _keep = _packed(buffers)                 # a PackedFiles (page-locked) goes over PCIe by DMA as it is
+        n = len(offs) - 1
+        out = np.empty((n, self.h, self.w, 3), np.uint8) if want_resized else None
         c = self.ctx
-        rc = c.lib.vo_frames_ingest_jpeg(c.handle, blob.ctypes.data, offs.ctypes.data, len(bufs), int(first_slot), _lib.ptr(out))
+        rc = c.lib.vo_frames_ingest_jpeg(c.handle, blob.ctypes.data, offs.ctypes.data, n, int(first_slot), _lib.ptr(out))
         if rc == _lib.VO_ERR_UNSUPPORTED:
             raise NotImplementedError(c.last_error())
         c.check(rc)

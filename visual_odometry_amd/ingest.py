@@ -89,17 +89,51 @@ def imread(filename, ctx=None):
     return imdecode(data, ctx)
 
 
-def decode_batch(buffers, ctx=None):
-    """Many JPEG files of ONE size -> [F, h, w, 3] uint8 (B G R) with one upload and one launch sequence."""
-    bufs = [bytes(b) for b in buffers]
-    if not bufs:
-        return np.empty((0, 0, 0, 3), np.uint8)
-    h, w = jpeg_info(bufs[0])[:2]
-    blob = np.frombuffer(b"".join(bufs), np.uint8)
+class PackedFiles:
+    """JPEG files laid back to back in ONE page-locked host buffer (vo_host_alloc): what vo_jpeg_decode_batch /
+    vo_frames_ingest_jpeg take, in memory the DMA engines read directly (a pageable blob is staged by the runtime at a
+    fraction of the PCIe rate).  Fill it from bytes objects (one memcpy per file) or let a reader write into
+    `blob[offsets[k]:offsets[k + 1]]` itself (file.readinto) and skip that copy too."""
+
+    def __init__(self, buffers=None, sizes=None):
+        if buffers is not None:
+            sizes = [len(b) for b in buffers]
+        self.offsets = np.zeros(len(sizes) + 1, np.int64)
+        self.offsets[1:] = np.cumsum(sizes)
+        self._hold = _lib.PinnedArray((int(self.offsets[-1]) + 16,), np.uint8)
+        self.blob = self._hold.array
+        if buffers is not None:
+            for k, b in enumerate(buffers):
+                self.blob[self.offsets[k]:self.offsets[k + 1]] = np.frombuffer(b, np.uint8)
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def file(self, k):
+        return self.blob[self.offsets[k]:self.offsets[k + 1]]
+
+
+def _packed(buffers):
+    """(blob, offsets, keep-alive) of a PackedFiles or of a sequence of bytes-like objects."""
+    if isinstance(buffers, PackedFiles):
+        return buffers.blob, buffers.offsets, buffers
+    bufs = [b if isinstance(b, (bytes, bytearray, memoryview)) else bytes(b) for b in buffers]
+    blob = np.frombuffer(b"".join(bufs), np.uint8) if bufs else np.zeros(0, np.uint8)
     offs = np.zeros(len(bufs) + 1, np.int64); offs[1:] = np.cumsum([len(b) for b in bufs])
-    out = np.empty((len(bufs), h, w, 3), np.uint8)
+    return blob, offs, bufs
+
+
+def decode_batch(buffers, ctx=None):
+    """Many JPEG files of ONE size (a sequence of bytes-like objects or a PackedFiles) -> [F, h, w, 3] uint8 (B G R) with
+    one upload and one launch sequence."""
+    blob, offs, _keep = _packed(buffers)
+    n = len(offs) - 1
+    if n == 0:
+        return np.empty((0, 0, 0, 3), np.uint8)
+    h, w = jpeg_info(blob[offs[0]:offs[1]])[:2]
+    out = np.empty((n, h, w, 3), np.uint8)
     ctx = ctx or _lib.default_context()
-    rc = ctx.lib.vo_jpeg_decode_batch(ctx.handle, blob.ctypes.data, offs.ctypes.data, len(bufs), out.ctypes.data, h, w)
+    rc = ctx.lib.vo_jpeg_decode_batch(ctx.handle, blob.ctypes.data, offs.ctypes.data, n, out.ctypes.data, h, w)
     if rc == _lib.VO_ERR_UNSUPPORTED:
         raise NotImplementedError(ctx.last_error())
     ctx.check(rc)
