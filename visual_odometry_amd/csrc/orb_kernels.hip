@@ -1346,19 +1346,22 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
     for (int r = 0; r < BL_ROWS_PER_LANE; r++) {
         const int gy = y0 + strip * BL_ROWS_PER_LANE + r;
         const int p0 = r >> 1;
-        uint32_t out = 0;
+        uint32_t sum[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            uint32_t sum = 1u << 15;
+            sum[b] = 1u << 15;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint4 v = pr[p0 + k];
                 const uint32_t x = b == 0 ? v.x : b == 1 ? v.y : b == 2 ? v.z : v.w;
-                sum = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, x), __builtin_bit_cast(vo_u16x2, (r & 1) ? TO[k] : TE[k]), sum, false);
+                sum[b] = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, x), __builtin_bit_cast(vo_u16x2, (r & 1) ? TO[k] : TE[k]), sum[b], false);
             }
-            sum >>= 16;
-            out |= (sum > 255u ? 255u : sum) << (8 * b);
         }
+        // (sum >> 16) <= 257 saturated to a byte: the high halves of two sums side by side (v_perm_b32), one packed minimum
+        // against 255 for both, one v_perm_b32 for the four bytes
+        const uint32_t p01 = pk_min16(__builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u), 0x00ff00ffu);
+        const uint32_t p23 = pk_min16(__builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u), 0x00ff00ffu);
+        const uint32_t out = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
         if (gy < lv.h && gx < lv.stride) *(uint32_t*)(blur + (size_t)f * g.frame_bytes + lv.off + (size_t)gy * lv.stride + gx) = out;
     }
 }
