@@ -320,9 +320,112 @@ __global__ __launch_bounds__(RS2_THREADS) void k_resize_strip(uint8_t* pyr, int 
     }
 }
 
+// Direct version of the strip kernel: the same per-lane arithmetic (4 destination columns per lane, source rows swept top to
+// bottom, the two live row results in registers), but a lane reads its 12-byte source window of every row straight from
+// global memory (three dwords at a 4-byte aligned address; neighbouring lanes' windows overlap and coalesce in the
+// texture path), RS3_AHEAD rows ahead of their use.  No LDS, no staging phase, no barrier: a wavefront is independent, so
+// the loads of one overlap the arithmetic of the others at 8 waves per SIMD (the staged kernel holds 5 workgroups per
+// CU, whose load and compute phases ran one after the other).
+#ifndef RS3_AHEAD
+#define RS3_AHEAD 4
+#endif
+__global__ __launch_bounds__(RS2_THREADS) void k_resize_direct(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom dst, ResizeTab tab)
+{
+    const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (dst.w + RS2_WW - 1) / RS2_WW;
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int tx = bid % tiles_x, ty = bid / tiles_x;
+    const int x0 = tx * RS2_WW, y0 = ty * RS2_TH;
+    const int dy0 = y0 + wave * RS2_WH, dy1 = min(dy0 + RS2_WH, dst.h);
+    if (dy0 >= dst.h) return;
+    const uint8_t* sp = pyr + (size_t)f * frame_bytes + src.off;
+    const int dx = x0 + 4 * lane;
+    int o[4], c1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int xi = min(dx + i, dst.w - 1); o[i] = tab.xofs[xi]; c1[i] = tab.xc1[xi]; }
+    // the row schedule of the wavefront's 16 destination rows, loaded once (lane i holds row dy0 + i) and read with v_readlane:
+    // no memory operation besides the window prefetches inside the sweep, so their s_waitcnt can leave RS3_AHEAD - 1 rows in flight
+    static_assert(RS2_WH <= 64, "one lane per destination row of the strip");
+    const int li = min(dy0 + lane, dst.h - 1);
+    const int yo_l = tab.yofs[li], yc_l = (int)tab.yc1[li];
+    const int yo_first = __builtin_amdgcn_readlane(yo_l, 0), yo_last = __builtin_amdgcn_readlane(yo_l, dy1 - 1 - dy0);
+    const uint32_t wy_first = (uint32_t)__builtin_amdgcn_readlane(yc_l, 0);
+    // per-lane column constants: window start, byte shift, selectors of the 4 + 4 source bytes, 8.8 weights
+    const int base = o[0] & ~3, sh = o[0] - base;
+    const uint32_t q1 = (uint32_t)(o[1] - o[0]), q2 = (uint32_t)(o[2] - o[0]), q3 = (uint32_t)(o[3] - o[0]);
+    const uint32_t sel_ae = 0x0c000c00u | (q2 << 16), sel_ao = 0x0c000c00u | q1 | (q3 << 16);
+    const uint32_t sel_be = sel_ae + 0x00010001u, sel_bo = sel_ao + 0x00010001u;
+    const uint32_t c1e = (uint32_t)c1[0] | ((uint32_t)c1[2] << 16), c1o = (uint32_t)c1[1] | ((uint32_t)c1[3] << 16);
+    const int r_first = yo_first, r_end = yo_last + 2;          // source rows this wavefront sweeps (wave-uniform); a row past the image repeats the last one
+    // stores go through a buffer descriptor of the destination level: an offset past its end is dropped by the hardware, which
+    // is how a row that emits nothing "stores" without a branch around the instruction
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(pyr + (size_t)f * frame_bytes + dst.off, 0, dst.stride * dst.h, 0x00020000);
+    uint32_t out = (uint32_t)(dy0 * dst.stride + dx);
+    const bool col_ok = dx < dst.stride;
+    const uint8_t* gp = sp + base;
+    uint32_t w[RS3_AHEAD][3];
+#pragma unroll
+    for (int u = 0; u < RS3_AHEAD; u++) {
+        const uint32_t* q = (const uint32_t*)(gp + (size_t)min(r_first + u, src.h - 1) * src.stride);
+        w[u][0] = q[0]; w[u][1] = q[1]; w[u][2] = q[2];
+    }
+    // row schedule: destination row dy is emitted at source row yofs[dy] + 1 with the weight pair of yc1[dy]
+    int dy = dy0;
+    int e_at = r_first + 1;
+    uint32_t wy = wy_first;
+    int e_next = dy + 1 < dy1 ? __builtin_amdgcn_readlane(yo_l, 1) + 1 : -1;
+    uint32_t wy_next = dy + 1 < dy1 ? (uint32_t)__builtin_amdgcn_readlane(yc_l, 1) : 0u;
+    uint32_t pe = 0, po = 0;                                // row results of the previous source row: (h0, h2), (h1, h3)
+    for (int r0 = r_first; r0 < r_end; r0 += RS3_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < RS3_AHEAD; u++) {
+            const int r = r0 + u;
+            if (r >= r_end) break;                          // wave-uniform
+            const uint32_t w0 = w[u][0], w1 = w[u][1], w2 = w[u][2];
+            {   // the window of row r + RS3_AHEAD replaces this one
+                const uint32_t* q = (const uint32_t*)(gp + (size_t)min(r + RS3_AHEAD, src.h - 1) * src.stride);
+                w[u][0] = q[0]; w[u][1] = q[1]; w[u][2] = q[2];
+            }
+            const uint32_t x0w = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)sh), x1w = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)sh);
+            const uint32_t a_e = __builtin_amdgcn_perm(x1w, x0w, sel_ae), a_o = __builtin_amdgcn_perm(x1w, x0w, sel_ao);
+            const uint32_t b_e = __builtin_amdgcn_perm(x1w, x0w, sel_be), b_o = __builtin_amdgcn_perm(x1w, x0w, sel_bo);
+            // h = (a << 8) + c1 * (b - a) = (256 - c1) * a + c1 * b <= 65280: exact in the low 16 bits of the packed multiply-add
+            const vo_u16x2 h_e = __builtin_bit_cast(vo_u16x2, c1e) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_e, a_e)) + __builtin_bit_cast(vo_u16x2, a_e << 8);
+            const vo_u16x2 h_o = __builtin_bit_cast(vo_u16x2, c1o) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_o, a_o)) + __builtin_bit_cast(vo_u16x2, a_o << 8);
+            const uint32_t ce = __builtin_bit_cast(uint32_t, h_e), co = __builtin_bit_cast(uint32_t, h_o);
+            {   // the vertical blend and the store are issued for every source row (the store under a lane mask that is empty
+                // unless r is the lower source row of destination row dy): a fixed sequence of memory operations per row, so
+                // that the compiler's s_waitcnt bookkeeping can keep the prefetched rows in flight
+                const bool emit = r == e_at;                // wave-uniform
+                const vo_u16x2 wv = __builtin_bit_cast(vo_u16x2, (256u - wy) | (wy << 16));
+                const uint32_t d0 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x05040100u)), wv, 32768u, false);
+                const uint32_t d2 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x07060302u)), wv, 32768u, false);
+                const uint32_t d1 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x05040100u)), wv, 32768u, false);
+                const uint32_t d3 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x07060302u)), wv, 32768u, false);
+                // (sum + 2^15) >> 16 is byte 2 of each dot product (at most 255: no saturation needed)
+                const uint32_t t01 = __builtin_amdgcn_perm(d1, d0, 0x0c0c0602u), t23 = __builtin_amdgcn_perm(d3, d2, 0x0c0c0602u);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(t23, t01, 0x05040100u), drs, col_ok && emit ? out : 0xfffffff0u, 0, 0);
+                out += emit ? (uint32_t)dst.stride : 0u;
+                dy += emit ? 1 : 0;
+                const int dn = min(dy + 1, dy1 - 1) - dy0;
+                const int en2 = dy + 1 < dy1 ? __builtin_amdgcn_readlane(yo_l, dn) + 1 : -1;
+                const uint32_t wn2 = (uint32_t)__builtin_amdgcn_readlane(yc_l, dn);
+                e_at = emit ? e_next : e_at; wy = emit ? wy_next : wy;
+                e_next = emit ? en2 : e_next; wy_next = emit ? wn2 : wy_next;
+            }
+            pe = ce; po = co;
+        }
+    }
+}
+
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F)
 {
     const LevelGeom& d = g.lv[level];
+    if (tab.strip == 2) {
+        dim3 grid(((d.w + RS2_WW - 1) / RS2_WW) * ((d.h + RS2_TH - 1) / RS2_TH), 1, F);
+        hipLaunchKernelGGL(k_resize_direct, grid, dim3(RS2_THREADS), 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
+        return;
+    }
     if (tab.strip) {
         dim3 grid(((d.w + RS2_WW - 1) / RS2_WW) * ((d.h + RS2_TH - 1) / RS2_TH), 1, F);
         hipLaunchKernelGGL(k_resize_strip, grid, dim3(RS2_THREADS), 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);

@@ -450,6 +450,7 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
             }
             const char* ev = getenv("VO_RESIZE_STRIP");
             t.strip = ok2 && !(ev && ev[0] == '0') ? 1 : 0;
+            if (t.strip && !(ev && ev[0] == '1')) t.strip = 2;           // default: k_resize_direct (no LDS staging); VO_RESIZE_STRIP=1: the staged strip kernel, 0: the tiled one
             if (getenv("VO_DEBUG")) fprintf(stderr, "resize level %d: tiled %d strip %d\n", l, t.tiled, t.strip);
         }
     }
@@ -457,7 +458,7 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     HIPCHK(hipMemcpy(d_c, hc.data(), (tab_u16 + 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
 
     const size_t F = (size_t)max_frames, fb = (size_t)g.frame_bytes;
-    HIPCHK(hipMalloc((void**)&ctx->pyr, F * fb));
+    HIPCHK(hipMalloc((void**)&ctx->pyr, F * fb + 256));          // + slack: k_resize_direct reads whole dwords around its last taps
     HIPCHK(hipMalloc((void**)&ctx->blur, F * fb));
     HIPCHK(hipMalloc((void**)&ctx->score, F * fb));
     HIPCHK(hipMemset(ctx->pyr, 0, F * fb));
