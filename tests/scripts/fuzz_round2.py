@@ -48,11 +48,18 @@ for it in range(N):
     p = O.orb_params(nfeatures=300, nlevels=nl, fast_threshold=thr)
     lw, lh = O.level_geometry(h, w, p)[:2]
     got = det.stage_levels("vo_stage_fast_scores", img, [(int(a), int(b)) for a, b in zip(lw, lh)])
-    for l, lvl in enumerate(O.pyramid(img, p)):
+    sizes = [(int(a), int(b)) for a, b in zip(lw, lh)]
+    pyr = O.pyramid(img, p)
+    for l, lvl in enumerate(pyr):
         ref = O.fast_score_nms(lvl, thr)
         if not np.array_equal(got[l], ref):
             print("FAST score differs", it, h, w, thr, l, np.count_nonzero(got[l] != ref)); sys.exit(1)
-print(f"FAST cornerScore: {N} images identical ({time.time() - t0:.0f} s)", flush=True)
+    if it % 2 == 0:                                                         # pyramid levels and their 7x7 blur: every width residue
+        gp, gb = det.stage_levels("vo_stage_pyramid", img, sizes), det.stage_levels("vo_stage_blur", img, sizes)
+        for l, lvl in enumerate(pyr):
+            if not np.array_equal(gp[l], lvl) or not np.array_equal(gb[l], O.gaussian_blur7(lvl)):
+                print("pyramid / blur differs", it, h, w, l); sys.exit(1)
+print(f"FAST cornerScore (+ pyramid, blur on every second image): {N} images identical ({time.time() - t0:.0f} s)", flush=True)
 
 t0 = time.time()
 for it in range(N):

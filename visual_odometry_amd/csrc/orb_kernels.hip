@@ -1469,8 +1469,155 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* pyr, uint8_t* blur,
     }
 }
 
+// Direct version (levels of at least 16 x 8 pixels): the same arithmetic without LDS.  A wavefront owns 256 columns (4 per lane)
+// of BD_R output rows and sweeps the BD_R + 6 input rows top to bottom, two per step: a lane reads its 12-byte window of a
+// row (columns x-4 .. x+7) straight from global memory, BD_AHEAD steps ahead of their use; horizontal pass as above; the
+// 16-bit sums of the two rows of a step share a dword per column, the last four such pairs stay in registers and give the
+// two output rows whose 7-row windows end in this step (4 x v_dot2_u32_u16 each).  BORDER_REFLECT_101: rows by the row
+// index (scalar), the <= 3 columns beyond either image edge by v_perm_b32 with per-lane selectors in the wavefronts that
+// touch an edge.  Stores through a buffer descriptor (an offset past the end is dropped: no branch around a store, so the
+// compiler's s_waitcnt bookkeeping keeps the prefetched rows in flight).  No barrier, 8 waves per SIMD.
+#ifndef BD_R
+#define BD_R 64
+#endif
+#define BD_AHEAD 2
+struct BdEdge { bool left, right; uint32_t shl, shr, s1, s2, s3, use_t; };
+
+__device__ __forceinline__ void bd_fix(uint32_t& w0, uint32_t& w1, uint32_t& w2, const BdEdge& e)
+{
+    if (e.left) {                                           // wave-uniform: lane 0 loaded columns 0..11 instead of -4..7
+        const uint32_t m = __builtin_amdgcn_perm(w0, w0, 0x01020300u);       // columns -3..-1 = columns 3..1
+        w2 = e.shl ? w1 : w2; w1 = e.shl ? w0 : w1; w0 = e.shl ? m : w0;
+    }
+    if (e.right) {                                          // wave-uniform
+        w0 = e.shr ? w1 : w0; w1 = e.shr ? w2 : w1;        // the last lane of a row loaded columns stride-12 .. stride-1
+        const uint32_t t = __builtin_amdgcn_perm(w1, w0, e.s2), u = __builtin_amdgcn_perm(w2, w1, e.s3);
+        w1 = __builtin_amdgcn_perm(w1, w0, e.s1);
+        w2 = e.use_t ? t : u;
+    }
+}
+
+__device__ __forceinline__ void bd_hpass(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t (&h)[4])
+{
+    const uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24), TB = 49u | (34u << 8) | (18u << 16);
+    // pixel j needs window bytes 1+j .. 7+j of {w0,w1,w2}
+    const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, 1), a1 = __builtin_amdgcn_alignbyte(w1, w0, 2);
+    const uint32_t a2 = __builtin_amdgcn_alignbyte(w1, w0, 3), a3 = w1;
+    const uint32_t b0 = __builtin_amdgcn_alignbyte(w2, w1, 1), b1 = __builtin_amdgcn_alignbyte(w2, w1, 2);
+    const uint32_t b2 = __builtin_amdgcn_alignbyte(w2, w1, 3), b3 = w2;
+    h[0] = __builtin_amdgcn_udot4(a0, TA, __builtin_amdgcn_udot4(b0, TB, 0u, false), false);
+    h[1] = __builtin_amdgcn_udot4(a1, TA, __builtin_amdgcn_udot4(b1, TB, 0u, false), false);
+    h[2] = __builtin_amdgcn_udot4(a2, TA, __builtin_amdgcn_udot4(b2, TB, 0u, false), false);
+    h[3] = __builtin_amdgcn_udot4(a3, TA, __builtin_amdgcn_udot4(b3, TB, 0u, false), false);
+}
+
+// one output row from four row pairs (oldest first); ODD: the row's window starts on the second row of the oldest pair
+template <bool ODD>
+__device__ __forceinline__ uint32_t bd_vrow(const uint32_t (&q0)[4], const uint32_t (&q1)[4], const uint32_t (&q2)[4], const uint32_t (&q3)[4])
+{
+    const uint32_t T0 = ODD ? 18u << 16 : 18u | (34u << 16), T1 = ODD ? 34u | (49u << 16) : 49u | (55u << 16);
+    const uint32_t T2 = ODD ? 55u | (49u << 16) : 49u | (34u << 16), T3 = ODD ? 34u | (18u << 16) : 18u;
+    uint32_t sum[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t a = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, q0[c]), __builtin_bit_cast(vo_u16x2, T0), 1u << 15, false);
+        a = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, q1[c]), __builtin_bit_cast(vo_u16x2, T1), a, false);
+        a = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, q2[c]), __builtin_bit_cast(vo_u16x2, T2), a, false);
+        sum[c] = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, q3[c]), __builtin_bit_cast(vo_u16x2, T3), a, false);
+    }
+    const uint32_t p01 = pk_min16(__builtin_amdgcn_perm(sum[1], sum[0], 0x07060302u), 0x00ff00ffu);
+    const uint32_t p23 = pk_min16(__builtin_amdgcn_perm(sum[3], sum[2], 0x07060302u), 0x00ff00ffu);
+    return __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+}
+
+__global__ __launch_bounds__(256) void k_blur_direct(const uint8_t* pyr, uint8_t* blur, PyrGeom g, int total)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wt = xcd_tile(blockIdx.x, gridDim.x) * 4 + wave;
+    if (wt >= total) return;
+    int l = 0, first = 0;
+    for (;;) {
+        const int nt = ((g.lv[l].stride + 255) / 256) * ((g.lv[l].h + BD_R - 1) / BD_R);
+        if (wt < first + nt || l + 1 == g.nlevels) break;
+        first += nt; l++;
+    }
+    const LevelGeom lv = g.lv[l];
+    const int ntx = (lv.stride + 255) / 256, tile = wt - first;
+    const int x0 = (tile % ntx) * 256, y0 = (tile / ntx) * BD_R;
+    const int x = x0 + 4 * lane;
+    const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
+    const int xb = min(max(x - 4, 0), lv.stride - 12);
+    BdEdge e;
+    e.left = x0 == 0; e.right = x0 + 256 + 8 > lv.w;
+    e.shl = x == 0; e.shr = x - 4 > lv.stride - 12 && x < lv.stride;
+    {
+        const int d = lv.w - x;                             // columns w .. w+2 mirror to w-2 .. w-4 (window position of column x+j: j+4)
+        e.s1 = d == 1 ? 0x01020304u : d == 2 ? 0x03040504u : d == 3 ? 0x05060504u : 0x07060504u;
+        e.s2 = d == 2 ? 0x0c0c0c02u : d == 3 ? 0x0c0c0304u : 0x0c040506u;
+        e.s3 = d == 5 ? 0x01020304u : d == 6 ? 0x03040504u : 0x07060504u;
+        e.use_t = d >= 2 && d <= 4;
+    }
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(blur + (size_t)f * g.frame_bytes + lv.off, 0, lv.stride * lv.h, 0x00020000);
+    const bool col_ok = x < lv.stride;
+    const int nout = min(BD_R, lv.h - y0);                  // output rows of this strip
+    const int nsteps = (nout + 1) / 2;                      // emitting steps; three priming steps come first
+
+    uint32_t W[BD_AHEAD][2][3];                             // prefetched windows: [step mod BD_AHEAD][row of the step][dword]
+    auto fetch = [&](int step, uint32_t (&dst)[2][3]) {     // input rows 2 step, 2 step + 1 of the strip (row 0 = y0 - 3)
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int gy = reflect101(y0 - 3 + 2 * step + r, lv.h);
+            const uint32_t* q = (const uint32_t*)(img + (size_t)gy * lv.stride + xb);
+            dst[r][0] = q[0]; dst[r][1] = q[1]; dst[r][2] = q[2];
+        }
+    };
+    uint32_t Q[4][4];                                       // row pairs of the last four steps: [step mod 4][column]
+    auto hstep = [&](uint32_t (&src)[2][3], uint32_t (&q)[4]) {
+        uint32_t h0[4], h1[4];
+        uint32_t a0 = src[0][0], a1 = src[0][1], a2 = src[0][2], b0 = src[1][0], b1 = src[1][1], b2 = src[1][2];
+        bd_fix(a0, a1, a2, e); bd_fix(b0, b1, b2, e);
+        bd_hpass(a0, a1, a2, h0); bd_hpass(b0, b1, b2, h1);
+#pragma unroll
+        for (int c = 0; c < 4; c++) q[c] = h0[c] | (h1[c] << 16);
+    };
+#pragma unroll
+    for (int u = 0; u < BD_AHEAD; u++) fetch(u, W[u]);
+    // priming: steps 0, 1, 2 (input rows y0-3 .. y0+2)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        hstep(W[k % BD_AHEAD], Q[k % 4]);
+        fetch(k + BD_AHEAD, W[k % BD_AHEAD]);
+    }
+    // step k = 3 + m: input rows y0+3+2m, y0+4+2m; output rows y0+2m (window = pairs k-3 .. k, even start) and y0+2m+1
+    uint32_t orow = (uint32_t)(y0 * lv.stride);
+    for (int m0 = 0; m0 < nsteps; m0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = m0 + j;
+            if (m >= nsteps) break;                         // wave-uniform
+            constexpr int K0 = 3;
+            const int ki = (K0 + j) % 4, wi = (K0 + j) % BD_AHEAD;       // ring slots of step k = 3 + m (m0 is a multiple of 4)
+            hstep(W[wi], Q[ki]);
+            fetch(K0 + m + BD_AHEAD, W[wi]);
+            const uint32_t r0 = bd_vrow<false>(Q[(ki + 1) % 4], Q[(ki + 2) % 4], Q[(ki + 3) % 4], Q[ki]);
+            const uint32_t r1 = bd_vrow<true>(Q[(ki + 1) % 4], Q[(ki + 2) % 4], Q[(ki + 3) % 4], Q[ki]);
+            __builtin_amdgcn_raw_buffer_store_b32(r0, drs, col_ok ? (uint32_t)x + orow : 0xfffffff0u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(r1, drs, col_ok && 2 * m + 1 < nout ? (uint32_t)x + orow + (uint32_t)lv.stride : 0xfffffff0u, 0, 0);
+            orow += 2u * (uint32_t)lv.stride;
+        }
+    }
+}
+
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F)
 {
+    static const int mode = [] { const char* e = getenv("VO_BLUR_DIRECT"); return e ? atoi(e) : 1; }();
+    bool direct = mode != 0;
+    int total = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        direct = direct && g.lv[l].w >= 16 && g.lv[l].h >= 8;
+        total += ((g.lv[l].stride + 255) / 256) * ((g.lv[l].h + BD_R - 1) / BD_R);
+    }
+    if (direct) { hipLaunchKernelGGL(k_blur_direct, dim3((total + 3) / 4, F), dim3(256), 0, s, pyr, blur, g, total); return; }
     hipLaunchKernelGGL(k_blur, dim3(g.btiles_total, F), dim3(256), 0, s, pyr, blur, g);
 }
 
