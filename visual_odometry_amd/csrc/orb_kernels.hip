@@ -736,6 +736,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     //    adds and subtracts (full issue rate) on halves biased by 0x7fff, whose bit 15 is the per-pixel answer.  Groups
     //    with a survivor go to the group queue (one ballot per step), which phase B' turns into the pixel queue.
     static_assert(FT_GROUPS_X <= 32 && FT_SCH % 2 == 0, "two bands of groups per wavefront");
+    static_assert(FT_SCH <= 32 && FT_SCW <= 128, "queue entries hold the score-tile row in 5 bits and the column in 7");
     constexpr int FB_ROWS = FT_SCH / 2;                // steps per band
     const uint32_t T2 = (uint32_t)t * 0x00010001u, K1 = 0x7fff7fffu - T2;
     const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
