@@ -610,6 +610,10 @@ __device__ __forceinline__ int count_inliers(const double* E, const double* x1, 
 #define RS_STREAM 512                     // RNG numbers staged per round (64 subsets x 5 + rejections)
 #define RS_ROUND FP_LANES
 #define RS_SCORE_G 4                       // models a wave scores at once
+#ifndef RS_WAVES
+#define RS_WAVES 4                         // wavefronts of the workgroup: wave 0 solves, all of them score
+#endif
+#define RS_THREADS (64 * RS_WAVES)
 
 struct RansacShared {
     double cm[200 * FP_LANES];          // 102400 B
@@ -618,11 +622,11 @@ struct RansacShared {
     int nm[64];
     int off[65];
     uint8_t eh[640];
-    int cnt[4 * RS_SCORE_G];
+    int cnt[RS_WAVES * RS_SCORE_G];
     int used;
 };
 
-__global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp, const uint32_t* rng_tab, int rng_n)
+__global__ __launch_bounds__(RS_THREADS, 1) void k_ransac(PairBuf pb, int kp_cap, RansacParams rp, const uint32_t* rng_tab, int rng_n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // dynamic: FP_LANES = 64 needs more than the static 64 KB
     RansacShared& sh = *(RansacShared*)s_dyn;
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
 
     if (M < 5) {
         if (tid == 0) { res->status = VO_ERR_TOO_FEW; res->n_inl = 0; res->ransac_iters = 0; }
-        for (int i = tid; i < M; i += 256) mask[i] = 0;
+        for (int i = tid; i < M; i += RS_THREADS) mask[i] = 0;
         return;
     }
     const double threshold = rp.thresh_px / ((rp.K[0] + rp.K[4]) / 2);
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
         //     their subsets in parallel from assumed start positions (5 numbers per earlier subset), a prefix sum of the
         //     numbers actually used gives the true starts, and the lanes repeat until the starts stop moving (one or two
         //     passes; each pass fixes at least the first lane that was wrong, so it ends).
-        for (int i = tid; i < RS_STREAM; i += 256) sh.stream[i] = pos + i < rng_n ? rng_tab[pos + i] % (uint32_t)M : 0u;
+        for (int i = tid; i < RS_STREAM; i += RS_THREADS) sh.stream[i] = pos + i < rng_n ? rng_tab[pos + i] % (uint32_t)M : 0u;
         __syncthreads();
         if (wave == 0) {
             int start = 5 * lane, used = 5;
@@ -751,13 +755,13 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
         const int T = sh.off[64];
         bool done = false;
         int last_h = -1;
-        for (int b0 = 0; b0 < T && !done; b0 += 4 * RS_SCORE_G) {
+        for (int b0 = 0; b0 < T && !done; b0 += RS_WAVES * RS_SCORE_G) {
             {
                 double E[RS_SCORE_G][9];
                 int ne = 0;
 #pragma unroll
                 for (int gq = 0; gq < RS_SCORE_G; gq++) {
-                    const int e = b0 + gq * 4 + wave;
+                    const int e = b0 + gq * RS_WAVES + wave;
                     const int ee = e < T ? e : (b0 + wave < T ? b0 + wave : 0);      // a dummy model keeps the lanes uniform
                     const int h = sh.eh[ee], m = ee - sh.off[h];
 #pragma unroll
@@ -778,12 +782,12 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
                     }
                     if (lane == 0) {
 #pragma unroll
-                        for (int gq = 0; gq < RS_SCORE_G; gq++) sh.cnt[gq * 4 + wave] = good[gq];
+                        for (int gq = 0; gq < RS_SCORE_G; gq++) sh.cnt[gq * RS_WAVES + wave] = good[gq];
                     }
                 }
             }
             __syncthreads();
-            for (int q = 0; q < 4 * RS_SCORE_G; q++) {
+            for (int q = 0; q < RS_WAVES * RS_SCORE_G; q++) {
                 const int e2 = b0 + q;
                 if (e2 >= T) break;
                 const int h = sh.eh[e2];
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
     }
 
     if (max_good > 0) {
-        count_inliers(bestE, x1, x2, M, t, tid, 256, 0, mask);
+        count_inliers(bestE, x1, x2, M, t, tid, RS_THREADS, 0, mask);
         if (tid == 0) {
 #pragma unroll
             for (int k = 0; k < 9; k++) res->E[k] = bestE[k];
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(256, 1) void k_ransac(PairBuf pb, int kp_cap, Ransa
 #endif
         }
     } else {
-        for (int i = tid; i < M; i += 256) mask[i] = 0;
+        for (int i = tid; i < M; i += RS_THREADS) mask[i] = 0;
         if (tid == 0) { res->n_inl = 0; res->status = VO_ERR_NO_MODEL; res->ransac_iters = iters_done; res->reserved = 0; }
     }
 }
@@ -831,7 +835,7 @@ void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp
 {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_ransac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RansacShared)); attr = true; }
-    hipLaunchKernelGGL(k_ransac, dim3(P), dim3(256), sizeof(RansacShared), s, pb, kp_cap, rp, rng_tab, rng_n);
+    hipLaunchKernelGGL(k_ransac, dim3(P), dim3(RS_THREADS), sizeof(RansacShared), s, pb, kp_cap, rp, rng_tab, rng_n);
 }
 
 // ------------------------------------------------------------------ triangulation (DLT, 4x4 SVD per point)
