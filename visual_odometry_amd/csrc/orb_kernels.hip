@@ -1737,7 +1737,8 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* blur, PyrGeom g, F
             uint64_t wv8 = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
             *(uint64_t*)(ff.desc + ki * 32 + lane * 8) = wv8;
         }
-        if (fp4) {                                             // FP4 image (match_kernels.hip k_nn_fp4): lane c < 8 expands bits 32c .. 32c + 31
+        if (fp4 < 0) {                                         // the operand image is written by k_desc_expand afterwards (all 64 lanes busy)
+        } else if (fp4) {                                      // FP4 image (match_kernels.hip k_nn_fp4): lane c < 8 expands bits 32c .. 32c + 31
             if (lane < 8) {
                 const uint64_t wv8 = lane < 2 ? words[0] : lane < 4 ? words[1] : lane < 6 ? words[2] : words[3];
                 const uint32_t bits = (uint32_t)(wv8 >> (32 * (lane & 1)));
@@ -1762,5 +1763,8 @@ void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFea
 {
     hipLaunchKernelGGL(k_brief_trig, dim3((g.kp_cap + 255) / 256, F), dim3(256), 0, s, g, ff);
     const int bpf = (g.kp_cap + 4 * BR_KPW - 1) / (4 * BR_KPW);
-    hipLaunchKernelGGL(k_brief, dim3(bpf * F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x, bpf, fp4);
+    // the matcher's operand image (+-127 bytes or FP4 nibbles) is expanded by its own lane-per-32-bits kernel: inside k_brief
+    // 8 (16) lanes of a wavefront did it while the other 56 (48) idled through the same instructions (16 % of the kernel)
+    hipLaunchKernelGGL(k_brief, dim3(bpf * F), dim3(256), 0, s, blur, g, ff, desc_x, cap_x, bpf, -1);
+    launch_desc_expand(s, ff.desc, ff.kp_count, g.kp_cap, cap_x, desc_x, F, fp4);
 }
