@@ -59,6 +59,24 @@ def test_blur_bit_exact(oracle, ctx, h, w):
         assert np.array_equal(got[l], ref), f"level {l}: {np.count_nonzero(got[l] != ref)} pixels differ"
 
 
+def test_staged_kernels_equal_direct_ones(oracle, ctx, monkeypatch):
+    """The LDS-staged pyramid / blur kernels stay in the library as fallbacks (VO_RESIZE_STRIP=1, VO_BLUR_DIRECT=0 and
+    levels under 16 x 8 pixels): same bytes as the direct (no-LDS) kernels that run by default."""
+    from visual_odometry_amd import _lib
+    img = random_image(9, 300, 517)
+    p = oracle.orb_params(nfeatures=500)
+    sizes = _level_sizes(oracle, 300, 517, p)
+    ref_p = _det().stage_levels("vo_stage_pyramid", img, sizes)
+    ref_b = _det().stage_levels("vo_stage_blur", img, sizes)
+    monkeypatch.setenv("VO_RESIZE_STRIP", "1"); monkeypatch.setenv("VO_BLUR_DIRECT", "0")
+    det = _det(ctx=_lib.Context(0))                               # a fresh context: the resize tables are built at configuration
+    got_p, got_b = det.stage_levels("vo_stage_pyramid", img, sizes), det.stage_levels("vo_stage_blur", img, sizes)
+    for l in range(len(sizes)):
+        assert np.array_equal(got_p[l], ref_p[l]) and np.array_equal(got_b[l], ref_b[l]), l
+    for l, lvl in enumerate(oracle.pyramid(img, p)):
+        assert np.array_equal(got_p[l], lvl) and np.array_equal(got_b[l], oracle.gaussian_blur7(lvl)), l
+
+
 @pytest.mark.parametrize("nfeatures,nlevels,h,w,seed", [(500, 8, 480, 640, 5), (2000, 8, 720, 1280, 6),
                                                          (300, 4, 300, 400, 7), (500, 8, 243, 331, 8)])
 def test_detect_and_compute_bit_exact(oracle, ctx, nfeatures, nlevels, h, w, seed):

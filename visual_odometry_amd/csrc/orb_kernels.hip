@@ -1622,8 +1622,8 @@ __global__ __launch_bounds__(256) void k_blur_direct(const uint8_t* pyr, uint8_t
 
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F)
 {
-    static const int mode = [] { const char* e = getenv("VO_BLUR_DIRECT"); return e ? atoi(e) : 1; }();
-    bool direct = mode != 0;
+    const char* ev = getenv("VO_BLUR_DIRECT");             // read per launch (tests switch it inside one process)
+    bool direct = !(ev && ev[0] == '0');
     int total = 0;
     for (int l = 0; l < g.nlevels; l++) {
         direct = direct && g.lv[l].w >= 16 && g.lv[l].h >= 8;
