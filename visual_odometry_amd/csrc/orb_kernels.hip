@@ -558,7 +558,6 @@ void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride,
 // w9[k] = min3(t3[k], t3[k+3], t3[k+6]) — 16 instructions for all 16 arcs (the integer ladder of windows 2, 4, 8, 9
 // needs 40), and the VOP3P op_sel bits read "index + 8" (the same register with its halves exchanged) without a
 // separate swap instruction.
-#ifndef FAST_SCORE_I16
 #define PKF_SEL_000 ""
 #define PKF_SEL_001 " op_sel:[0,0,1] op_sel_hi:[1,1,0]"
 #define PKF_SEL_010 " op_sel:[0,1,0] op_sel_hi:[1,0,1]"
@@ -633,44 +632,6 @@ __device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)      
     fast_ring_pairs(c, R);
     return fast_score_from_ring(c[0], R, t);
 }
-#define FAST_SCORE_PAIR 1
-#else
-// the packed-int16 form (windows of 2, 4, 8, 9): Q[k] holds the ring differences (d[k], d[k+8]) as two int16
-__device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)
-{
-    const uint32_t v = c[0], vv = v | (v << 16);
-    uint32_t Q[8];
-#define RD(k, o0, o8) Q[k] = pk_sub16(vv, (uint32_t)c[o0] | ((uint32_t)c[o8] << 16))
-    RD(0, 3 * FT_PXW, -3 * FT_PXW);         RD(1, 3 * FT_PXW + 1, -3 * FT_PXW - 1);
-    RD(2, 2 * FT_PXW + 2, -2 * FT_PXW - 2); RD(3, FT_PXW + 3, -FT_PXW - 3);
-    RD(4, 3, -3);                           RD(5, -FT_PXW + 3, FT_PXW - 3);
-    RD(6, -2 * FT_PXW + 2, 2 * FT_PXW - 2); RD(7, -3 * FT_PXW + 1, 3 * FT_PXW - 1);
-#undef RD
-    // windows of 2, 4, 8 and 9 consecutive differences; index k+8 is the same register with halves swapped
-    uint32_t mn2[8], mx2[8], mn4[8], mx4[8];
-    const uint32_t q8 = swap16(Q[0]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const uint32_t nx = k < 7 ? Q[k + 1] : q8; mn2[k] = pk_min16(Q[k], nx); mx2[k] = pk_max16(Q[k], nx); }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t n2 = k < 6 ? mn2[k + 2] : swap16(mn2[k - 6]), x2 = k < 6 ? mx2[k + 2] : swap16(mx2[k - 6]);
-        mn4[k] = pk_min16(mn2[k], n2); mx4[k] = pk_max16(mx2[k], x2);
-    }
-    uint32_t A2 = 0x80008000u, B2 = 0x7fff7fffu;       // running max of arc minima / min of arc maxima
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t n4 = k < 4 ? mn4[k + 4] : swap16(mn4[k - 4]), x4 = k < 4 ? mx4[k + 4] : swap16(mx4[k - 4]);
-        const uint32_t far = swap16(Q[k]);              // (d[k+8], d[k])
-        A2 = pk_max16(A2, pk_min16(pk_min16(mn4[k], n4), far));
-        B2 = pk_min16(B2, pk_max16(pk_max16(mx4[k], x4), far));
-    }
-    const int A = max((int)(short)(A2 & 0xffffu), (int)(short)(A2 >> 16));
-    const int B = -min((int)(short)(B2 & 0xffffu), (int)(short)(B2 >> 16));
-    const int m = max(A, B);
-    return m > t ? m - 1 : 0;
-}
-
-#endif
 
 // DENSE = true writes the score map (the stage API / tests); false (the pipeline) writes, per tile, the list of NMS
 // winners inside the border as (score << 16 | row in tile << 8 | column in tile) and their number: retainBest then
@@ -843,16 +804,11 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
             const int ea = e0 + lane, eb = ea + 64;
             const bool ha = ea < qn, hb = eb < qn;
             const int qa = s_q[ha ? ea : 0], qb = s_q[hb ? eb : 0];
-#ifdef FAST_SCORE_PAIR
             const uint8_t* ca = s_px + ((qa >> 8) + 3) * FT_PXW + 12 + (qa & 255); const uint8_t* cb = s_px + ((qb >> 8) + 3) * FT_PXW + 12 + (qb & 255);
             uint32_t Ra[8], Rb[8];
             fast_ring_pairs(ca, Ra); fast_ring_pairs(cb, Rb);
             int sa = fast_score_from_ring(ca[0], Ra, t);
             int sb = fast_score_from_ring(cb[0], Rb, t);
-#else
-            int sa = fast_score_or_zero(s_px + ((qa >> 8) + 3) * FT_PXW + 12 + (qa & 255), t);
-            int sb = fast_score_or_zero(s_px + ((qb >> 8) + 3) * FT_PXW + 12 + (qb & 255), t);
-#endif
             sa = ha ? sa : 0; sb = hb ? sb : 0;
             const unsigned long long ma = __ballot(sa != 0), mb = __ballot(sb != 0);
             const int pa = nc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
