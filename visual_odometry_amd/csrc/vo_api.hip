@@ -1886,8 +1886,10 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
 // how many files of a batch go through the device at once (coefficients: 2 bytes per sample and component)
 static int jpeg_chunk(int h, int w, int F)
 {
+    // one workgroup decodes one file's entropy stream, so a launch wants at least as many files as the GPU has CUs (256):
+    // 24 GB of work buffers per launch = 360 files of 3840 x 2160 (the card has 288 GB)
     const size_t per = (size_t)h * w * 8 + (1 << 20);
-    size_t c = ((size_t)6 << 30) / per;
+    size_t c = ((size_t)24 << 30) / per;
     if (c < 1) c = 1;
     return c > (size_t)F ? F : (int)c;
 }
