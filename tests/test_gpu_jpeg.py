@@ -128,6 +128,10 @@ def test_ingest_jpeg_equals_decode_resize_gray(oracle, ctx):
     assert len(packed) == 3 and bytes(packed.file(1)) == bufs[1]
     assert np.array_equal(fe.ingest_jpeg(packed, want_resized=True), resized)
     assert np.array_equal(ingest.decode_batch(packed, ctx), ingest.decode_batch(bufs, ctx))
+    empty = ingest.PackedFiles(sizes=[len(b) for b in bufs])            # the reader-fills-it form (file.readinto)
+    for k, b in enumerate(bufs):
+        empty.file(k)[:] = np.frombuffer(b, np.uint8)
+    assert np.array_equal(fe.ingest_jpeg(empty, want_resized=True), resized)
 
 
 def test_corrupt_entropy_data_is_survived(oracle, ctx):
