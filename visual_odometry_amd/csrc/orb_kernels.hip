@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     __shared__ __attribute__((aligned(16))) uint8_t s_px[FT_PXH * FT_PXW];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[FT_SCH * FT_SCW];
     __shared__ uint16_t s_q[FT_QCAP + 1];            // + one spare slot for the branch-free push
-    static_assert(FT_GROUPS_X * FT_SCH * 4 <= FT_SCH * FT_SCW, "the group queue of phase B (dead before the score tile is cleared) fits the score tile");
+    static_assert(FT_GROUPS_X * FT_SCH * 4 + 4 <= FT_SCH * FT_SCW, "the group queue of phase B (dead before the score tile is cleared) and its spare slot fit the score tile");
     const int f = blockIdx.y, lane = threadIdx.x;
     const int bid = xcd_tile(blockIdx.x, g.ftiles_total);
     int l = 0;
@@ -717,6 +717,12 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     const uint32_t* colp = (const uint32_t*)s_px + 3 + gc + band * (FB_ROWS * (FT_PXW / 4));   // dword of the group, first pixel-tile row of the band
     uint32_t* s_g32 = (uint32_t*)s_sc;
     const uint32_t entry0 = (uint32_t)gc | ((uint32_t)(FB_ROWS * band) << 8);
+    // the v_perm_b32 selectors of the sweep as opaque scalar registers: as literals the compiler re-materialises each of them
+    // with an s_mov_b32 in every step (a wave issues one instruction at a time, scalar or vector)
+    uint32_t SEL_R4E, SEL_R4O, SEL_R12E, SEL_R12O, SEL_ANS;
+    asm volatile("s_mov_b32 %0, 0x0c050c03" : "=s"(SEL_R4E));  asm volatile("s_mov_b32 %0, 0x0c060c04" : "=s"(SEL_R4O));
+    asm volatile("s_mov_b32 %0, 0x0c030c01" : "=s"(SEL_R12E)); asm volatile("s_mov_b32 %0, 0x0c040c02" : "=s"(SEL_R12O));
+    asm volatile("s_mov_b32 %0, 0x07030501" : "=s"(SEL_ANS));
     int gn = 0;                                        // wave-uniform group-queue length
     uint32_t raw[FB_ROWS + 6], pe[FB_ROWS + 6], po[FB_ROWS + 6];     // band rows -3 .. +3 around the centres (compile-time indices)
 #pragma unroll
@@ -733,8 +739,8 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         const uint32_t c_e = pe[jc], c_o = po[jc];
         // ring 0 (0,+3) and ring 8 (0,-3): the rows three below / above; ring 4 (+3,0): bytes 7..10; ring 12 (-3,0): bytes 1..4
         const uint32_t r0_e = pe[j], r0_o = po[j], r8_e = pe[st], r8_o = po[st];
-        const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, 0x0c050c03u), r4_o = __builtin_amdgcn_perm(wr, c, 0x0c060c04u);
-        const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, 0x0c030c01u), r12_o = __builtin_amdgcn_perm(c, wl, 0x0c040c02u);
+        const uint32_t r4_e = __builtin_amdgcn_perm(wr, c, SEL_R4E), r4_o = __builtin_amdgcn_perm(wr, c, SEL_R4O);
+        const uint32_t r12_e = __builtin_amdgcn_perm(c, wl, SEL_R12E), r12_o = __builtin_amdgcn_perm(c, wl, SEL_R12O);
         // two adjacent compass pixels both brighter than v + t  <=>  X = min(max(r0, r8), max(r4, r12)) > v + t, both darker
         // <=> Y = max(min(r0, r8), min(r4, r12)) < v - t.  Per 16-bit half: 0x7fff - t + X - v has bit 15 set <=> X > v + t,
         // 0x7fff - t + v - Y has it set <=> Y < v - t; no half borrows from or carries into its neighbour (|..| < 0x100).
@@ -744,13 +750,14 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         const uint32_t dk_e = (c_e + K1) - Y_e, dk_o = (c_o + K1) - Y_o;
         // bytes 1 and 3 of the two words carry the answers (either polarity) in their top bits: gather them to bit 7 of
         // each byte — pixel 1, 0, 3, 2 from byte 0 up
-        const uint32_t bits = __builtin_amdgcn_perm(br_e | dk_e, br_o | dk_o, 0x07030501u) & 0x80808080u & colmask;
+        const uint32_t bits = __builtin_amdgcn_perm(br_e | dk_e, br_o | dk_o, SEL_ANS) & 0x80808080u & colmask;
+        // branch-free push: lanes without a survivor write the spare slot behind the queue (a branch around the store
+        // costs four scalar instructions per step, the select one vector instruction)
         const unsigned long long m = __ballot(bits != 0);
-        if (m) {                                                             // wave-uniform
-            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (bits) *(uint32_t*)((uint8_t*)s_g32 + ((slot << 2) + (uint32_t)(gn << 2))) = bits + entry0 + ((uint32_t)st << 8);   // answers | (score-tile row) << 8 | gc
-            gn += (int)__popcll(m);
-        }
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t at = bits ? (slot << 2) + (uint32_t)(gn << 2) : (uint32_t)(FT_GROUPS_X * FT_SCH * 4);
+        *(uint32_t*)((uint8_t*)s_g32 + at) = bits + entry0 + ((uint32_t)st << 8);       // answers | (score-tile row) << 8 | gc
+        gn += (int)__popcll(m);
     }
     __syncthreads();
 #if defined(FT_STOP_AFTER) && FT_STOP_AFTER == 2
