@@ -1505,6 +1505,62 @@ __device__ __forceinline__ uint32_t bd_vrow(const uint32_t (&q0)[4], const uint3
     return __builtin_amdgcn_perm(p23, p01, 0x06040200u);
 }
 
+// The sweep of one strip.  INSIDE: every input row (prefetched ones included) lies inside the image — no row reflection; EDGE:
+// the wavefront touches the left or right image edge — column fix-ups.  Both are wave-uniform and compiled apart so that the
+// common interior wavefront carries neither the branches nor the scalar bookkeeping of the other cases.
+template <bool INSIDE, bool EDGE>
+__device__ __forceinline__ void bd_strip(const uint8_t* img, const LevelGeom& lv, __amdgpu_buffer_rsrc_t drs, int x, int xb, int y0,
+                                         int nout, int nsteps, bool col_ok, const BdEdge& e)
+{
+    uint32_t W[BD_AHEAD][2][3];                             // prefetched windows: [step mod BD_AHEAD][row of the step][dword]
+    // input rows 2 step, 2 step + 1 of the strip (row 0 = y0 - 3); a row outside the image reflects once (|overshoot| <= 7 < h).
+    // Address = the level's scalar base + a 32-bit per-lane offset (row * stride is one scalar multiply).
+    auto fetch = [&](int step, uint32_t (&dst)[2][3]) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            int gy = y0 - 3 + 2 * step + r;
+            if (!INSIDE) gy = gy < 0 ? -gy : gy >= lv.h ? 2 * lv.h - 2 - gy : gy;
+            const uint32_t* q = (const uint32_t*)(img + ((uint32_t)(gy * lv.stride) + (uint32_t)xb));
+            dst[r][0] = q[0]; dst[r][1] = q[1]; dst[r][2] = q[2];
+        }
+    };
+    uint32_t Q[4][4];                                       // row pairs of the last four steps: [step mod 4][column]
+    auto hstep = [&](uint32_t (&src)[2][3], uint32_t (&q)[4]) {
+        uint32_t h0[4], h1[4];
+        uint32_t a0 = src[0][0], a1 = src[0][1], a2 = src[0][2], b0 = src[1][0], b1 = src[1][1], b2 = src[1][2];
+        if (EDGE) { bd_fix(a0, a1, a2, e); bd_fix(b0, b1, b2, e); }
+        bd_hpass(a0, a1, a2, h0); bd_hpass(b0, b1, b2, h1);
+#pragma unroll
+        for (int c = 0; c < 4; c++) q[c] = h0[c] | (h1[c] << 16);
+    };
+#pragma unroll
+    for (int u = 0; u < BD_AHEAD; u++) fetch(u, W[u]);
+    // priming: steps 0, 1, 2 (input rows y0-3 .. y0+2)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        hstep(W[k % BD_AHEAD], Q[k % 4]);
+        fetch(k + BD_AHEAD, W[k % BD_AHEAD]);
+    }
+    // step k = 3 + m: input rows y0+3+2m, y0+4+2m; output rows y0+2m (window = pairs k-3 .. k, even start) and y0+2m+1
+    uint32_t orow = (uint32_t)(y0 * lv.stride);
+    for (int m0 = 0; m0 < nsteps; m0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = m0 + j;
+            if (m >= nsteps) break;                         // wave-uniform
+            constexpr int K0 = 3;
+            const int ki = (K0 + j) % 4, wi = (K0 + j) % BD_AHEAD;       // ring slots of step k = 3 + m (m0 is a multiple of 4)
+            hstep(W[wi], Q[ki]);
+            fetch(K0 + m + BD_AHEAD, W[wi]);
+            const uint32_t r0 = bd_vrow<false>(Q[(ki + 1) % 4], Q[(ki + 2) % 4], Q[(ki + 3) % 4], Q[ki]);
+            const uint32_t r1 = bd_vrow<true>(Q[(ki + 1) % 4], Q[(ki + 2) % 4], Q[(ki + 3) % 4], Q[ki]);
+            __builtin_amdgcn_raw_buffer_store_b32(r0, drs, col_ok ? (uint32_t)x + orow : 0xfffffff0u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(r1, drs, col_ok && 2 * m + 1 < nout ? (uint32_t)x + orow + (uint32_t)lv.stride : 0xfffffff0u, 0, 0);
+            orow += 2u * (uint32_t)lv.stride;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_blur_direct(const uint8_t* pyr, uint8_t* blur, PyrGeom g, int total)
 {
     const int f = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1536,51 +1592,11 @@ __global__ __launch_bounds__(256) void k_blur_direct(const uint8_t* pyr, uint8_t
     const bool col_ok = x < lv.stride;
     const int nout = min(BD_R, lv.h - y0);                  // output rows of this strip
     const int nsteps = (nout + 1) / 2;                      // emitting steps; three priming steps come first
-
-    uint32_t W[BD_AHEAD][2][3];                             // prefetched windows: [step mod BD_AHEAD][row of the step][dword]
-    auto fetch = [&](int step, uint32_t (&dst)[2][3]) {     // input rows 2 step, 2 step + 1 of the strip (row 0 = y0 - 3)
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int gy = reflect101(y0 - 3 + 2 * step + r, lv.h);
-            const uint32_t* q = (const uint32_t*)(img + (size_t)gy * lv.stride + xb);
-            dst[r][0] = q[0]; dst[r][1] = q[1]; dst[r][2] = q[2];
-        }
-    };
-    uint32_t Q[4][4];                                       // row pairs of the last four steps: [step mod 4][column]
-    auto hstep = [&](uint32_t (&src)[2][3], uint32_t (&q)[4]) {
-        uint32_t h0[4], h1[4];
-        uint32_t a0 = src[0][0], a1 = src[0][1], a2 = src[0][2], b0 = src[1][0], b1 = src[1][1], b2 = src[1][2];
-        bd_fix(a0, a1, a2, e); bd_fix(b0, b1, b2, e);
-        bd_hpass(a0, a1, a2, h0); bd_hpass(b0, b1, b2, h1);
-#pragma unroll
-        for (int c = 0; c < 4; c++) q[c] = h0[c] | (h1[c] << 16);
-    };
-#pragma unroll
-    for (int u = 0; u < BD_AHEAD; u++) fetch(u, W[u]);
-    // priming: steps 0, 1, 2 (input rows y0-3 .. y0+2)
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        hstep(W[k % BD_AHEAD], Q[k % 4]);
-        fetch(k + BD_AHEAD, W[k % BD_AHEAD]);
-    }
-    // step k = 3 + m: input rows y0+3+2m, y0+4+2m; output rows y0+2m (window = pairs k-3 .. k, even start) and y0+2m+1
-    uint32_t orow = (uint32_t)(y0 * lv.stride);
-    for (int m0 = 0; m0 < nsteps; m0 += 4) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int m = m0 + j;
-            if (m >= nsteps) break;                         // wave-uniform
-            constexpr int K0 = 3;
-            const int ki = (K0 + j) % 4, wi = (K0 + j) % BD_AHEAD;       // ring slots of step k = 3 + m (m0 is a multiple of 4)
-            hstep(W[wi], Q[ki]);
-            fetch(K0 + m + BD_AHEAD, W[wi]);
-            const uint32_t r0 = bd_vrow<false>(Q[(ki + 1) % 4], Q[(ki + 2) % 4], Q[(ki + 3) % 4], Q[ki]);
-            const uint32_t r1 = bd_vrow<true>(Q[(ki + 1) % 4], Q[(ki + 2) % 4], Q[(ki + 3) % 4], Q[ki]);
-            __builtin_amdgcn_raw_buffer_store_b32(r0, drs, col_ok ? (uint32_t)x + orow : 0xfffffff0u, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(r1, drs, col_ok && 2 * m + 1 < nout ? (uint32_t)x + orow + (uint32_t)lv.stride : 0xfffffff0u, 0, 0);
-            orow += 2u * (uint32_t)lv.stride;
-        }
-    }
+    const bool inside = y0 >= 3 && y0 - 3 + 2 * (nsteps + 3 + BD_AHEAD) <= lv.h, edge = e.left || e.right;
+    if (inside && !edge) bd_strip<true, false>(img, lv, drs, x, xb, y0, nout, nsteps, col_ok, e);
+    else if (inside) bd_strip<true, true>(img, lv, drs, x, xb, y0, nout, nsteps, col_ok, e);
+    else if (!edge) bd_strip<false, false>(img, lv, drs, x, xb, y0, nout, nsteps, col_ok, e);
+    else bd_strip<false, true>(img, lv, drs, x, xb, y0, nout, nsteps, col_ok, e);
 }
 
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F)
