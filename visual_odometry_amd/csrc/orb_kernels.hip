@@ -9,6 +9,7 @@
 // All integer stages are bit-exact against oracle/voo_orb.c; float stages use the same operation
 // order (the library is compiled with -ffp-contract=off).
 #include "vo_internal.h"
+#include <type_traits>
 #include <float.h>
 #include <stdlib.h>
 
@@ -320,6 +321,16 @@ __global__ __launch_bounds__(RS2_THREADS) void k_resize_strip(uint8_t* pyr, int 
     }
 }
 
+// f(integral_constant<int, I>) for I = 0, 1, ... while I < n (n <= N, wave-uniform): nested ifs, every index a compile-time
+// constant inside f (`#pragma unroll` gives up on a loop with a run-time trip count and an early exit)
+template <int I, int N, typename F>
+__device__ __forceinline__ void unroll_while(int n, F& f)
+{
+    if constexpr (I < N) {
+        if (I < n) { f(std::integral_constant<int, I>{}); unroll_while<I + 1, N>(n, f); }
+    }
+}
+
 // Direct version of the strip kernel: the same per-lane arithmetic (4 destination columns per lane, source rows swept top to
 // bottom, the two live row results in registers), but a lane reads its 12-byte source window of every row straight from
 // global memory (three dwords at a 4-byte aligned address; neighbouring lanes' windows overlap and coalesce in the
@@ -347,9 +358,10 @@ __global__ __launch_bounds__(RS2_THREADS) void k_resize_direct(uint8_t* pyr, int
     // no memory operation besides the window prefetches inside the sweep, so their s_waitcnt can leave RS3_AHEAD - 1 rows in flight
     static_assert(RS2_WH <= 64, "one lane per destination row of the strip");
     const int li = min(dy0 + lane, dst.h - 1);
-    const int yo_l = tab.yofs[li], yc_l = (int)tab.yc1[li];
+    const int yo_l = tab.yofs[li];
+    const uint32_t yw1 = tab.yc1[li];
+    const int yc_l = (int)((256u - yw1) | (yw1 << 16));      // the (upper, lower) 8.8 weight pair of the row, as v_dot2_u32_u16 takes it
     const int yo_first = __builtin_amdgcn_readlane(yo_l, 0), yo_last = __builtin_amdgcn_readlane(yo_l, dy1 - 1 - dy0);
-    const uint32_t wy_first = (uint32_t)__builtin_amdgcn_readlane(yc_l, 0);
     // per-lane column constants: window start, byte shift, selectors of the 4 + 4 source bytes, 8.8 weights
     const int base = o[0] & ~3, sh = o[0] - base;
     const uint32_t q1 = (uint32_t)(o[1] - o[0]), q2 = (uint32_t)(o[2] - o[0]), q3 = (uint32_t)(o[3] - o[0]);
@@ -357,65 +369,65 @@ __global__ __launch_bounds__(RS2_THREADS) void k_resize_direct(uint8_t* pyr, int
     const uint32_t sel_be = sel_ae + 0x00010001u, sel_bo = sel_ao + 0x00010001u;
     const uint32_t c1e = (uint32_t)c1[0] | ((uint32_t)c1[2] << 16), c1o = (uint32_t)c1[1] | ((uint32_t)c1[3] << 16);
     const int r_first = yo_first, r_end = yo_last + 2;          // source rows this wavefront sweeps (wave-uniform); a row past the image repeats the last one
+    // which of those rows complete a destination row: bit (yofs[dy] + 1 - r_first), OR-ed over the strip's rows (every source
+    // row is the lower row of at most one destination row: checked when the tables are built)
+    static_assert((RS2_WH * 127 + 99) / 100 + 3 <= 32, "the emit mask of a strip fits 32 bits");
+    uint32_t emask = dy0 + lane < dy1 ? 1u << (yo_l + 1 - r_first) : 0u;
+#pragma unroll
+    for (int d = 1; d < RS2_WH; d <<= 1) emask |= (uint32_t)__shfl_xor((int)emask, d, 64);
+    emask = (uint32_t)__builtin_amdgcn_readfirstlane((int)emask);
     // stores go through a buffer descriptor of the destination level: an offset past its end is dropped by the hardware, which
     // is how a row that emits nothing "stores" without a branch around the instruction
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(pyr + (size_t)f * frame_bytes + dst.off, 0, dst.stride * dst.h, 0x00020000);
     uint32_t out = (uint32_t)(dy0 * dst.stride + dx);
     const bool col_ok = dx < dst.stride;
-    const uint8_t* gp = sp + base;
+    const int hmax = src.h - 1;
     uint32_t w[RS3_AHEAD][3];
 #pragma unroll
-    for (int u = 0; u < RS3_AHEAD; u++) {
-        const uint32_t* q = (const uint32_t*)(gp + (size_t)min(r_first + u, src.h - 1) * src.stride);
+    for (int u = 0; u < RS3_AHEAD; u++) {                   // address = the level's scalar base + a 32-bit per-lane offset
+        const uint32_t* q = (const uint32_t*)(sp + ((uint32_t)(min(r_first + u, hmax) * src.stride) + (uint32_t)base));
         w[u][0] = q[0]; w[u][1] = q[1]; w[u][2] = q[2];
     }
-    // row schedule: destination row dy is emitted at source row yofs[dy] + 1 with the weight pair of yc1[dy]
-    int dy = dy0;
-    int e_at = r_first + 1;
-    uint32_t wy = wy_first;
-    int e_next = dy + 1 < dy1 ? __builtin_amdgcn_readlane(yo_l, 1) + 1 : -1;
-    uint32_t wy_next = dy + 1 < dy1 ? (uint32_t)__builtin_amdgcn_readlane(yc_l, 1) : 0u;
+    int dyi = 0;                                            // destination rows emitted so far (wave-uniform)
     uint32_t pe = 0, po = 0;                                // row results of the previous source row: (h0, h2), (h1, h3)
-    for (int r0 = r_first; r0 < r_end; r0 += RS3_AHEAD) {
-#pragma unroll
-        for (int u = 0; u < RS3_AHEAD; u++) {
-            const int r = r0 + u;
-            if (r >= r_end) break;                          // wave-uniform
-            const uint32_t w0 = w[u][0], w1 = w[u][1], w2 = w[u][2];
-            {   // the window of row r + RS3_AHEAD replaces this one
-                const uint32_t* q = (const uint32_t*)(gp + (size_t)min(r + RS3_AHEAD, src.h - 1) * src.stride);
-                w[u][0] = q[0]; w[u][1] = q[1]; w[u][2] = q[2];
-            }
-            const uint32_t x0w = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)sh), x1w = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)sh);
-            const uint32_t a_e = __builtin_amdgcn_perm(x1w, x0w, sel_ae), a_o = __builtin_amdgcn_perm(x1w, x0w, sel_ao);
-            const uint32_t b_e = __builtin_amdgcn_perm(x1w, x0w, sel_be), b_o = __builtin_amdgcn_perm(x1w, x0w, sel_bo);
-            // h = (a << 8) + c1 * (b - a) = (256 - c1) * a + c1 * b <= 65280: exact in the low 16 bits of the packed multiply-add
-            const vo_u16x2 h_e = __builtin_bit_cast(vo_u16x2, c1e) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_e, a_e)) + __builtin_bit_cast(vo_u16x2, a_e << 8);
-            const vo_u16x2 h_o = __builtin_bit_cast(vo_u16x2, c1o) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_o, a_o)) + __builtin_bit_cast(vo_u16x2, a_o << 8);
-            const uint32_t ce = __builtin_bit_cast(uint32_t, h_e), co = __builtin_bit_cast(uint32_t, h_o);
-            {   // the vertical blend and the store are issued for every source row (the store under a lane mask that is empty
-                // unless r is the lower source row of destination row dy): a fixed sequence of memory operations per row, so
-                // that the compiler's s_waitcnt bookkeeping can keep the prefetched rows in flight
-                const bool emit = r == e_at;                // wave-uniform
-                const vo_u16x2 wv = __builtin_bit_cast(vo_u16x2, (256u - wy) | (wy << 16));
-                const uint32_t d0 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x05040100u)), wv, 32768u, false);
-                const uint32_t d2 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x07060302u)), wv, 32768u, false);
-                const uint32_t d1 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x05040100u)), wv, 32768u, false);
-                const uint32_t d3 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x07060302u)), wv, 32768u, false);
-                // (sum + 2^15) >> 16 is byte 2 of each dot product (at most 255: no saturation needed)
-                const uint32_t t01 = __builtin_amdgcn_perm(d1, d0, 0x0c0c0602u), t23 = __builtin_amdgcn_perm(d3, d2, 0x0c0c0602u);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(t23, t01, 0x05040100u), drs, col_ok && emit ? out : 0xfffffff0u, 0, 0);
-                out += emit ? (uint32_t)dst.stride : 0u;
-                dy += emit ? 1 : 0;
-                const int dn = min(dy + 1, dy1 - 1) - dy0;
-                const int en2 = dy + 1 < dy1 ? __builtin_amdgcn_readlane(yo_l, dn) + 1 : -1;
-                const uint32_t wn2 = (uint32_t)__builtin_amdgcn_readlane(yc_l, dn);
-                e_at = emit ? e_next : e_at; wy = emit ? wy_next : wy;
-                e_next = emit ? en2 : e_next; wy_next = emit ? wn2 : wy_next;
-            }
-            pe = ce; po = co;
+    const int nrows = r_end - r_first;
+    constexpr int RS3_MAXR = (RS2_WH * 127 + 99) / 100 + 3; // source rows a strip can span at scale factors <= 1.27
+    // fully unrolled over the most rows a strip can have (the ring slot of a row is a compile-time constant: no register moves,
+    // one compare + branch of loop control per row)
+    auto row = [&](auto ic) {
+        constexpr int i = decltype(ic)::value, u = i % RS3_AHEAD;
+        const uint32_t w0 = w[u][0], w1 = w[u][1], w2 = w[u][2];
+        {   // the window of row i + RS3_AHEAD replaces this one
+            const uint32_t* q = (const uint32_t*)(sp + ((uint32_t)(min(r_first + i + RS3_AHEAD, hmax) * src.stride) + (uint32_t)base));
+            w[u][0] = q[0]; w[u][1] = q[1]; w[u][2] = q[2];
         }
-    }
+        const uint32_t x0w = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)sh), x1w = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)sh);
+        const uint32_t a_e = __builtin_amdgcn_perm(x1w, x0w, sel_ae), a_o = __builtin_amdgcn_perm(x1w, x0w, sel_ao);
+        const uint32_t b_e = __builtin_amdgcn_perm(x1w, x0w, sel_be), b_o = __builtin_amdgcn_perm(x1w, x0w, sel_bo);
+        // h = (a << 8) + c1 * (b - a) = (256 - c1) * a + c1 * b <= 65280: exact in the low 16 bits of the packed multiply-add
+        const vo_u16x2 h_e = __builtin_bit_cast(vo_u16x2, c1e) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_e, a_e)) + __builtin_bit_cast(vo_u16x2, a_e << 8);
+        const vo_u16x2 h_o = __builtin_bit_cast(vo_u16x2, c1o) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_o, a_o)) + __builtin_bit_cast(vo_u16x2, a_o << 8);
+        const uint32_t ce = __builtin_bit_cast(uint32_t, h_e), co = __builtin_bit_cast(uint32_t, h_o);
+        {   // the vertical blend and the store are issued for every source row (the store lands past the end of the buffer unless
+            // the row completes a destination row): a fixed sequence of memory operations per row, so that the compiler's
+            // s_waitcnt bookkeeping can keep the prefetched rows in flight; the schedule costs one v_readlane and a few
+            // scalar instructions per row
+            const bool emit = emask & 1u;                   // wave-uniform
+            emask >>= 1;
+            const vo_u16x2 wv = __builtin_bit_cast(vo_u16x2, __builtin_amdgcn_readlane(yc_l, dyi));     // weights of the next destination row
+            const uint32_t d0 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x05040100u)), wv, 32768u, false);
+            const uint32_t d2 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x07060302u)), wv, 32768u, false);
+            const uint32_t d1 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x05040100u)), wv, 32768u, false);
+            const uint32_t d3 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x07060302u)), wv, 32768u, false);
+            // (sum + 2^15) >> 16 is byte 2 of each dot product (at most 255: no saturation needed)
+            const uint32_t t01 = __builtin_amdgcn_perm(d1, d0, 0x0c0c0602u), t23 = __builtin_amdgcn_perm(d3, d2, 0x0c0c0602u);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(t23, t01, 0x05040100u), drs, col_ok && emit ? out : 0xfffffff0u, 0, 0);
+            out += emit ? (uint32_t)dst.stride : 0u;
+            dyi += emit ? 1 : 0;                            // <= RS2_WH: lane RS2_WH holds a valid (unused) weight pair too
+        }
+        pe = ce; po = co;
+    };
+    unroll_while<0, RS3_MAXR>(nrows, row);
 }
 
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F)
