@@ -855,7 +855,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
                 const bool inside = gr >= 1 && gr <= FAST_TH && cx >= 4 && cx < 4 + FAST_TW;      // the tile proper, not its ring
                 const bool win = inside && sv > c[-1] && sv > c[1] && sv > c[-FT_SCW - 1] && sv > c[-FT_SCW] && sv > c[-FT_SCW + 1] &&
                                  sv > c[FT_SCW - 1] && sv > c[FT_SCW] && sv > c[FT_SCW + 1];
-                if (has && !win) lose |= 1u << (k + h);
+                if (DENSE && has && !win) lose |= 1u << (k + h);       // the score map is an output of the stage API only
                 const bool keep = has && win && gx >= g.edge && gx < lv.w - g.edge && gy >= g.edge && gy < lv.h - g.edge;
                 if (keep) atomicAdd(&hist[((size_t)f * VO_MAX_LEVELS + l) * 256 + sv], 1u);
                 if (!DENSE) {
@@ -868,10 +868,12 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
                 }
             }
         }
-        __syncthreads();
-        for (int e0 = 0, k = 0; e0 < nc; e0 += 64, k++)
-            if ((lose >> k) & 1u) { const int q = s_q[e0 + lane]; s_sc[(q >> 8) * FT_SCW + (q & 255)] = 0; }
-        __syncthreads();
+        if (DENSE) {
+            __syncthreads();
+            for (int e0 = 0, k = 0; e0 < nc; e0 += 64, k++)
+                if ((lose >> k) & 1u) { const int q = s_q[e0 + lane]; s_sc[(q >> 8) * FT_SCW + (q & 255)] = 0; }
+            __syncthreads();
+        }
     } else {
         // the queue overflowed (extremely corner-dense tile): score every pixel of the tile + ring, dense NMS
         for (int i = lane; i < FT_SCH * (FAST_TW + 2); i += 64) {
