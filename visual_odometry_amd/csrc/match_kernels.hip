@@ -334,13 +334,13 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_fp4(const uint8_t* desc_x, co
         if (sg + 1 < nstages) { MF_GLDS(sg + 1, (sg + 1) & 1); }
         const uint8_t* sb = s_b[sg & 1];
         const int ng = active ? min(MF_STAGE_ROWS / 16, (nb - sg * MF_STAGE_ROWS + 15) >> 4) : 0;
-        for (int g = 0; g < ng; g++) {
+        // one 16-column group: both k-halves of the 16 x 16 x 256 product of the wave's four row blocks
+        auto group = [&](int g, v4f (&acc)[MM_RB]) {
             const int j0 = sg * MF_STAGE_ROWS + g * 16;
             float c0 = c_lane - (float)j0;
             if (j0 + 16 > nb && j0 + li >= nb) c0 = c_bad;
             const v4f cin = {c0, c0, c0, c0};
             v8i b[2];
-            v4f acc[MM_RB];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const v4i v = *(const v4i*)(sb + g * 2048 + (4 * s + lg) * 256 + li * 16);
@@ -350,6 +350,29 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_fp4(const uint8_t* desc_x, co
             for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[rb][0], b[0], cin, 4, 4, 0, 140, 0, 127);
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[rb][1], b[1], acc[rb], 4, 4, 0, 140, 0, 127);
+        };
+        // two groups per step: the 32 accumulators of a step fold into the running maxima with 16 three-input maxima
+        // (v_max3_i32) instead of 32 two-input ones — the kernel is bound by instruction issue, not by the matrix pipe
+        int g = 0;
+        for (; g + 1 < ng; g += 2) {
+            v4f acc0[MM_RB], acc1[MM_RB];
+            group(g, acc0); group(g + 1, acc1);
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k0 = __float_as_int(acc0[rb][r]), k1 = __float_as_int(acc1[rb][r]);
+                    if (KNN2) {
+                        best2[rb][r] = max(best2[rb][r], min(best[rb][r], k0));
+                        best[rb][r] = max(best[rb][r], k0);
+                        best2[rb][r] = max(best2[rb][r], min(best[rb][r], k1));
+                        best[rb][r] = max(best[rb][r], k1);
+                    } else best[rb][r] = max(max(best[rb][r], k0), k1);
+                }
+        }
+        if (g < ng) {
+            v4f acc[MM_RB];
+            group(g, acc);
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++)
 #pragma unroll
