@@ -323,6 +323,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_fp4(const uint8_t* desc_x, co
 
     const int nstages = (nb + MF_STAGE_ROWS - 1) / MF_STAGE_ROWS;
     const bool active = wrow0 < na;
+    v4f cin = {c_lane, c_lane, c_lane, c_lane};                  // accumulator start of column group 0; -16 per group
 #define MF_GLDS(stage, buf)                                                                                        \
     _Pragma("unroll") for (int q = 0; q < MF_LD; q++)                                                              \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)(stage) * (MF_STAGE_ROWS * 128) + (size_t)(q * MM_THREADS + tid) * 16), \
@@ -333,13 +334,14 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_fp4(const uint8_t* desc_x, co
         __syncthreads();
         if (sg + 1 < nstages) { MF_GLDS(sg + 1, (sg + 1) & 1); }
         const uint8_t* sb = s_b[sg & 1];
-        const int ng = active ? min(MF_STAGE_ROWS / 16, (nb - sg * MF_STAGE_ROWS + 15) >> 4) : 0;
-        // one 16-column group: both k-halves of the 16 x 16 x 256 product of the wave's four row blocks
-        auto group = [&](int g, v4f (&acc)[MM_RB]) {
-            const int j0 = sg * MF_STAGE_ROWS + g * 16;
-            float c0 = c_lane - (float)j0;
-            if (j0 + 16 > nb && j0 + li >= nb) c0 = c_bad;
-            const v4f cin = {c0, c0, c0, c0};
+        // column groups of this stage: full ones (16 valid columns, no masking) and possibly the batch's last, partial one
+        const int first = sg * (MF_STAGE_ROWS / 16);
+        const int ngf = active ? min(MF_STAGE_ROWS / 16, max((nb >> 4) - first, 0)) : 0;
+        const bool tail = active && (nb & 15) && first + ngf == (nb >> 4) && ngf < MF_STAGE_ROWS / 16;
+        // one 16-column group: both k-halves of the 16 x 16 x 256 product of the wave's four row blocks.  The accumulators start
+        // from cin = (tie-break / index term of the column) - 16 * (group index): one packed subtraction per group keeps it
+        // current (integers below 2^24: exact)
+        auto group = [&](int g, const v4f& c, v4f (&acc)[MM_RB]) {
             v8i b[2];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
@@ -347,16 +349,19 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_fp4(const uint8_t* desc_x, co
                 b[s] = __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1);
             }
 #pragma unroll
-            for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[rb][0], b[0], cin, 4, 4, 0, 140, 0, 127);
+            for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[rb][0], b[0], c, 4, 4, 0, 140, 0, 127);
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[rb][1], b[1], acc[rb], 4, 4, 0, 140, 0, 127);
         };
+        const v4f sixteen = {16.f, 16.f, 16.f, 16.f};
         // two groups per step: the 32 accumulators of a step fold into the running maxima with 16 three-input maxima
         // (v_max3_i32) instead of 32 two-input ones — the kernel is bound by instruction issue, not by the matrix pipe
         int g = 0;
-        for (; g + 1 < ng; g += 2) {
+        for (; g + 1 < ngf; g += 2) {
             v4f acc0[MM_RB], acc1[MM_RB];
-            group(g, acc0); group(g + 1, acc1);
+            const v4f c1 = cin - sixteen;
+            group(g, cin, acc0); group(g + 1, c1, acc1);
+            cin = c1 - sixteen;
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++)
 #pragma unroll
@@ -370,9 +375,12 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_fp4(const uint8_t* desc_x, co
                     } else best[rb][r] = max(max(best[rb][r], k0), k1);
                 }
         }
-        if (g < ng) {
+        for (; g < ngf + (tail ? 1 : 0); g++) {                 // an odd full group and / or the partial one
             v4f acc[MM_RB];
-            group(g, acc);
+            v4f c = cin;
+            if (g == ngf) { const float cm = (first + g) * 16 + li >= nb ? c_bad : cin[0]; c = (v4f){cm, cm, cm, cm}; }
+            group(g, c, acc);
+            cin = cin - sixteen;
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++)
 #pragma unroll
