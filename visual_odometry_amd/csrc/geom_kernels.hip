@@ -1027,10 +1027,26 @@ __global__ __launch_bounds__(1024) void k_pose(PairBuf pb, int kp_cap, RansacPar
         ninl += tot;
     }
     __syncthreads();
-    double E[9], R1[9], R2[9], tt[3];
+    // decomposeEssentialMat once (the first wavefront; sixteen waves doing it side by side took three times as long), shared through LDS
+    __shared__ double s_dec[21];
+    double R1[9], R2[9], tt[3];
+    if (threadIdx.x < 64) {
+        double E[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) E[k] = res->E[k];
-    decompose_essential(E, R1, R2, tt);
+        for (int k = 0; k < 9; k++) E[k] = res->E[k];
+        decompose_essential(E, R1, R2, tt);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) { s_dec[k] = R1[k]; s_dec[9 + k] = R2[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) s_dec[18 + k] = tt[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; k++) { R1[k] = s_dec[k]; R2[k] = s_dec[9 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) tt[k] = s_dec[18 + k];
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     {
         const int c = cand;                              // wave-uniform: four waves per candidate
