@@ -59,6 +59,20 @@ def test_blur_bit_exact(oracle, ctx, h, w):
         assert np.array_equal(got[l], ref), f"level {l}: {np.count_nonzero(got[l] != ref)} pixels differ"
 
 
+@pytest.mark.parametrize("sf,nlevels", [(1.1, 8), (1.2, 5), (1.25, 6), (1.27, 4), (1.3, 5), (1.5, 4), (2.0, 3)])
+def test_pyramid_and_blur_other_scale_factors(oracle, ctx, sf, nlevels):
+    """Scale factors on both sides of the direct pyramid kernel's limit (1.27): the strip / tiled / generic resize kernels and the
+    blur of every level against the oracle."""
+    img = random_image(21, 413, 634)
+    p = oracle.orb_params(nfeatures=300, scale_factor=sf, nlevels=nlevels)
+    sizes = _level_sizes(oracle, 413, 634, p)
+    det = _det(300, nlevels, scaleFactor=sf)
+    got_p, got_b = det.stage_levels("vo_stage_pyramid", img, sizes), det.stage_levels("vo_stage_blur", img, sizes)
+    for l, lvl in enumerate(oracle.pyramid(img, p)):
+        assert np.array_equal(got_p[l], lvl), f"pyramid level {l}"
+        assert np.array_equal(got_b[l], oracle.gaussian_blur7(lvl)), f"blur level {l}"
+
+
 def test_staged_kernels_equal_direct_ones(oracle, ctx, monkeypatch):
     """The LDS-staged pyramid / blur kernels stay in the library as fallbacks (VO_RESIZE_STRIP=1, VO_BLUR_DIRECT=0 and
     levels under 16 x 8 pixels): same bytes as the direct (no-LDS) kernels that run by default."""
