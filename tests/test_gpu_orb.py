@@ -73,6 +73,20 @@ def test_pyramid_and_blur_other_scale_factors(oracle, ctx, sf, nlevels):
         assert np.array_equal(got_b[l], oracle.gaussian_blur7(lvl)), f"blur level {l}"
 
 
+@pytest.mark.parametrize("h,w,nl", [(16, 16, 1), (17, 40, 2), (40, 17, 2), (24, 300, 3), (300, 24, 3), (9, 64, 1), (8, 16, 1), (33, 33, 4),
+                                    (20, 20, 3), (64, 19, 2), (19, 1000, 2), (1000, 19, 2), (21, 257, 1), (70, 260, 5)])
+def test_pyramid_and_blur_tiny_and_thin_images(oracle, ctx, h, w, nl):
+    """Images at and below the direct kernels' size limits (16 x 8 pixels per level), one tile wide or high, extreme aspect ratios:
+    the reflected borders of the blur and the clamped taps of the resize against the oracle."""
+    img = random_image(31, h, w)
+    p = oracle.orb_params(nfeatures=100, nlevels=nl)
+    sizes = _level_sizes(oracle, h, w, p)
+    det = _det(100, nl)
+    got_p, got_b = det.stage_levels("vo_stage_pyramid", img, sizes), det.stage_levels("vo_stage_blur", img, sizes)
+    for l, lvl in enumerate(oracle.pyramid(img, p)):
+        assert np.array_equal(got_p[l], lvl) and np.array_equal(got_b[l], oracle.gaussian_blur7(lvl)), (l, sizes[l])
+
+
 def test_staged_kernels_equal_direct_ones(oracle, ctx, monkeypatch):
     """The LDS-staged pyramid / blur kernels stay in the library as fallbacks (VO_RESIZE_STRIP=1, VO_BLUR_DIRECT=0 and
     levels under 16 x 8 pixels): same bytes as the direct (no-LDS) kernels that run by default."""
