@@ -83,8 +83,10 @@ def test_pyramid_and_blur_tiny_and_thin_images(oracle, ctx, h, w, nl):
     sizes = _level_sizes(oracle, h, w, p)
     det = _det(100, nl)
     got_p, got_b = det.stage_levels("vo_stage_pyramid", img, sizes), det.stage_levels("vo_stage_blur", img, sizes)
+    got_f = det.stage_levels("vo_stage_fast_scores", img, sizes)
     for l, lvl in enumerate(oracle.pyramid(img, p)):
         assert np.array_equal(got_p[l], lvl) and np.array_equal(got_b[l], oracle.gaussian_blur7(lvl)), (l, sizes[l])
+        assert np.array_equal(got_f[l], oracle.fast_score_nms(lvl, 20)), (l, sizes[l])
 
 
 def test_staged_kernels_equal_direct_ones(oracle, ctx, monkeypatch):
