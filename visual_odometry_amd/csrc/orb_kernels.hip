@@ -999,43 +999,23 @@ __global__ __launch_bounds__(64) void k_sel_rows(const uint32_t* tile_list, cons
         for (int d = 32; d >= 1; d >>= 1) base += __shfl_xor(base, d, 64);
     }
     int n = 0;                                        // wave-uniform: kept winners of this tile row
-    // The lists of a tile row are short (a dozen winners per tile) and the kernel is all load latency: the counts of the row's
-    // tiles come with one vector load (lane t = tile t), and the first 64 entries of eight tiles at a time are requested
-    // before any is looked at — two round trips to memory per eight tiles instead of sixteen.
-    auto take = [&](uint32_t e, bool valid, int t) {
-        const bool kept = valid && (int)(e >> 16) >= T;
-        const unsigned long long m = __ballot(kept);
-        if (EMIT) {
-            const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (kept && slot < lds_cap) {
-                const uint32_t gy = (uint32_t)(chunk * FAST_TH) + ((e >> 8) & 255u), gx = (uint32_t)(t * FAST_TW) + (e & 255u);
-                s_sel[slot] = (gy << 16) | gx;
-                s_sel[lds_cap + slot] = e >> 16;
-            }
-        }
-        n += (int)__popcll(m);
-    };
-    for (int tb = 0; tb < lv.ftiles_x; tb += 64) {                          // 64 tiles of the row per batch of counts (7168 pixels)
-        const int my_cnt = tb + lane < lv.ftiles_x ? min(tile_count[tile0 + tb + lane], FT_LISTCAP) : 0;
-        const int nt = min(64, lv.ftiles_x - tb);
-        for (int t0 = 0; t0 < nt; t0 += 8) {
-            uint32_t e[8]; int cnt[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int t = min(t0 + u, nt - 1);
-                cnt[u] = t0 + u < nt ? __builtin_amdgcn_readlane(my_cnt, t) : 0;
-                e[u] = lane < cnt[u] ? tile_list[(tile0 + tb + t) * FT_LISTCAP + lane] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (t0 + u >= nt) break;                                       // wave-uniform
-                const int t = tb + t0 + u;
-                take(e[u], lane < cnt[u], t);
-                for (int j0 = 64; j0 < cnt[u]; j0 += 64) {                    // rare: more than 64 winners in one tile
-                    const int j = j0 + lane;
-                    take(j < cnt[u] ? tile_list[(tile0 + t) * FT_LISTCAP + j] : 0u, j < cnt[u], t);
+    for (int t = 0; t < lv.ftiles_x; t++) {
+        const int cnt = min(tile_count[tile0 + t], FT_LISTCAP);
+        const uint32_t* lst = tile_list + (tile0 + t) * FT_LISTCAP;
+        for (int j0 = 0; j0 < cnt; j0 += 64) {
+            const int j = j0 + lane;
+            const uint32_t e = j < cnt ? lst[j] : 0u;
+            const bool kept = j < cnt && (int)(e >> 16) >= T;
+            const unsigned long long m = __ballot(kept);
+            if (EMIT) {
+                const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (kept && slot < lds_cap) {
+                    const uint32_t gy = (uint32_t)(chunk * FAST_TH) + ((e >> 8) & 255u), gx = (uint32_t)(t * FAST_TW) + (e & 255u);
+                    s_sel[slot] = (gy << 16) | gx;
+                    s_sel[lds_cap + slot] = e >> 16;
                 }
             }
+            n += (int)__popcll(m);
         }
     }
     if (!EMIT) {
