@@ -197,32 +197,8 @@ void launch_sift_refine(hipStream_t s, const SiftPyr& P, const SiftCand* cand, i
                         const SiftExpTab& E, SiftSurv* surv, int* nsurv, int cap_surv, SiftKp* kps, int* nkp, int cap);
 void launch_sift_descriptor(hipStream_t s, const SiftPyr& P, const SiftKp* kps, int nkp, const SiftExpTab& E, float* desc);
 
-// ---- JPEG decode (jpeg_kernels.hip): cv2.imread in front of the path
-#define JPG_NT 512               // threads of the two entropy kernels = subsequences per image
-#define JPG_LOOK 10              // bits of Huffman look-ahead table
-#define JPG_PAD 16               // zero bytes after every clean stream
-#define JPG_MAX_BPM 10           // blocks per MCU (T.81 limit)
-struct JpegImage {               // one file of a batch: geometry from the headers + where its data lives in the batch buffers
-    uint32_t raw_off, raw_len, hdr_len;          // entropy-coded bytes in the blob (from the end of the SOS header to the end of the file)
-    uint32_t clean_off, clean_len;               // the same without stuffing / restart markers (written by k_jpeg_unstuff)
-    uint32_t rst_off, rst_cap, nrst;             // restart positions (clean-stream byte offsets)
-    uint32_t sync_rounds;                        // diagnostic: propagation rounds k_jpeg_huffman needed
-    uint32_t coef_blk;                           // first 8x8 block in the coefficient buffer
-    uint32_t out_stride;
-    uint64_t plane_off[3], out_off;
-    int32_t W, H, nc, mx, my, ri, ycc, bpm, total_blocks, mode /*0: 4:4:4 or grey, 1: h2v1, 2: h2v2*/, orientation;
-    int32_t ch[3], cv[3], bw[3], bh[3], dw[3], dh[3], tq[3], td[3], ta[3];
-    uint8_t blk_comp[JPG_MAX_BPM], blk_bx[JPG_MAX_BPM], blk_by[JPG_MAX_BPM];
-};
-struct JpegTables {
-    uint16_t q[4][64];                           // quantisation tables, natural order
-    uint16_t lut[8][1 << JPG_LOOK];              // slots 0-3: DC tables, 4-7: AC tables; (code length << 8) | symbol, 0 = longer code
-    int32_t maxcode[8][18], valoff[8][18];
-    uint8_t vals[8][256];
-};
-int jpeg_info(const uint8_t* d, size_t n, int* h, int* w, int* ncomp, int* sampling, int* orientation);
-int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why, const uint8_t* prev_hdr = nullptr,
-               size_t prev_hdr_len = 0, const JpegImage* prev_img = nullptr, const JpegTables* prev_T = nullptr);
+// ---- JPEG decode (jpeg_kernels.hip, jpeg_host.cpp): cv2.imread in front of the path
+#include "jpeg_host.h"
 void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
                         int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h);
 
