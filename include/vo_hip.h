@@ -269,6 +269,20 @@ int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, in
                                float* kp_xy /*cap x 2*/, float* kp_size, float* kp_angle, float* kp_response, int32_t* kp_octave,
                                float* desc /*cap x 128*/, int cap, int32_t* n_out);
 
+/* The same detector as the detector of the batched, HBM-resident path — the configuration the reference runs live:
+ * cv2.SIFT_create() (src/visual_slam.py:17, injected at :21) + cv2.BFMatcher(cv2.NORM_L2, crossCheck=True) (:19), per pair
+ * in the order of src/visual_slam.py:294-298.  After vo_batch_configure_sift the calls vo_frames_upload[_async],
+ * vo_frames_detect[_async], vo_pairs_run[_async], vo_pair_matches, vo_pairs_gather and vo_sync act on the SIFT state
+ * (vo_batch_configure switches back to ORB).  Frames are detected in sub-batches whose float scale space (5 Gaussian + 5 DoG
+ * planes per octave of the 2x up-sampled image) is scratch; keypoints, the 128-byte descriptors (integer bin values 0..255),
+ * and the int8 operand image of the matrix-core L2 matcher stay resident per slot.  nfeatures must be 0 (cv2's default: keep
+ * every keypoint); kp_cap = keypoints kept per frame (0: a default from the frame size, rounded up to 256); a frame with more
+ * is truncated in cv2's list order and flagged (VO_WARN_CAPACITY from vo_frame_features_sift). */
+int vo_batch_configure_sift(vo_ctx* ctx, int h, int w, const vo_sift_params* params, int max_frames, int max_pairs, int kp_cap);
+/* like vo_frame_features; desc: cap x 128 bytes = the descriptor values cv2 hands out as float32 */
+int vo_frame_features_sift(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                           int32_t* kp_octave, uint8_t* desc /*cap x 128*/, int cap, int32_t* n_out);
+
 /* cv2.imread(filename) for a .jpg — /root/reference/src/visual_slam.py:346 (also triangulate_points_from_images.py:14-15,
  * feature_detection.py:5,10).  What cv2 does with such a file is libjpeg-turbo's default decompression: baseline Huffman
  * decoding, the 13-bit integer IDCT (JDCT_ISLOW), triangle-filter ("fancy") chroma upsampling, fixed-point YCbCr -> RGB,
@@ -307,7 +321,7 @@ int vo_feature_tracks(vo_ctx* ctx, int F, int cap, const int32_t* pair_frames, c
  * With profiling on, every kernel family of the batched path is bracketed by hipEvents on the
  * ctx stream; vo_profile_read returns accumulated milliseconds and launch counts per stage since
  * the last vo_profile_reset. */
-#define VO_STAGE_COUNT 16
+#define VO_STAGE_COUNT 24
 int vo_profile_enable(vo_ctx* ctx, int on);
 int vo_profile_reset(vo_ctx* ctx);
 int vo_profile_read(vo_ctx* ctx, float* ms /*VO_STAGE_COUNT*/, int32_t* launches /*VO_STAGE_COUNT*/);

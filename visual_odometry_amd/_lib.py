@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VO_HIP_LIBRARY") or os.path.join(_HERE, "libvo_hip.so
 VO_OK, VO_WARN_CAPACITY = 0, 1
 VO_ERR_INVALID, VO_ERR_HIP, VO_ERR_TOO_FEW, VO_ERR_NO_MODEL, VO_ERR_NOT_CONFIGURED, VO_ERR_AMBIGUOUS = -1, -2, -3, -4, -5, -6
 VO_ERR_UNSUPPORTED = -7
-VO_STAGE_COUNT = 16
+VO_STAGE_COUNT = 24
 VO_COMM_ID_BYTES, VO_RECORD_DOUBLES = 128, 16
 
 
@@ -90,6 +90,8 @@ _SIGS = {
     "vo_resize_area": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vo_frames_ingest": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, _P]),
     "vo_sift_detect_and_compute": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "vo_batch_configure_sift": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "vo_frame_features_sift": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "vo_jpeg_info": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, _P]),
     "vo_jpeg_decode": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, C.c_int, _P, _P]),
     "vo_jpeg_decode_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int]),

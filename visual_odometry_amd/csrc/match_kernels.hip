@@ -440,6 +440,135 @@ void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, 
     else if (dirs_mask == 2) hipLaunchKernelGGL(k_nn_mfma<false>, dim3(gx * P, 1, 1), block, 0, s, desc_x, kp_count, kp_cap, cap_x, pb, 1, gx);
 }
 
+// ------------------------------------------------------------------ L2 nearest neighbours of SIFT rows on the matrix cores
+// cv2.BFMatcher(cv2.NORM_L2, crossCheck=True) on SIFT descriptors (the reference's LIVE matcher, src/visual_slam.py:19).  A SIFT
+// descriptor element is an integer 0..255 stored as float: every (a - b)^2 and every partial sum of normL2Sqr_ is an integer
+// below 2^24, so the float sum IS the exact integer d^2 = |a|^2 + |b|^2 - 2 a.b whatever the summation order — and that
+// identity can be evaluated on v_mfma_i32_16x16x64_i8 with the rows shifted to int8 (v - 128; a distance does not see a
+// common shift).  batchDistance then stores sqrtf(d^2) and selects on those floats with strict `<`: sqrtf is strictly
+// increasing on the integers below 2^22 (tests/test_oracle_properties.py checks all of them) and k_sb_descriptor flags any row
+// whose norm would allow a larger d^2, so ordering by the integer d^2 (ties to the lower index) is the same selection.
+// Operand image (written by k_sb_descriptor): [frame][group = row / 16][chunk 0..7][row % 16][16 B], norms[frame][row] = |v - 128|^2.
+// Per 16-column group a wave forms dot products for its 64 rows (2 MFMAs per 16 x 16 block), val = 2 dot - |b|^2 (larger =
+// nearer), and keeps per lane the best (and second best) value with the group it came from: strict > keeps the earliest.
+#define L8_STAGE_ROWS 128
+#define L8_LD (L8_STAGE_ROWS * 128 / 16 / MM_THREADS)
+template <bool KNN2>
+__global__ __launch_bounds__(MM_THREADS) void k_nn_l2i8(const uint8_t* desc_x, const int* norms, const int* kp_count, int kp_cap, int cap_x,
+                                                 PairBuf pb, int dir_first, int row_blocks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[2][L8_STAGE_ROWS * 128];
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int p = bid / row_blocks, dir = dir_first + blockIdx.z;
+    const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
+    const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
+    const int row0 = (bid % row_blocks) * MM_BLOCK_ROWS;
+    if (row0 >= na) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const uint8_t* A = desc_x + (size_t)fa * cap_x * 128;
+    const uint8_t* B = desc_x + (size_t)fb * cap_x * 128;
+    const int* nB = norms + (size_t)fb * cap_x;
+    const int wrow0 = row0 + wave * MM_WAVE_ROWS;
+
+    v4i a[MM_RB][2];
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            a[rb][s] = wrow0 < na ? *(const v4i*)(A + ((size_t)((wrow0 >> 4) + rb) * 8 + 4 * s + lg) * 256 + li * 16) : (v4i){0, 0, 0, 0};
+    v4i bv[MM_RB], bg[MM_RB], bv2[MM_RB], bg2[MM_RB];
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++) { bv[rb] = (v4i){INT_MIN, INT_MIN, INT_MIN, INT_MIN}; bg[rb] = (v4i){-1, -1, -1, -1}; bv2[rb] = bv[rb]; bg2[rb] = bg[rb]; }
+
+    const int nstages = (nb + L8_STAGE_ROWS - 1) / L8_STAGE_ROWS;
+    const bool active = wrow0 < na;
+#define L8_GLDS(stage, buf)                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < L8_LD; q++)                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)(stage) * (L8_STAGE_ROWS * 128) + (size_t)(q * MM_THREADS + tid) * 16), \
+                                         (__attribute__((address_space(3))) void*)(s_b[buf] + (q * MM_THREADS + wave * 64) * 16), 16, 0, 0)
+    if (nstages > 0) { L8_GLDS(0, 0); }
+    for (int sg = 0; sg < nstages; sg++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (sg + 1 < nstages) { L8_GLDS(sg + 1, (sg + 1) & 1); }
+        const uint8_t* sb = s_b[sg & 1];
+        const int ng = active ? min(L8_STAGE_ROWS / 16, (nb - sg * L8_STAGE_ROWS + 15) >> 4) : 0;
+        for (int g = 0; g < ng; g++) {
+            const int gi = sg * (L8_STAGE_ROWS / 16) + g, j = gi * 16 + li;
+            const int nbj = j < nb ? nB[j] : 0x3fffffff;          // columns past the end can never win
+            v4i b[2], acc[MM_RB];
+#pragma unroll
+            for (int s = 0; s < 2; s++) b[s] = *(const v4i*)(sb + g * 2048 + (4 * s + lg) * 256 + li * 16);
+            const v4i zero = {0, 0, 0, 0};
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][0], b[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][1], b[1], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int val = 2 * acc[rb][r] - nbj;
+                    if (KNN2) {
+                        const bool gt1 = val > bv[rb][r], gt2 = val > bv2[rb][r];
+                        bv2[rb][r] = gt1 ? bv[rb][r] : gt2 ? val : bv2[rb][r];
+                        bg2[rb][r] = gt1 ? bg[rb][r] : gt2 ? gi : bg2[rb][r];
+                        bv[rb][r] = gt1 ? val : bv[rb][r];
+                        bg[rb][r] = gt1 ? gi : bg[rb][r];
+                    } else {
+                        const bool gt1 = val > bv[rb][r];
+                        bv[rb][r] = gt1 ? val : bv[rb][r];
+                        bg[rb][r] = gt1 ? gi : bg[rb][r];
+                    }
+                }
+        }
+    }
+#undef L8_GLDS
+    // fold the 16 lanes (columns li of every group) of a row: 64-bit keys (value + 2^31) << 32 | ~column — larger value first,
+    // then the lower column
+    const int* nA = norms + (size_t)fa * cap_x;
+    const size_t o = ((size_t)p * 2 + dir) * kp_cap, o2 = (size_t)p * kp_cap;
+#pragma unroll
+    for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            auto mk = [&](int v, int g) -> unsigned long long {
+                return g < 0 ? 0ull : ((unsigned long long)((unsigned)v ^ 0x80000000u) << 32) | (unsigned)(0x7fffffff - (g * 16 + li));
+            };
+            unsigned long long k0 = mk(bv[rb][r], bg[rb][r]), k1 = KNN2 ? mk(bv2[rb][r], bg2[rb][r]) : 0ull;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const unsigned long long u0 = __shfl_xor(k0, d, 64), u1 = __shfl_xor(k1, d, 64);
+                if (KNN2) { const unsigned long long lo = k0 < u0 ? k0 : u0; k1 = k1 > u1 ? k1 : u1; k1 = k1 > lo ? k1 : lo; }
+                k0 = k0 > u0 ? k0 : u0;
+            }
+            const int row = wrow0 + rb * 16 + lg * 4 + r;
+            if (li == 0 && row < na) {
+                const int na2 = nA[row];
+                const int v0 = (int)((unsigned)(k0 >> 32) ^ 0x80000000u), j0 = 0x7fffffff - (int)(k0 & 0xffffffffu);
+                pb.nn_idx[o + row] = k0 ? j0 : -1;
+                pb.nn_dist[o + row] = k0 ? na2 - v0 : INT_MAX;
+                if (KNN2) {
+                    const int v1 = (int)((unsigned)(k1 >> 32) ^ 0x80000000u), j1 = 0x7fffffff - (int)(k1 & 0xffffffffu);
+                    pb.nn_idx2[o2 + row] = k1 ? j1 : -1;
+                    pb.nn_dist2[o2 + row] = k1 ? na2 - v1 : INT_MAX;
+                }
+            }
+        }
+}
+
+void launch_match_nn_l2i8(hipStream_t s, const uint8_t* desc_x, const int* norms, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,
+                          int dirs_mask, int knn2)
+{
+    if (P <= 0) return;
+    dim3 block(MM_THREADS);
+    const int gx = (kp_cap + MM_BLOCK_ROWS - 1) / MM_BLOCK_ROWS;
+    if (knn2) hipLaunchKernelGGL(k_nn_l2i8<true>, dim3(gx * P, 1, 1), block, 0, s, desc_x, norms, kp_count, kp_cap, cap_x, pb, 0, gx);
+    else if (dirs_mask == 3) hipLaunchKernelGGL(k_nn_l2i8<false>, dim3(gx * P, 1, 2), block, 0, s, desc_x, norms, kp_count, kp_cap, cap_x, pb, 0, gx);
+    else hipLaunchKernelGGL(k_nn_l2i8<false>, dim3(gx * P, 1, 1), block, 0, s, desc_x, norms, kp_count, kp_cap, cap_x, pb, dirs_mask == 2 ? 1 : 0, gx);
+}
+
 // ------------------------------------------------------------------ match selection + ordered compaction, one workgroup per pair
 // mode 0: nearest neighbour; 1: legacy cross-check (batchDistance reverse-NN update without the forward test,
 // strict <, ascending train index == 64-bit atomic min of (dist << 32 | train)); 2: cv2 4.x crossCheck=True =
@@ -463,7 +592,7 @@ __device__ __forceinline__ int excl_scan_256(int v, int* s_w, int* total)
 }
 
 __global__ __launch_bounds__(256) void k_match_select(const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb,
-                                                      int mode, double ratio, const double* Kd)
+                                                      int mode, double ratio, const double* Kd, int l2)
 {
     extern __shared__ unsigned long long s_best[];      // [kp_cap] for mode 1
     __shared__ int s_w[4];
@@ -497,13 +626,15 @@ __global__ __launch_bounds__(256) void k_match_select(const float* kp_xy, const 
             else {
                 const int d1 = pb.nn_dist2[op + q];
                 t = fidx[q]; d = fdist[q];
-                if (nt < 2 || !((double)(float)d < ratio * (double)(float)d1)) t = -1;
+                // (L2: batchDistance hands knnMatch sqrt(normL2Sqr) as float; Hamming: the integer distance as float)
+                const float fd = l2 ? sqrtf((float)d) : (float)d, fd1 = l2 ? sqrtf((float)d1) : (float)d1;
+                if (nt < 2 || !((double)fd < ratio * (double)fd1)) t = -1;
             }
         }
         int tot;
         const int pos = out_base + excl_scan_256(t >= 0 ? 1 : 0, s_w, &tot);
         if (t >= 0) {
-            pb.m_q[op + pos] = q; pb.m_t[op + pos] = t; pb.m_d[op + pos] = (float)d;
+            pb.m_q[op + pos] = q; pb.m_t[op + pos] = t; pb.m_d[op + pos] = l2 ? sqrtf((float)d) : (float)d;
             const double u1 = (double)xy1[2 * q], v1 = (double)xy1[2 * q + 1];
             const double u2 = (double)xy2[2 * t], v2 = (double)xy2[2 * t + 1];
             const size_t o = (op + pos) * 2;
@@ -520,13 +651,13 @@ __global__ __launch_bounds__(256) void k_match_select(const float* kp_xy, const 
 }
 
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
-                         int mode, double ratio, const double* K)
+                         int mode, double ratio, const double* K, int l2)
 {
     if (P <= 0) return;
     size_t shmem = mode == 1 ? (size_t)kp_cap * 8 : 8;
     // above the 64 KB default a workgroup must opt in to its dynamic LDS (the API layer bounds kp_cap * 8 by 160 KB)
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_match_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_match_select, dim3(P), dim3(256), shmem, s, kp_xy, kp_count, kp_cap, pb, mode, ratio, K);
+    hipLaunchKernelGGL(k_match_select, dim3(P), dim3(256), shmem, s, kp_xy, kp_count, kp_cap, pb, mode, ratio, K, l2);
 }
 
 // ------------------------------------------------------------------ BFMatcher(NORM_L2) on float descriptors

@@ -1,0 +1,808 @@
+// sift_batch.hip — the reference's LIVE detector, frame-batched and HBM-resident: cv2.SIFT_create() at
+// /root/reference/src/visual_slam.py:17, detector.detectAndCompute(image, None) (src/frame_generator.py:25-26).
+// Stage for stage what OpenCV 4.7's features2d/src/sift.dispatch.cpp + sift.simd.hpp do (defaults: 3 layers per octave,
+// contrast 0.04, edge 10, sigma 1.6), every float operation rounded on its own (-ffp-contract=off) in the operation order
+// of OpenCV's scalar code, so that keypoints and descriptors equal the CPU oracle's (oracle/voo_sift.c) bit for bit.
+//
+// Every kernel takes a batch of frames (grid.z or grid.y = frame); nothing returns to the host between the stages —
+// candidate / survivor / keypoint counts stay in HBM.  One frame's scale space is 5 Gaussian + 5 DoG float planes per
+// octave (the 6th Gaussian of an octave only exists inside the kernel that forms the last DoG plane):
+//   k_sb_base        gray -> float -> 2x INTER_LINEAR up-sampling (createInitialImage)
+//   k_sb_sweep<N>    ONE pass per scale-space layer: separable float Gaussian (BORDER_REFLECT_101; row taps left to right,
+//                    column taps centre first then symmetric pairs: RowFilter / SymmColumnFilter) + the DoG plane
+//                    G[i] - G[i-1], formed while G[i-1] is still in LDS.  A workgroup owns a 128-column strip and sweeps
+//                    it top to bottom eight rows at a time: rows stream HBM -> registers -> LDS one step ahead of their use,
+//                    row-filtered rows live in an LDS ring, every source plane is read once and every output written once
+//   k_sb_half        INTER_NEAREST half-size (first image of the next octave)
+//   k_sb_extrema     26-neighbour extrema of the DoG stack above the contrast pre-threshold, from an LDS tile of the five
+//                    DoG planes: a pixel is an extremum iff it equals the max (min) of the 3 x 3 x 3 block
+//   k_sb_refine      lane per candidate: adjustLocalExtrema (<= 5 steps, Matx33f::solve closed form), contrast and edge tests
+//   k_sb_orient      wavefront per refined extremum: calcOrientationHist (cv::exp32f's table algorithm, cv::fastAtan2); the 36
+//                    bins are owned by 36 lanes that add their samples in window order (bit masks by LDS atomic OR)
+//   k_sb_rank / k_sb_emit   KeyPointsFilter::removeDuplicatedSorted on the device: rank of every record under
+//                    KeyPoint_LessThan (all-pairs count on 64-bit (x, y) keys, full comparator on ties), scatter, drop repeats
+//   k_sb_descriptor  wavefront per keypoint: calcSIFTDescriptor.  The window is first compacted to the samples that fall
+//                    inside the rotated 4 x 4 grid; 64 of them are evaluated in parallel (gradient, fastAtan2, exp32f,
+//                    trilinear split); the 128 + 16 histogram bins that matter live in REGISTERS of their owner lanes
+//                    (lane = inner cell x orientation-bin pair), which add their samples in window order.
+#include "vo_internal.h"
+#include <float.h>
+#include <math.h>
+
+// ------------------------------------------------------------------ helpers shared with the oracle's definitions
+__device__ __forceinline__ float sift_atan2_deg(float y, float x)            // cv::fastAtan2
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ float sift_expf(float x, const float* tab)       // cv::hal::exp32f, scalar form
+{
+    const double prescale = 1.4426950408889634073599246810019 * 64;
+    const float A4 = (float)(1.000000000000002438532970795181890933776 / 1.000000000000002438532970795181890933776),
+                A3 = (float)(.6931471805521448196800669615864773144641 / 1.000000000000002438532970795181890933776),
+                A2 = (float)(.2402265109513301490103372422686535526573 / 1.000000000000002438532970795181890933776),
+                A1 = (float)(.5550339366753125211915322047004666939128e-1 / 1.000000000000002438532970795181890933776);
+    const float minval = (float)(-3000. * 64 / prescale), maxval = (float)(3000. * 64 / prescale), postscale = (float)(1. / 64);
+    float x0 = x < minval ? minval : x > maxval ? maxval : x;
+    x0 = x0 * (float)prescale;
+    const int xi = __float2int_rn(x0);
+    x0 = (x0 - (float)xi) * postscale;
+    int t = (xi >> 6) + 127;
+    t = !(t & ~255) ? t : t < 0 ? 0 : 255;
+    return __int_as_float(t << 23) * tab[xi & 63] * ((((x0 + A1) * x0 + A2) * x0 + A3) * x0 + A4);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; }
+
+// ------------------------------------------------------------------ base image
+__global__ __launch_bounds__(256) void k_sb_base(const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh,
+                                                 float* dst, int dstride, size_t dframe)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y, dw = 2 * sw;
+    if (dx >= dw) return;
+    src += (size_t)blockIdx.z * frame_stride;
+    float fx = (float)((dx + 0.5) * 0.5 - 0.5), fy = (float)((dy + 0.5) * 0.5 - 0.5);
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx; fy -= (float)sy;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    if (sy < 0) { fy = 0; sy = 0; }
+    if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+    const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
+    auto px = [&](int y, int x) -> float {
+        const uint8_t* p = src + (size_t)y * row_stride + (size_t)x * channels;
+        const int v = channels == 1 ? p[0] : (p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15;
+        return (float)v;
+    };
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const float r0 = px(sy, sx) * a0 + px(sy, sx1) * a1, r1 = px(sy1, sx) * a0 + px(sy1, sx1) * a1;
+    dst[(size_t)blockIdx.z * dframe + (size_t)dy * dstride + dx] = r0 * b0 + r1 * b1;
+}
+
+__global__ __launch_bounds__(256) void k_sb_half(const float* src, size_t sframe, int sw, int sh, int sstride,
+                                                 float* dst, size_t dframe, int dw, int dh, int dstride)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const double fx = (double)sw / dw, fy = (double)sh / dh;
+    const int sx = min((int)floor(x * fx), sw - 1), sy = min((int)floor(y * fy), sh - 1);
+    dst[(size_t)blockIdx.z * dframe + (size_t)y * dstride + x] = src[(size_t)blockIdx.z * sframe + (size_t)sy * sstride + sx];
+}
+
+// ------------------------------------------------------------------ one scale-space layer: Gaussian blur + DoG, one sweep
+#define SW_TW 128                      // columns of a strip
+#define SW_RS 8                        // source rows per step
+#define SW_THREADS 256
+struct SiftTaps { int n; float k[SIFT_MAX_TAPS]; };
+
+// N > 0: tap count known at compile time (windows in registers); N == 0: any odd tap count <= SW_NMAX, taken from t.n
+#define SW_NMAX 63
+template <int N>
+struct SweepDims {
+    static constexpr int NN = N > 0 ? N : SW_NMAX;
+    static constexpr int R = NN / 2;
+    static constexpr int R4 = (R + 3) & ~3;
+    static constexpr int INW = SW_TW + 2 * R4;                  // floats of a source row segment (starts 16-byte aligned)
+    static constexpr int INP = INW + 4;                          // LDS pitch of s_in
+    static constexpr int RING = (NN + SW_RS - 1 + 7) & ~7;       // row-filtered rows kept
+    static constexpr int CRING = (R + SW_RS + 7) & ~7;           // source centre rows kept (for the DoG)
+    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + CRING * SW_TW;
+    static constexpr int LOADS = (SW_RS * (INW / 4) + SW_THREADS - 1) / SW_THREADS;
+};
+
+template <int N>
+__global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs,
+                                                         int w, int h, int stride, int seg, SiftTaps t)
+{
+    typedef SweepDims<N> DM;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int n = N > 0 ? N : t.n, r = n / 2;
+    const int R4 = N > 0 ? DM::R4 : ((r + 3) & ~3);
+    const int INW = SW_TW + 2 * R4, INP = INW + 4;
+    const int RING = N > 0 ? DM::RING : ((n + SW_RS - 1 + 7) & ~7);
+    const int CRING = N > 0 ? DM::CRING : ((r + SW_RS + 7) & ~7);
+    float* s_in = s_dyn;                                   // [SW_RS][INP]
+    float* s_ring = s_in + SW_RS * INP;                    // [RING][SW_TW]
+    float* s_ctr = s_ring + RING * SW_TW;                  // [CRING][SW_TW]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * SW_TW, Y0 = blockIdx.y * seg, Y1 = min(h, Y0 + seg);
+    if (Y0 >= h) return;
+    src += (size_t)blockIdx.z * src_fs;
+    if (dstG) dstG += (size_t)blockIdx.z * g_fs;
+    if (dstD) dstD += (size_t)blockIdx.z * d_fs;
+    const int xa = x0 - R4;                                // first source column of a segment (multiple of 4)
+    const bool interior = xa >= 0 && xa + INW <= w;        // whole segments inside the image: aligned 16-byte loads, no reflection
+    const int per_row = INW / 4, items = SW_RS * per_row;
+    const int nsteps = (Y1 - Y0 + 2 * r + SW_RS - 1) / SW_RS;
+
+    float4 ld[DM::LOADS];
+    auto issue = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < DM::LOADS; q++) {
+            const int it = q * SW_THREADS + tid;
+            if (it < items) {
+                const int row = it / per_row, c4 = it - row * per_row;
+                const int yy = reflect101(Y0 - r + k * SW_RS + row, h);
+                const float* p = src + (size_t)yy * stride;
+                const int x = xa + 4 * c4;
+                if (interior) ld[q] = *(const float4*)(p + x);
+                else { ld[q].x = p[reflect101(x, w)]; ld[q].y = p[reflect101(x + 1, w)]; ld[q].z = p[reflect101(x + 2, w)]; ld[q].w = p[reflect101(x + 3, w)]; }
+            }
+        }
+    };
+    issue(0);
+    // thread roles
+    const int rrow = tid >> 5, rx4 = (tid & 31) * 4;       // row pass: 4 consecutive columns of one of the 8 rows
+    const int cc = tid & (SW_TW - 1), crg = tid >> 7;      // column pass: 4 consecutive rows of one column
+    const int woff = R4 - r;                               // window start inside the aligned span
+    for (int k = 0; k < nsteps; k++) {
+        // the segment of step k: registers -> LDS (all threads are past the row pass of step k - 1: second barrier below)
+#pragma unroll
+        for (int q = 0; q < DM::LOADS; q++) {
+            const int it = q * SW_THREADS + tid;
+            if (it < items) { const int row = it / per_row, c4 = it - row * per_row; *(float4*)(s_in + row * INP + 4 * c4) = ld[q]; }
+        }
+        if (k + 1 < nsteps) issue(k + 1);                  // in flight during this step's arithmetic
+        __syncthreads();
+        // ---- row pass: s_in row rrow -> ring row (k * 8 + rrow); the source centre values go to their own ring
+        {
+            const int seq = k * SW_RS + rrow;
+            const float* in = s_in + rrow * INP + rx4;
+            float acc[4];
+            if (N > 0) {
+                float win[2 * DM::R4 + 4];
+#pragma unroll
+                for (int i = 0; i < (2 * DM::R4 + 4) / 4; i++) { const float4 v = *(const float4*)(in + 4 * i); win[4 * i] = v.x; win[4 * i + 1] = v.y; win[4 * i + 2] = v.z; win[4 * i + 3] = v.w; }
+                constexpr int WO = DM::R4 - DM::R;
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = t.k[0] * win[WO + q];
+#pragma unroll
+                for (int i = 1; i < N; i++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[q] += t.k[i] * win[WO + i + q];
+                }
+                *(float4*)(s_ctr + (seq % DM::CRING) * SW_TW + rx4) = make_float4(win[DM::R4], win[DM::R4 + 1], win[DM::R4 + 2], win[DM::R4 + 3]);
+                *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = t.k[0] * in[woff + q];
+                for (int i = 1; i < n; i++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[q] += t.k[i] * in[woff + i + q];
+                }
+                *(float4*)(s_ctr + (seq % CRING) * SW_TW + rx4) = make_float4(in[R4], in[R4 + 1], in[R4 + 2], in[R4 + 3]);
+                *(float4*)(s_ring + (seq % RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+        __syncthreads();
+        // ---- column pass: output rows m = 8 k - 2 r + 4 crg + q (relative to Y0) have their whole window in the ring now
+        {
+            const int m0 = k * SW_RS - 2 * r + 4 * crg;
+            const int x = x0 + cc;
+            if (m0 + 3 >= 0 && Y0 + m0 < Y1 && x < w) {
+                float acc[4];
+                if (N > 0) {
+                    float win[N + 3];
+#pragma unroll
+                    for (int i = 0; i < N + 3; i++) win[i] = s_ring[((m0 + i + 4 * DM::RING) % DM::RING) * SW_TW + cc];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[q] = t.k[DM::R] * win[DM::R + q];
+#pragma unroll
+                    for (int i = 1; i <= DM::R; i++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) acc[q] += t.k[DM::R + i] * (win[DM::R + q + i] + win[DM::R + q - i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[q] = t.k[r] * s_ring[((m0 + r + q + 4 * RING) % RING) * SW_TW + cc];
+                    for (int i = 1; i <= r; i++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            acc[q] += t.k[r + i] * (s_ring[((m0 + r + q + i + 4 * RING) % RING) * SW_TW + cc] + s_ring[((m0 + r + q - i + 4 * RING) % RING) * SW_TW + cc]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int m = m0 + q, y = Y0 + m;
+                    if (m >= 0 && y < Y1) {
+                        if (dstG) dstG[(size_t)y * stride + x] = acc[q];
+                        if (dstD) dstD[(size_t)y * stride + x] = acc[q] - s_ctr[((m + r) % CRING) * SW_TW + cc];
+                    }
+                }
+            }
+        }
+        // (no barrier here: the next step writes s_in, which nobody reads after the second barrier above, and touches the rings
+        //  only after its own first barrier, which every thread reaches after this column pass)
+    }
+}
+
+// ------------------------------------------------------------------ extrema
+#define EX_TW 64
+#define EX_TH 16
+#define EX_MAXP 10                     // DoG planes of an octave held in the tile (nOctaveLayers + 2 <= 10)
+__global__ __launch_bounds__(256) void k_sb_extrema(const float* dog, size_t d_fs, size_t plane, int w, int h, int stride, int nLayers, int o,
+                                                    float threshold, SiftCand* cand, int* counts /*[F][4]*/, int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_ex[];        // [planes][EX_TH + 2][EX_TW + 2]
+    const int PW = EX_TW + 2, PH = EX_TH + 2, np = nLayers + 2;
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int c0 = SIFT_IMG_BORDER + blockIdx.x * EX_TW, r0 = SIFT_IMG_BORDER + blockIdx.y * EX_TH;
+    const float* D = dog + (size_t)f * d_fs;
+    for (int i = tid; i < np * PH * PW; i += 256) {
+        const int pl = i / (PH * PW), rem = i - pl * (PH * PW), yy = rem / PW, xx = rem - yy * PW;
+        const int y = min(r0 - 1 + yy, h - 1), x = min(c0 - 1 + xx, w - 1);          // (r0, c0 >= 5: never negative)
+        s_ex[i] = D[(size_t)pl * plane + (size_t)y * stride + x];
+    }
+    __syncthreads();
+    const int lx = tid & 63;
+    for (int ly = tid >> 6; ly < EX_TH; ly += 4) {
+        const int c = c0 + lx, r = r0 + ly;
+        if (c >= w - SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) continue;
+        // 3 x 3 max / min of every plane at this pixel, then the three layers
+        float mx[EX_MAXP], mn[EX_MAXP], ctr[EX_MAXP];
+#pragma unroll
+        for (int pl = 0; pl < EX_MAXP; pl++) {
+            if (pl < np) {
+                const float* p = s_ex + pl * (PH * PW) + (ly + 1) * PW + lx + 1;
+                float a = p[-PW - 1], b = a;
+                const float v[8] = {p[-PW], p[-PW + 1], p[-1], p[0], p[1], p[PW - 1], p[PW], p[PW + 1]};
+#pragma unroll
+                for (int q = 0; q < 8; q++) { a = fmaxf(a, v[q]); b = fminf(b, v[q]); }
+                mx[pl] = a; mn[pl] = b; ctr[pl] = p[0];
+            }
+        }
+#pragma unroll
+        for (int layer = 1; layer <= EX_MAXP - 2; layer++) {
+            if (layer <= nLayers) {
+                const float val = ctr[layer];
+                if (fabsf(val) > threshold) {
+                    const float hi = fmaxf(fmaxf(mx[layer - 1], mx[layer]), mx[layer + 1]), lo = fminf(fminf(mn[layer - 1], mn[layer]), mn[layer + 1]);
+                    if (val > 0 ? val >= hi : val <= lo) {
+                        const int slot = atomicAdd(counts + 4 * f, 1);
+                        if (slot < cap) { SiftCand cd; cd.o = o; cd.layer = layer; cd.r = r; cd.c = c; cand[(size_t)f * cap + slot] = cd; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ refinement
+__global__ __launch_bounds__(64) void k_sb_refine(SiftGeom P, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr, float edgeThr,
+                                                  float sigma, SiftSurv* surv, int surv_cap, int* counts)
+{
+    const int f = blockIdx.y, id = blockIdx.x * 64 + threadIdx.x;
+    const int ncand = min(counts[4 * f], cand_cap);
+    if (id >= ncand) return;
+    const SiftCand cd = cand[(size_t)f * cand_cap + id];
+    const int o = cd.o, nLayers = P.nLayers, w = P.w[o], h = P.h[o], st = P.stride[o];
+    int layer = cd.layer, r = cd.r, c = cd.c;
+    const size_t plane = P.plane[o];
+    const float* dbase = dog + (size_t)f * P.dframe + P.doff[o];
+    const float img_scale = 1.f / 255.f, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int i = 0;
+#define D(L, rr, cc) dbase[(size_t)(L) * plane + (size_t)(rr) * st + (cc)]
+    for (; i < SIFT_MAX_INTERP_STEPS; i++) {
+        const float dD0 = (D(layer, r, c + 1) - D(layer, r, c - 1)) * deriv_scale, dD1 = (D(layer, r + 1, c) - D(layer, r - 1, c)) * deriv_scale,
+                    dD2 = (D(layer + 1, r, c) - D(layer - 1, r, c)) * deriv_scale;
+        const float v2 = D(layer, r, c) * 2;
+        const float dxx = (D(layer, r, c + 1) + D(layer, r, c - 1) - v2) * second_deriv_scale, dyy = (D(layer, r + 1, c) + D(layer, r - 1, c) - v2) * second_deriv_scale,
+                    dss = (D(layer + 1, r, c) + D(layer - 1, r, c) - v2) * second_deriv_scale;
+        const float dxy = (D(layer, r + 1, c + 1) - D(layer, r + 1, c - 1) - D(layer, r - 1, c + 1) + D(layer, r - 1, c - 1)) * cross_deriv_scale,
+                    dxs = (D(layer + 1, r, c + 1) - D(layer + 1, r, c - 1) - D(layer - 1, r, c + 1) + D(layer - 1, r, c - 1)) * cross_deriv_scale,
+                    dys = (D(layer + 1, r + 1, c) - D(layer + 1, r - 1, c) - D(layer - 1, r + 1, c) + D(layer - 1, r - 1, c)) * cross_deriv_scale;
+        const float a00 = dxx, a01 = dxy, a02 = dxs, a10 = dxy, a11 = dyy, a12 = dys, a20 = dxs, a21 = dys, a22 = dss;
+        float d = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+        float X0 = 0, X1 = 0, X2 = 0;
+        if (d != 0) {
+            d = 1 / d;
+            X0 = d * (dD0 * (a11 * a22 - a12 * a21) - a01 * (dD1 * a22 - a12 * dD2) + a02 * (dD1 * a21 - a11 * dD2));
+            X1 = d * (a00 * (dD1 * a22 - a12 * dD2) - dD0 * (a10 * a22 - a12 * a20) + a02 * (a10 * dD2 - dD1 * a20));
+            X2 = d * (a00 * (a11 * dD2 - dD1 * a21) - a01 * (a10 * dD2 - dD1 * a20) + dD0 * (a10 * a21 - a11 * a20));
+        }
+        xi = -X2; xr = -X1; xc = -X0;
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        if (fabsf(xi) > (float)(INT_MAX / 3) || fabsf(xr) > (float)(INT_MAX / 3) || fabsf(xc) > (float)(INT_MAX / 3)) return;
+        c += __float2int_rn(xc); r += __float2int_rn(xr); layer += __float2int_rn(xi);
+        if (layer < 1 || layer > nLayers || c < SIFT_IMG_BORDER || c >= w - SIFT_IMG_BORDER || r < SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
+    }
+    if (i >= SIFT_MAX_INTERP_STEPS) return;
+    float contr;
+    {
+        const float dD0 = (D(layer, r, c + 1) - D(layer, r, c - 1)) * deriv_scale, dD1 = (D(layer, r + 1, c) - D(layer, r - 1, c)) * deriv_scale,
+                    dD2 = (D(layer + 1, r, c) - D(layer - 1, r, c)) * deriv_scale;
+        const float t = dD0 * xc + dD1 * xr + dD2 * xi;
+        contr = D(layer, r, c) * img_scale + t * 0.5f;
+        if (fabsf(contr) * nLayers < contrastThr) return;
+        const float v2 = D(layer, r, c) * 2.f;
+        const float dxx = (D(layer, r, c + 1) + D(layer, r, c - 1) - v2) * second_deriv_scale, dyy = (D(layer, r + 1, c) + D(layer, r - 1, c) - v2) * second_deriv_scale;
+        const float dxy = (D(layer, r + 1, c + 1) - D(layer, r + 1, c - 1) - D(layer, r - 1, c + 1) + D(layer, r - 1, c - 1)) * cross_deriv_scale;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        if (det <= 0 || tr * tr * edgeThr >= (edgeThr + 1) * (edgeThr + 1) * det) return;
+    }
+#undef D
+    SiftSurv sv;
+    sv.kp.x = ((float)c + xc) * (float)(1 << o); sv.kp.y = ((float)r + xr) * (float)(1 << o);
+    sv.kp.octave = o + (layer << 8) + (__double2int_rn(((double)xi + 0.5) * 255) << 16);
+    sv.kp.size = sigma * (float)pow(2.0, (double)(((float)layer + xi) / (float)nLayers)) * (float)(1 << o) * 2;
+    sv.kp.response = fabsf(contr);
+    sv.kp.angle = 0.f;
+    sv.o = o; sv.layer = layer; sv.r = r; sv.c = c;
+    const int slot = atomicAdd(counts + 4 * f + 1, 1);
+    if (slot < surv_cap) surv[(size_t)f * surv_cap + slot] = sv;
+}
+
+// ------------------------------------------------------------------ orientation
+// calcOrientationHist + the peak selection of findScaleSpaceExtremaT, one WAVEFRONT per refined extremum.  The 36-bin
+// histogram receives w * mag of every window sample in row-major order: per batch of 64 samples the lanes compute one
+// sample each and set their bit in the mask of their bin (LDS atomic OR); lane b < 36 then adds the samples of bin b, lowest
+// bit (= earliest sample) first.
+#define SO_BINS 36
+__global__ __launch_bounds__(64) void k_sb_orient(SiftGeom P, const float* gauss, const SiftSurv* surv, int surv_cap, SiftExpTab E,
+                                                  SiftKp* kps, int kp_cap, int* counts)
+{
+    __shared__ float s_tab[64];
+    __shared__ float s_val[64];
+    __shared__ unsigned long long s_mask[SO_BINS];
+    __shared__ float s_th[SO_BINS + 4];
+    const int lane = threadIdx.x, f = blockIdx.y;
+    const int nsurv = min(counts[4 * f + 1], surv_cap);
+    s_tab[lane] = E.tab[lane];
+    const int n = SO_BINS;
+    for (int id = blockIdx.x; id < nsurv; id += gridDim.x) {
+        const SiftSurv sv = surv[(size_t)f * surv_cap + id];
+        const int o = sv.o, w = P.w[o], h = P.h[o], st = P.stride[o], r = sv.r, c = sv.c;
+        const float scl_octv = sv.kp.size * 0.5f / (float)(1 << o);
+        const int radius = __float2int_rn(3 * 1.5f * scl_octv);
+        const float osigma = 1.5f * scl_octv, expf_scale = -1.f / (2.f * osigma * osigma);
+        const float* g = gauss + (size_t)f * P.gframe + P.goff[o] + (size_t)sv.layer * P.plane[o];
+        const int side = 2 * radius + 1, total = side * side;
+        float acc = 0.f;                                         // temphist[lane] for lane < 36
+        __syncthreads();
+        for (int q0 = 0; q0 < total; q0 += 64) {
+            if (lane < n) s_mask[lane] = 0ull;
+            __syncthreads();
+            const int q = q0 + lane;
+            if (q < total) {
+                const int ii = q / side - radius, jj = q % side - radius, y = r + ii, x = c + jj;
+                if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
+                    const float dx = g[(size_t)y * st + x + 1] - g[(size_t)y * st + x - 1], dy = g[(size_t)(y - 1) * st + x] - g[(size_t)(y + 1) * st + x];
+                    const float wgt = sift_expf((float)(ii * ii + jj * jj) * expf_scale, s_tab);
+                    const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                    int bin = __float2int_rn((n / 360.f) * ori);
+                    if (bin >= n) bin -= n;
+                    if (bin < 0) bin += n;
+                    s_val[lane] = wgt * mag;
+                    atomicOr(&s_mask[bin], 1ull << lane);
+                }
+            }
+            __syncthreads();
+            if (lane < n) {
+                unsigned long long m = s_mask[lane];
+                while (m) { const int t = __ffsll((long long)m) - 1; m &= m - 1; acc += s_val[t]; }
+            }
+            __syncthreads();
+        }
+        if (lane < n) s_th[2 + lane] = acc;
+        __syncthreads();
+        if (lane == 0) { s_th[1] = s_th[2 + n - 1]; s_th[0] = s_th[2 + n - 2]; s_th[2 + n] = s_th[2]; s_th[2 + n + 1] = s_th[3]; }
+        __syncthreads();
+        float hj = 0.f;
+        if (lane < n) {
+            const float* th = s_th + 2 + lane;
+            hj = (th[-2] + th[2]) * (1.f / 16.f) + (th[-1] + th[1]) * (4.f / 16.f) + th[0] * (6.f / 16.f);
+        }
+        __syncthreads();
+        if (lane < n) s_val[lane] = hj;
+        __syncthreads();
+        if (lane < n) {
+            float maxval = s_val[0];
+            for (int b = 1; b < n; b++) maxval = s_val[b] > maxval ? s_val[b] : maxval;
+            const float mag_thr = maxval * 0.8f;
+            const int j = lane, l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
+            const float hl = s_val[l], hr = s_val[r2];
+            if (hj > hl && hj > hr && hj >= mag_thr) {
+                float bin = (float)j + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+                bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
+                SiftKp kp = sv.kp;
+                kp.angle = 360.f - (float)((360.f / n) * bin);
+                if (fabsf(kp.angle - 360.f) < FLT_EPSILON) kp.angle = 0.f;
+                const int slot = atomicAdd(counts + 4 * f + 2, 1);
+                if (slot < kp_cap) kps[(size_t)f * kp_cap + slot] = kp;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ KeyPointsFilter::removeDuplicatedSorted on the device
+// KeyPoint_LessThan: x asc, y asc, size desc, angle asc, response desc, octave desc (the remaining keys — class_id, the
+// index — only separate records that are identical in every field written here, which the duplicate filter then merges).
+__device__ __forceinline__ uint32_t f2ord(float v) { const uint32_t u = __float_as_uint(v); return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u); }
+__device__ __forceinline__ bool kp_less(const SiftKp& a, const SiftKp& b)
+{
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.size != b.size) return a.size > b.size;
+    if (a.angle != b.angle) return a.angle < b.angle;
+    if (a.response != b.response) return a.response > b.response;
+    if (a.octave != b.octave) return a.octave > b.octave;
+    return false;
+}
+
+#define RK_TILE 512
+__global__ __launch_bounds__(256) void k_sb_rank(const SiftKp* kps, int kp_cap, const int* counts, int* rank)
+{
+    __shared__ unsigned long long s_key[RK_TILE];
+    __shared__ SiftKp s_rec[RK_TILE];
+    const int f = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    const int nk = min(counts[4 * f + 2], kp_cap);
+    if ((int)(blockIdx.x * 256) >= nk) return;
+    const SiftKp* K = kps + (size_t)f * kp_cap;
+    SiftKp me = K[i < nk ? i : 0];
+    const unsigned long long mykey = ((unsigned long long)f2ord(me.x) << 32) | f2ord(me.y);
+    int rk = 0;
+    for (int base = 0; base < nk; base += RK_TILE) {
+        __syncthreads();
+        for (int j = tid; j < RK_TILE; j += 256)
+            if (base + j < nk) { const SiftKp q = K[base + j]; s_rec[j] = q; s_key[j] = ((unsigned long long)f2ord(q.x) << 32) | f2ord(q.y); }
+        __syncthreads();
+        const int lim = min(RK_TILE, nk - base);
+        for (int j = 0; j < lim; j++) {
+            const unsigned long long kj = s_key[j];
+            if (kj < mykey) rk++;
+            else if (kj == mykey) {                            // same (x, y): the full comparator, then the index
+                const SiftKp q = s_rec[j];
+                if (kp_less(q, me) || (!kp_less(me, q) && base + j < i)) rk++;
+            }
+        }
+    }
+    if (i < nk) rank[(size_t)f * kp_cap + i] = rk;
+}
+
+__global__ __launch_bounds__(256) void k_sb_scatter(const SiftKp* kps, int kp_cap, const int* counts, const int* rank, SiftKp* sorted)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int nk = min(counts[4 * f + 2], kp_cap);
+    if (i < nk) sorted[(size_t)f * kp_cap + rank[(size_t)f * kp_cap + i]] = kps[(size_t)f * kp_cap + i];
+}
+
+// drop the records that repeat (pt, size, angle) of their predecessor; firstOctave = -1: back to input-image coordinates;
+// writes the final list (at most out_cap records, the count says how many there were)
+__global__ __launch_bounds__(256) void k_sb_emit(const SiftKp* sorted, int kp_cap, int* counts, SiftKp* out, int out_cap, int* out_count, int* out_flags,
+                                                 int raw_cap_cand, int raw_cap_surv)
+{
+    __shared__ int s_w[4];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nraw = counts[4 * f + 2], nk = min(nraw, kp_cap);
+    const SiftKp* S = sorted + (size_t)f * kp_cap;
+    int out_base = 0;
+    for (int base = 0; base < nk; base += 256) {
+        const int i = base + tid;
+        SiftKp me; bool keep = false;
+        if (i < nk) {
+            me = S[i];
+            keep = true;
+            if (i > 0) { const SiftKp pv = S[i - 1]; keep = !(pv.x == me.x && pv.y == me.y && pv.size == me.size && pv.angle == me.angle); }
+        }
+        int inc = keep ? 1 : 0;
+        const int v = inc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        __syncthreads();
+        if (lane == 63) s_w[wid] = inc;
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int x = s_w[q]; if (q < wid) off += x; tot += x; }
+        const int pos = out_base + off + inc - v;
+        if (keep && pos < out_cap) {
+            me.octave = (me.octave & ~255) | ((me.octave - 1) & 255);
+            me.x *= 0.5f; me.y *= 0.5f; me.size *= 0.5f;
+            out[(size_t)f * out_cap + pos] = me;
+        }
+        out_base += tot;
+    }
+    if (tid == 0) {
+        out_count[f] = out_base;
+        int fl = 0;
+        if (out_base > out_cap || nraw > kp_cap || counts[4 * f] > raw_cap_cand || counts[4 * f + 1] > raw_cap_surv) fl = 1;
+        out_flags[f] = fl;
+        counts[4 * f + 3] = min(out_base, out_cap);
+    }
+}
+
+// ------------------------------------------------------------------ descriptors
+// One WAVEFRONT per keypoint.  calcSIFTDescriptor adds every sample of the (2 radius + 1)^2 window, in row-major order, into 8
+// bins of a 6 x 6 x 10 histogram of which only the inner 4 x 4 cells (and orientation bins 0..8) are ever read; float addition
+// is not associative, so each bin must receive its contributions in that order.
+//  (1) the window is scanned 64 positions at a time with the cheap tests only (rotated position inside the grid, pixel inside
+//      the image); the positions that pass are appended IN ORDER to an LDS queue (ballot + prefix count);
+//  (2) whenever the queue holds 64 positions they are evaluated one per lane (gradient, fastAtan2, exp32f weight, trilinear
+//      split -> 8 values) and every sample sets its bit in the masks of the owner lanes it feeds;
+//  (3) the 64 lanes OWN the histogram: lane = inner cell (a, b) x q, q = orientation bins {2q, 2q+1} (+ bin 8 for q = 3), kept
+//      in registers; an owner walks the set bits of its mask, lowest (= earliest sample) first, and adds.
+// Same additions, same order as the scalar loop; no read-modify-write chain through memory.
+#define SD_D 4
+#define SD_N 8
+__global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* gauss, const SiftKp* kps, int kp_cap, const int* counts, SiftExpTab E,
+                                                      uint8_t* desc, uint8_t* desc_x, int cap_x, int* norms, int* flags, int first_slot)
+{
+    __shared__ float s_tab[64];
+    __shared__ unsigned int s_q[128];                           // queue of window positions (i + 32768) << 16 | (j + 32768)
+    __shared__ float s_v[8][64];                                // s_v[(dr * 2 + dc) * 2 + dori][sample]
+    __shared__ unsigned int s_code[64];                         // A | B << 4 | o0 << 8  (A = r0 + 1, B = c0 + 1 in 0..4)
+    __shared__ unsigned long long s_own[64];
+    __shared__ __attribute__((aligned(16))) float s_fin[128];
+    const int lane = threadIdx.x, f = blockIdx.y;
+    const int nkp = min(counts[4 * f + 3], kp_cap);
+    s_tab[lane] = E.tab[lane];
+    // owner role of this lane
+    const int own_a = 1 + (lane >> 4), own_b = 1 + ((lane >> 2) & 3), own_q = lane & 3;
+    const int d = SD_D, n = SD_N;
+    for (int id = blockIdx.x; id < nkp; id += gridDim.x) {
+        const SiftKp kp = kps[(size_t)f * kp_cap + id];         // already in input-image coordinates (firstOctave = -1 applied)
+        int octave = kp.octave & 255; const int layer = (kp.octave >> 8) & 255;
+        octave = octave < 128 ? octave : (-128 | octave);
+        const float scale = octave >= 0 ? 1.f / (float)(1 << octave) : (float)(1 << -octave);
+        const float size = kp.size * scale, ptx = kp.x * scale, pty = kp.y * scale;
+        float angle = 360.f - kp.angle;
+        if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
+        const int o = octave + 1, w = P.w[o], h = P.h[o], st = P.stride[o];
+        const float* img = gauss + (size_t)f * P.gframe + P.goff[o] + (size_t)layer * P.plane[o];
+        const float ori = angle, scl = size * 0.5f;
+        const int px = __float2int_rn(ptx), py = __float2int_rn(pty);
+        float cos_t = (float)cos((double)(ori * (float)(3.14159265358979323846 / 180))), sin_t = (float)sin((double)(ori * (float)(3.14159265358979323846 / 180)));
+        const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = 3.f * scl;
+        int radius = __float2int_rn(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+        const int rmax = (int)sqrt((double)w * w + (double)h * h);
+        if (radius > rmax) radius = rmax;
+        cos_t /= hist_width; sin_t /= hist_width;
+        const int side = 2 * radius + 1, total = side * side;
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f;                     // bins 2q, 2q+1 (and 8 for q = 3) of cell (own_a, own_b)
+        int qn = 0;                                             // queue fill (wave-uniform)
+        __syncthreads();
+        // one dense batch: `cnt` queue entries starting at s_q[0]
+        auto process = [&](int cnt) {
+            s_own[lane] = 0ull;
+            __syncthreads();
+            if (lane < cnt) {
+                const unsigned int pk = s_q[lane];
+                const int i = (int)(pk >> 16) - 32768, j = (int)(pk & 0xffffu) - 32768;
+                const float c_rot = (float)j * cos_t - (float)i * sin_t, r_rot = (float)j * sin_t + (float)i * cos_t;
+                float rbin = r_rot + (float)(d / 2) - 0.5f, cbin = c_rot + (float)(d / 2) - 0.5f;
+                const int r = py + i, c = px + j;
+                const float dx = img[(size_t)r * st + c + 1] - img[(size_t)r * st + c - 1], dy = img[(size_t)(r - 1) * st + c] - img[(size_t)(r + 1) * st + c];
+                const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
+                const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
+                float obin = (Ori - ori) * bins_per_rad;
+                const float mag = Mag * Wq;
+                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                int o0 = (int)floorf(obin);
+                rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                s_v[0][lane] = v_rco000; s_v[1][lane] = v_rco001; s_v[2][lane] = v_rco010; s_v[3][lane] = v_rco011;
+                s_v[4][lane] = v_rco100; s_v[5][lane] = v_rco101; s_v[6][lane] = v_rco110; s_v[7][lane] = v_rco111;
+                const int A = r0 + 1, B = c0 + 1;               // cells (A, B), (A, B+1), (A+1, B), (A+1, B+1) of the 6 x 6 grid
+                s_code[lane] = (unsigned)A | ((unsigned)B << 4) | ((unsigned)o0 << 8);
+                // owners fed: orientation group(s) of o0 — even o0 = 2q: q (both of its bins); odd o0 = 2q+1: q (bin 2q+1) and
+                // q+1 (bin 2q+2), except o0 = 7 whose upper bin 8 also belongs to q = 3
+                const int qa = o0 >> 1, qb = (o0 & 1) && o0 < 7 ? qa + 1 : -1;
+                const unsigned long long bit = 1ull << lane;
+#pragma unroll
+                for (int dr = 0; dr < 2; dr++)
+#pragma unroll
+                    for (int dc = 0; dc < 2; dc++) {
+                        const int a = A + dr, b = B + dc;
+                        if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
+                            const int ow = ((a - 1) << 4) | ((b - 1) << 2);
+                            atomicOr(&s_own[ow | qa], bit);
+                            if (qb >= 0) atomicOr(&s_own[ow | qb], bit);
+                        }
+                    }
+            }
+            __syncthreads();
+            unsigned long long m = s_own[lane];
+            while (m) {
+                const int t = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const unsigned int code = s_code[t];
+                const int A = code & 15, B = (code >> 4) & 15, o0 = code >> 8;
+                const int sel = ((own_a - A) * 2 + (own_b - B)) * 2;
+                const float v0 = s_v[sel][t], v1 = s_v[sel + 1][t];
+                const int rel = o0 - 2 * own_q;                 // -1, 0 or 1
+                if (rel == 0) { e0 += v0; e1 += v1; }
+                else if (rel == 1) { e1 += v0; e2 += v1; }      // (e2 is only read for q = 3: o0 = 7 -> bin 8)
+                else e0 += v1;
+            }
+            __syncthreads();
+        };
+        for (int q0 = 0; q0 < total; q0 += 64) {
+            // (1) cheap tests, ordered append
+            const int q = q0 + lane;
+            bool ok = false; unsigned int pk = 0;
+            if (q < total) {
+                const int i = q / side - radius, j = q % side - radius;
+                const float c_rot = (float)j * cos_t - (float)i * sin_t, r_rot = (float)j * sin_t + (float)i * cos_t;
+                const float rbin = r_rot + (float)(d / 2) - 0.5f, cbin = c_rot + (float)(d / 2) - 0.5f;
+                const int r = py + i, c = px + j;
+                ok = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
+                pk = ((unsigned)(i + 32768) << 16) | (unsigned)(j + 32768);
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (ok) s_q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = pk;
+            qn += __popcll(bal);
+            __syncthreads();
+            if (qn >= 64) {
+                process(64);
+                if (lane < qn - 64) { const unsigned int v = s_q[64 + lane]; s_q[lane] = v; }     // (same lane reads then writes: no overlap hazard within 64)
+                qn -= 64;
+                __syncthreads();
+            }
+        }
+        if (qn > 0) process(qn);
+        // finalisation: hist[.][0] += hist[.][8] (hist[.][9] is never written), then the strictly sequential norm / clip / norm chain
+        // of calcSIFTDescriptor on one lane; element order (cell row, cell column, bin)
+        s_v[0][lane] = e2;                                      // bin 8 of (cell, q = 3) -> read by q = 0
+        __syncthreads();
+        if (own_q == 0) e0 += s_v[0][lane + 3];
+        s_fin[(lane >> 2) * 8 + own_q * 2] = e0; s_fin[(lane >> 2) * 8 + own_q * 2 + 1] = e1;
+        __syncthreads();
+        if (lane == 0) {
+            float nrm2 = 0;
+            for (int k = 0; k < 128; k++) { const float v = s_fin[k]; nrm2 += v * v; }
+            const float thr = sqrtf(nrm2) * 0.2f;
+            nrm2 = 0;
+            for (int k = 0; k < 128; k++) { float v = s_fin[k]; v = v < thr ? v : thr; s_fin[k] = v; nrm2 += v * v; }
+            s_v[1][0] = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
+        }
+        __syncthreads();
+        {
+            const float sc = s_v[1][0];
+            const int u0 = min(max(__float2int_rn(s_fin[2 * lane] * sc), 0), 255), u1 = min(max(__float2int_rn(s_fin[2 * lane + 1] * sc), 0), 255);
+            const size_t slot = (size_t)(first_slot + f);
+            if (desc) *(uint16_t*)(desc + (slot * kp_cap + id) * 128 + 2 * lane) = (uint16_t)(u0 | (u1 << 8));
+            // |v - 128|^2 summed over the row (exact integer), and the matrix-core operand image: bytes v - 128 as int8,
+            // [slot][group = row / 16][chunk 0..7 = 16 elements][row % 16][16 B]
+            int sq = (u0 - 128) * (u0 - 128) + (u1 - 128) * (u1 - 128), raw = u0 * u0 + u1 * u1;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { sq += __shfl_xor(sq, dd, 64); raw += __shfl_xor(raw, dd, 64); }
+            // the matrix-core matcher orders candidates by the exact integer d^2 instead of sqrtf(d^2): the same order as long as
+            // d^2 < 2^22 (sqrtf is strictly increasing on those integers), which |row|^2 <= 2^20 guarantees; SIFT's normalisation
+            // gives |row|^2 ~ 2^18.  A row that breaks the bound is flagged (bit 1) instead of silently matched.
+            if (lane == 0 && raw > (1 << 20) && flags) atomicOr(flags + slot, 2);
+            if (desc_x) {
+                *(uint16_t*)(desc_x + slot * (size_t)cap_x * 128 + ((size_t)((id >> 4) * 8 + (lane >> 3)) * 16 + (id & 15)) * 16 + 2 * (lane & 7)) =
+                    (uint16_t)(((u0 - 128) & 255) | (((u1 - 128) & 255) << 8));
+                if (lane == 0) norms[slot * cap_x + id] = sq;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// final keypoint records -> the per-slot SoA arrays the pair stage reads (kp_xy) and the host downloads
+__global__ __launch_bounds__(256) void k_sb_unpack(const SiftKp* kps, int kp_cap, const int* counts, int first_slot, float* kp_xy, float* kp_size,
+                                                   float* kp_angle, float* kp_resp, int* kp_oct, int* kp_count, const int* fin_count, const int* fin_flags, int* flags)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int nk = min(counts[4 * f + 3], kp_cap);
+    const size_t slot = (size_t)(first_slot + f);
+    if (i == 0) { kp_count[slot] = fin_count[f]; flags[slot] = fin_flags[f]; }
+    if (i >= nk) return;
+    const SiftKp k = kps[(size_t)f * kp_cap + i];
+    const size_t o = slot * kp_cap + i;
+    kp_xy[2 * o] = k.x; kp_xy[2 * o + 1] = k.y; kp_size[o] = k.size; kp_angle[o] = k.angle; kp_resp[o] = k.response; kp_oct[o] = k.octave;
+}
+
+// ------------------------------------------------------------------ launchers
+void launch_sb_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh, float* dst, int dstride, size_t dframe, int F)
+{
+    hipLaunchKernelGGL(k_sb_base, dim3((2 * sw + 255) / 256, 2 * sh, F), dim3(256), 0, s, src, channels, row_stride, frame_stride, sw, sh, dst, dstride, dframe);
+}
+
+void launch_sb_half(hipStream_t s, const float* src, size_t sframe, int sw, int sh, int sstride, float* dst, size_t dframe, int dw, int dh, int dstride, int F)
+{
+    hipLaunchKernelGGL(k_sb_half, dim3((dw + 255) / 256, dh, F), dim3(256), 0, s, src, sframe, sw, sh, sstride, dst, dframe, dw, dh, dstride);
+}
+
+template <int N>
+static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F, const SiftTaps& t)
+{
+    // segments: tall enough that the 2 r halo rows stay a small fraction, short enough that a small batch still fills the chip
+    const int strips = (w + SW_TW - 1) / SW_TW;
+    int seg = 256;
+    while (seg > 64 && (long long)strips * ((h + seg - 1) / seg) * F < 2048) seg >>= 1;
+    const int n = N > 0 ? N : t.n, r = n / 2, R4 = (r + 3) & ~3;
+    const size_t lds = N > 0 ? (size_t)SweepDims<N>::LDS_FLOATS * 4
+                             : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + ((r + SW_RS + 7) & ~7)) * SW_TW) * 4;
+    hipLaunchKernelGGL(k_sb_sweep<N>, dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t);
+}
+
+int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
+                    const float* taps, int ntaps)
+{
+    if (ntaps < 1 || ntaps > SW_NMAX || !(ntaps & 1)) return -1;
+    SiftTaps t; t.n = ntaps;
+    for (int i = 0; i < SIFT_MAX_TAPS; i++) t.k[i] = i < ntaps ? taps[i] : 0.f;
+    switch (ntaps) {                                        // the sizes cv2's defaults produce are 11, 13, 17, 21, 27
+#define SW_CASE(N) case N: sweep_n<N>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t); break;
+        SW_CASE(11) SW_CASE(13) SW_CASE(17) SW_CASE(21) SW_CASE(27)
+#undef SW_CASE
+        default: sweep_n<0>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t);
+    }
+    return 0;
+}
+
+void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o, float threshold, SiftCand* cand, int* counts, int cap, int F)
+{
+    const int w = P.w[o], h = P.h[o];
+    if (w <= 2 * SIFT_IMG_BORDER || h <= 2 * SIFT_IMG_BORDER) return;
+    const size_t lds = (size_t)(P.nLayers + 2) * (EX_TH + 2) * (EX_TW + 2) * 4;
+    hipLaunchKernelGGL(k_sb_extrema, dim3((w - 2 * SIFT_IMG_BORDER + EX_TW - 1) / EX_TW, (h - 2 * SIFT_IMG_BORDER + EX_TH - 1) / EX_TH, F), dim3(256), lds, s,
+                       dog + P.doff[o], P.dframe, P.plane[o], w, h, P.stride[o], P.nLayers, o, threshold, cand, counts, cap);
+}
+
+void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr,
+                             float edgeThr, float sigma, const SiftExpTab& E, SiftSurv* surv, int surv_cap, SiftKp* kps, int kp_cap, int* counts, int F, int waves)
+{
+    hipLaunchKernelGGL(k_sb_refine, dim3((cand_cap + 63) / 64, F), dim3(64), 0, s, P, dog, cand, cand_cap, contrastThr, edgeThr, sigma, surv, surv_cap, counts);
+    hipLaunchKernelGGL(k_sb_orient, dim3(waves, F), dim3(64), 0, s, P, gauss, surv, surv_cap, E, kps, kp_cap, counts);
+}
+
+void launch_sb_sort_emit(hipStream_t s, const SiftKp* kps, int kp_cap, int* counts, int* rank, SiftKp* sorted, SiftKp* out, int out_cap, int* out_count,
+                         int* out_flags, int cand_cap, int surv_cap, int F)
+{
+    hipLaunchKernelGGL(k_sb_rank, dim3((kp_cap + 255) / 256, F), dim3(256), 0, s, kps, kp_cap, counts, rank);
+    hipLaunchKernelGGL(k_sb_scatter, dim3((kp_cap + 255) / 256, F), dim3(256), 0, s, kps, kp_cap, counts, rank, sorted);
+    hipLaunchKernelGGL(k_sb_emit, dim3(F), dim3(256), 0, s, sorted, kp_cap, counts, out, out_cap, out_count, out_flags, cand_cap, surv_cap);
+}
+
+void launch_sb_descriptor(hipStream_t s, const SiftGeom& P, const float* gauss, const SiftKp* kps, int kp_cap, const int* counts, const SiftExpTab& E,
+                          uint8_t* desc, uint8_t* desc_x, int cap_x, int* norms, int* flags, int first_slot, int F, int waves)
+{
+    hipLaunchKernelGGL(k_sb_descriptor, dim3(waves, F), dim3(64), 0, s, P, gauss, kps, kp_cap, counts, E, desc, desc_x, cap_x, norms, flags, first_slot);
+}
+
+void launch_sb_unpack(hipStream_t s, const SiftKp* kps, int kp_cap, const int* counts, int first_slot, float* kp_xy, float* kp_size, float* kp_angle,
+                      float* kp_resp, int* kp_oct, int* kp_count, const int* fin_count, const int* fin_flags, int* flags, int F)
+{
+    hipLaunchKernelGGL(k_sb_unpack, dim3((kp_cap + 255) / 256, F), dim3(256), 0, s, kps, kp_cap, counts, first_slot, kp_xy, kp_size, kp_angle, kp_resp, kp_oct,
+                       kp_count, fin_count, fin_flags, flags);
+}

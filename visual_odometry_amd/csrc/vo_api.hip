@@ -9,7 +9,23 @@
 #include <vector>
 #include <algorithm>
 
-#define MAX_EVENTS 96
+#define MAX_EVENTS 160
+
+// One SIFT configuration: per-slot results for max_frames slots + the scale-space scratch of one sub-batch of fb frames
+struct SiftState {
+    bool configured = false, with_operands = false;
+    vo_sift_params prm{};
+    int h = 0, w = 0, fstride = 0, max_frames = 0, kp_cap = 0, cap_x = 0, raw_cap = 0, cand_cap = 0, surv_cap = 0, fb = 0;
+    SiftGeom P{};
+    float taps[16][SIFT_MAX_TAPS]; int ntaps[16];
+    SiftExpTab E{};
+    uint8_t* frames = nullptr;                                    // [slot][h][fstride] gray
+    float *kp_xy = nullptr, *kp_size = nullptr, *kp_angle = nullptr, *kp_resp = nullptr; int *kp_oct = nullptr, *kp_count = nullptr, *flags = nullptr;
+    uint8_t *desc = nullptr, *desc_x = nullptr; int* norms = nullptr;   // [slot][kp_cap][128] u8; int8 operand image + |v - 128|^2 for the matrix-core matcher
+    float *G = nullptr, *D = nullptr, *up = nullptr;              // sub-batch scratch: Gaussian / DoG pyramids, the up-sampled base image
+    SiftCand* cand = nullptr; SiftSurv* surv = nullptr; SiftKp *kraw = nullptr, *ksorted = nullptr, *kfin = nullptr;
+    int *rank = nullptr, *counts = nullptr, *fin_count = nullptr, *fin_flags = nullptr;
+};
 
 struct vo_ctx {
     int device = 0;
@@ -31,7 +47,10 @@ struct vo_ctx {
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *staging = nullptr;
     uint8_t* desc_x = nullptr;            // descriptors expanded to +1 / -1 bytes for the MFMA matcher
     uint8_t* ingest_out = nullptr; size_t ingest_out_bytes = 0;      // resized frames (frame ingest)
-    uint8_t *sift_buf = nullptr; size_t sift_buf_n = 0;              // SIFT: pyramids, scratch, candidate / keypoint lists, descriptors
+    SiftState sift, sift1;                                           // SIFT: the batched detector's state; the single-image call's
+    uint8_t* sift_img = nullptr; size_t sift_img_n = 0;              // the single-image call's input on the device
+    int detector = 0;                                                // detector of the batched path: 0 = ORB (vo_batch_configure), 1 = SIFT (vo_batch_configure_sift)
+    int sift_pairs = 0;
     // JPEG decode: the batch's files, clean streams, restart lists, coefficients, component planes, B G R output, descriptors
     uint8_t *jpg_blob = nullptr, *jpg_clean = nullptr, *jpg_rst = nullptr, *jpg_coef = nullptr, *jpg_planes = nullptr, *jpg_out = nullptr,
             *jpg_img = nullptr, *jpg_tab = nullptr;
@@ -76,7 +95,8 @@ struct vo_ctx {
 static const char* k_stage_names[VO_STAGE_COUNT] = {
     "gray", "pyramid_resize", "fast_score_nms", "select_fast", "harris", "select_harris", "ic_angle",
     "gaussian_blur", "rbrief", "match_nn", "match_select", "essential_ransac", "recover_pose",
-    "triangulate", "misc", "reserved"};
+    "triangulate", "misc", "reserved", "sift_scale_space", "sift_extrema", "sift_refine_orient", "sift_sort_unique",
+    "sift_descriptor", "cv2_keypoint_order", "trajectory_gather", "reserved2"};
 
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
@@ -286,7 +306,11 @@ static void free_config(vo_ctx* c)
     c->configured = false;
 }
 
-extern "C" int vo_version(void) { return 100; }
+static void sift_free(SiftState& S);
+static int sift_frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot);
+static int sift_frames_detect_enqueue(vo_ctx* ctx, int first_slot, int F);
+
+extern "C" int vo_version(void) { return 110; }
 
 extern "C" int vo_create(int device_id, vo_ctx** out)
 {
@@ -337,8 +361,9 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_config(ctx);
     free_pairbuf(ctx->raw_pb);
+    sift_free(ctx->sift); sift_free(ctx->sift1);
     void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab, ctx->raw_desc_x,
-                    ctx->ingest_out, ctx->ingest_tab, ctx->sift_buf, ctx->jpg_blob, ctx->jpg_clean, ctx->jpg_rst, ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out,
+                    ctx->ingest_out, ctx->ingest_tab, ctx->sift_img, ctx->jpg_blob, ctx->jpg_clean, ctx->jpg_rst, ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out,
                     ctx->jpg_img, ctx->jpg_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
@@ -398,8 +423,10 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     if (h < 1 || w < 1 || max_frames < 1 || max_pairs < 1) FAIL(VO_ERR_INVALID, "bad sizes");
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->configured && ctx->h == h && ctx->w == w && memcmp(&ctx->params, params, sizeof(*params)) == 0 &&
-        ctx->max_frames >= max_frames && ctx->max_pairs >= max_pairs)
+        ctx->max_frames >= max_frames && ctx->max_pairs >= max_pairs && ctx->pb_cap == ctx->g.kp_cap) {
+        ctx->detector = 0;
         return VO_OK;
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     free_config(ctx);
     PyrGeom g;
@@ -487,12 +514,14 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     ctx->pb_pairs = max_pairs; ctx->pb_cap = g.kp_cap;
     HIPCHK(hipDeviceSynchronize());                         // the initialising memsets ran on the NULL stream
     ctx->configured = true;
+    ctx->detector = 0;
     if (ctx->kp_order == 1) { rc = alloc_cv2(ctx); if (rc) return rc; }
     return VO_OK;
 }
 
 static int frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
 {
+    if (ctx->detector == 1) return sift_frames_upload_enqueue(ctx, frames, F, row_stride, frame_stride, first_slot);
     if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
     if (row_stride < ctx->w) FAIL(VO_ERR_INVALID, "row_stride < width");
@@ -534,8 +563,9 @@ extern "C" int vo_frames_upload_color(vo_ctx* ctx, const uint8_t* frames, int F,
                                       int64_t frame_stride, int first_slot)
 {
     if (!ctx) return VO_ERR_INVALID;
-    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (channels == 1) return vo_frames_upload(ctx, frames, F, row_stride, frame_stride, first_slot);
+    if (ctx->detector == 1) FAIL(VO_ERR_UNSUPPORTED, "the batched SIFT path takes gray frames (vo_frames_upload)");
+    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (channels != 3 && channels != 4) FAIL(VO_ERR_INVALID, "channels must be 1, 3 or 4");
     if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
     if (row_stride < ctx->w * channels || frame_stride < (int64_t)row_stride * ctx->h) FAIL(VO_ERR_INVALID, "strides too small");
@@ -604,7 +634,7 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
     { StageTimer t(ctx, ST_SELECT_HARRIS); launch_select_harris(s, g, ff, F, ctx->har_thr + (size_t)first_slot * VO_MAX_LEVELS, ctx->har_kept + (size_t)first_slot * VO_MAX_LEVELS); }
     if (ctx->kp_order == 1 && ctx->cv2_ready) {
         // cv2's list order: permute every level's keypoints the way retainBest's nth_element / partition leave them
-        StageTimer t(ctx, ST_MISC);
+        StageTimer t(ctx, ST_CV2_ORDER);
         Cv2Buf cb = ctx->cv2;
         const size_t fo = (size_t)first_slot;
         cb.all_pos += fo * cb.all_total; cb.all_resp += fo * cb.all_total; cb.work += fo * cb.all_total;
@@ -627,6 +657,7 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
 
 extern "C" int vo_batch_kp_capacity(vo_ctx* ctx)
 {
+    if (ctx && ctx->detector == 1) return ctx->sift.configured ? ctx->sift.kp_cap : 0;
     return ctx && ctx->configured ? ctx->g.kp_cap : 0;
 }
 
@@ -645,6 +676,13 @@ extern "C" void vo_host_free(void* p)
 extern "C" int vo_frames_detect_async(vo_ctx* ctx, int first_slot, int F)
 {
     if (!ctx) return VO_ERR_INVALID;
+    if (ctx->detector == 1) {
+        int rc = sift_frames_detect_enqueue(ctx, first_slot, F);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(ctx->ev_det, ctx->stream));
+        ctx->ev_det_set = true;
+        return VO_OK;
+    }
     if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
     if (F == 0) return VO_OK;
@@ -674,6 +712,13 @@ extern "C" int vo_detect_after(vo_ctx* ctx, vo_ctx* other)
 extern "C" int vo_frames_detect(vo_ctx* ctx, int first_slot, int F)
 {
     if (!ctx) return VO_ERR_INVALID;
+    if (ctx->detector == 1) {
+        int rc = sift_frames_detect_enqueue(ctx, first_slot, F);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->prof) prof_collect(ctx);
+        return VO_OK;
+    }
     if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
     if (F == 0) return VO_OK;
@@ -840,17 +885,28 @@ static int ensure_rng(vo_ctx* ctx, uint64_t seed)
     return VO_OK;
 }
 
+static int batch_cap(const vo_ctx* ctx) { return ctx->detector == 1 ? ctx->sift.kp_cap : ctx->g.kp_cap; }
+static bool batch_ready(const vo_ctx* ctx) { return ctx->detector == 1 ? ctx->sift.configured : ctx->configured; }
+static int batch_max_pairs(const vo_ctx* ctx) { return ctx->detector == 1 ? ctx->sift_pairs : ctx->max_pairs; }
+
 // vo_pair_opts.match_mode -> k_match_select mode.  BFMatcher(crossCheck=True) of OpenCV 4.x is the strict mutual
 // nearest neighbour (batchDistance compares the forward result too: `d < d0 && sidx[idx] == i`); the older
 // reverse-NN-only update rule stays selectable as match_mode 2.
 static int map_select_mode(int match_mode) { return match_mode == 0 ? 2 : match_mode == 2 ? 1 : 3; }
 
 static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t* desc_x, const float* kp_xy, const int* kp_count, int cap,
-                     int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points, int descx_fp4)
+                     int P, int select_mode, double ratio, const RansacParams& rp, bool do_geometry, bool want_points, int descx_fp4,
+                     const int* l2_norms = nullptr)
 {
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemsetAsync(pb.res, 0, (size_t)P * sizeof(vo_pair_result), s));
-    {
+    if (l2_norms) {                                              // SIFT rows: squared L2 distances on the int8 matrix cores
+        StageTimer t(ctx, ST_MATCH_NN);
+        const int cx = desc_x_rows(cap);
+        const int dirs = select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3;
+        if (select_mode == 3) launch_match_nn_l2i8(s, desc_x, l2_norms, kp_count, cap, cx, pb, P, 1, 1);
+        else launch_match_nn_l2i8(s, desc_x, l2_norms, kp_count, cap, cx, pb, P, dirs, 0);
+    } else {
         StageTimer t(ctx, ST_MATCH_NN);
         const int cx = desc_x_rows(cap);
         const int dirs = select_mode == 0 ? 1 : select_mode == 1 ? 2 : 3;
@@ -861,7 +917,7 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t
         } else if (select_mode == 3) launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, 1, 1, descx_fp4);   // the image that was written,
         else launch_match_nn(s, desc_x, kp_count, cap, cx, pb, P, dirs, 0, descx_fp4);                        // whatever the setter says now
     }
-    { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK); }
+    { StageTimer t(ctx, ST_MATCH_SELECT); launch_match_select(s, kp_xy, kp_count, cap, pb, P, select_mode, ratio, ctx->dK, l2_norms ? 1 : 0); }
     if (!do_geometry) return VO_OK;
     { int rc = ensure_rng(ctx, rp.seed); if (rc) return rc; }
     const bool hi = ctx->stream_hi != nullptr && P >= 16;     // the tail on the high-priority stream, fenced by two events
@@ -884,17 +940,19 @@ static int run_pairs(vo_ctx* ctx, PairBuf pb, const uint8_t* desc, const uint8_t
 static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
                          vo_pair_result* results, double* X, int32_t x_cap, bool* whole_x_out)
 {
-    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
-    if (!pair_slots || !K || !opts || !results || B < 0 || B > ctx->max_pairs) FAIL(VO_ERR_INVALID, "bad pair batch arguments");
+    const bool sift = ctx->detector == 1;
+    if (sift ? !ctx->sift.configured : !ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    const int max_pairs = sift ? ctx->sift_pairs : ctx->max_pairs, max_frames = sift ? ctx->sift.max_frames : ctx->max_frames;
+    if (!pair_slots || !K || !opts || !results || B < 0 || B > max_pairs) FAIL(VO_ERR_INVALID, "bad pair batch arguments");
     if (opts->match_mode < 0 || opts->match_mode > 2) FAIL(VO_ERR_INVALID, "match_mode must be 0, 1 or 2");
     if (!(opts->ransac_prob > 0 && opts->ransac_prob < 1)) FAIL(VO_ERR_INVALID, "ransac_prob must be in (0, 1)");
     for (int i = 0; i < 2 * B; i++)
-        if (pair_slots[i] < 0 || pair_slots[i] >= ctx->max_frames) FAIL(VO_ERR_INVALID, "pair slot %d out of range", pair_slots[i]);
+        if (pair_slots[i] < 0 || pair_slots[i] >= max_frames) FAIL(VO_ERR_INVALID, "pair slot %d out of range", pair_slots[i]);
     *whole_x_out = false;
     if (B == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const int cap = ctx->g.kp_cap;
+    const int cap = batch_cap(ctx);
     HIPCHK(hipMemcpyAsync(ctx->pb.slots, pair_slots, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, s));
     RansacParams rp{};
@@ -902,8 +960,10 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
     rp.seed = opts->ransac_seed; rp.dist_thresh = opts->pose_dist_thresh; rp.dk_early = ctx->dk_early;
     memcpy(rp.K, K, sizeof(rp.K));
     const bool wp = opts->want_points != 0;
-    int rc = run_pairs(ctx, ctx->pb, ctx->ff.desc, ctx->desc_x, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
-                       map_select_mode(opts->match_mode), opts->ratio, rp, true, wp, ctx->descx_fp4);
+    int rc = sift ? run_pairs(ctx, ctx->pb, ctx->sift.desc, ctx->sift.desc_x, ctx->sift.kp_xy, ctx->sift.kp_count, cap, B,
+                              map_select_mode(opts->match_mode), opts->ratio, rp, true, wp, 0, ctx->sift.norms)
+                  : run_pairs(ctx, ctx->pb, ctx->ff.desc, ctx->desc_x, ctx->ff.kp_xy, ctx->ff.kp_count, cap, B,
+                              map_select_mode(opts->match_mode), opts->ratio, rp, true, wp, ctx->descx_fp4);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(results, ctx->pb.res, (size_t)B * sizeof(vo_pair_result), hipMemcpyDeviceToHost, s));
@@ -924,7 +984,7 @@ extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const
     if (rc || B == 0) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) prof_collect(ctx);
-    const int cap = ctx->g.kp_cap;
+    const int cap = batch_cap(ctx);
     if (X && opts->want_points && !whole_x) {
         for (int p = 0; p < B; p++) {
             const int n = results[p].status == VO_OK ? (results[p].n_inl < x_cap ? results[p].n_inl : x_cap) : 0;
@@ -944,7 +1004,7 @@ extern "C" int vo_pairs_run_async(vo_ctx* ctx, const int32_t* pair_slots, int B,
                                   vo_pair_result* results, double* X, int32_t x_cap)
 {
     if (!ctx) return VO_ERR_INVALID;
-    if (X && opts && opts->want_points && ctx->configured && x_cap != ctx->g.kp_cap)
+    if (X && opts && opts->want_points && batch_ready(ctx) && x_cap != batch_cap(ctx))
         FAIL(VO_ERR_INVALID, "vo_pairs_run_async needs x_cap == vo_batch_kp_capacity()");
     bool whole_x = false;
     return pairs_enqueue(ctx, pair_slots, B, K, opts, results, X, x_cap, &whole_x);
@@ -963,7 +1023,7 @@ extern "C" int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* ti
                                int cap, int32_t* n_out)
 {
     if (!ctx) return VO_ERR_INVALID;
-    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!batch_ready(ctx)) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (pair < 0 || pair >= ctx->last_pairs || !n_out) FAIL(VO_ERR_INVALID, "bad pair index");
     HIPCHK(hipSetDevice(ctx->device));
     int n = 0;
@@ -971,7 +1031,7 @@ extern "C" int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* ti
     HIPCHK(hipMemcpy(&n, ctx->pb.m_count + pair, sizeof(int), hipMemcpyDeviceToHost));
     if (n > cap) n = cap;
     *n_out = n;
-    const size_t o = (size_t)pair * ctx->g.kp_cap;
+    const size_t o = (size_t)pair * batch_cap(ctx);
     if (n > 0) {
         if (qidx) HIPCHK(hipMemcpy(qidx, ctx->pb.m_q + o, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
         if (tidx) HIPCHK(hipMemcpy(tidx, ctx->pb.m_t + o, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -1013,8 +1073,8 @@ extern "C" int vo_comm_destroy(vo_ctx* ctx)
 extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
 {
     if (!ctx) return VO_ERR_INVALID;
-    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
-    if (B < 0 || B > ctx->max_pairs || !gathered) FAIL(VO_ERR_INVALID, "bad gather arguments");
+    if (!batch_ready(ctx)) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (B < 0 || B > batch_max_pairs(ctx) || !gathered) FAIL(VO_ERR_INVALID, "bad gather arguments");
     if (B == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     const int world = ctx->comm ? ctx->comm_world : 1;
@@ -1024,12 +1084,12 @@ extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
         if (ctx->rec_send) (void)hipFree(ctx->rec_send);
         if (ctx->rec_recv) (void)hipFree(ctx->rec_recv);
         ctx->rec_send = ctx->rec_recv = nullptr; ctx->rec_cap = 0;
-        HIPCHK(dmalloc(&ctx->rec_send, (size_t)ctx->max_pairs * VO_RECORD_DOUBLES));
-        HIPCHK(dmalloc(&ctx->rec_recv, (size_t)ctx->max_pairs * VO_RECORD_DOUBLES * world));
-        ctx->rec_cap = (size_t)ctx->max_pairs * VO_RECORD_DOUBLES * world;
+        HIPCHK(dmalloc(&ctx->rec_send, (size_t)batch_max_pairs(ctx) * VO_RECORD_DOUBLES));
+        HIPCHK(dmalloc(&ctx->rec_recv, (size_t)batch_max_pairs(ctx) * VO_RECORD_DOUBLES * world));
+        ctx->rec_cap = (size_t)batch_max_pairs(ctx) * VO_RECORD_DOUBLES * world;
     }
     hipStream_t s = ctx->stream;
-    StageTimer t(ctx, ST_MISC);
+    StageTimer t(ctx, ST_GATHER);
     launch_pack_records(s, ctx->pb.res, B, ctx->rec_send);
     HIPCHK(hipGetLastError());
     const double* src = ctx->rec_send;
@@ -1665,7 +1725,7 @@ extern "C" int vo_frames_ingest(vo_ctx* ctx, const uint8_t* frames, int F, int s
 }
 
 
-// ------------------------------------------------------------------ "next" row: SIFT, the reference's live detector (visual_slam.py:17)
+// ------------------------------------------------------------------ SIFT, the reference's live detector (visual_slam.py:17), frame-batched
 // getGaussianKernel(n, sigma, CV_32F) with n = cvRound(sigma * 8 + 1) | 1
 static int sift_gauss_taps(double sigma, float* k)
 {
@@ -1679,6 +1739,135 @@ static int sift_gauss_taps(double sigma, float* k)
     return n;
 }
 
+static void sift_free(SiftState& S)
+{
+    void* ptrs[] = {S.frames, S.kp_xy, S.kp_size, S.kp_angle, S.kp_resp, S.kp_oct, S.kp_count, S.flags, S.desc, S.desc_x, S.norms,
+                    S.G, S.D, S.up, S.cand, S.surv, S.kraw, S.ksorted, S.kfin, S.rank, S.counts, S.fin_count, S.fin_flags};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    S = SiftState();
+}
+
+// Buffers of one SIFT configuration: the per-slot results (keypoints, descriptors, matcher operands) for max_frames slots and
+// the scale-space scratch of one sub-batch of `fb` frames.
+static int sift_setup(vo_ctx* ctx, SiftState& S, int h, int w, const vo_sift_params* p, int max_frames, int kp_cap, int raw_cap, int cand_cap,
+                      int surv_cap, int fb, bool with_operands)
+{
+    if (p->n_octave_layers < 1 || p->n_octave_layers > 8 || !(p->sigma > 0.5) || p->nfeatures < 0)
+        FAIL(VO_ERR_UNSUPPORTED, "SIFT: nOctaveLayers 1..8, sigma > 0.5 and nfeatures >= 0 are built");
+    if (S.configured && S.h == h && S.w == w && memcmp(&S.prm, p, sizeof(*p)) == 0 && S.max_frames >= max_frames && S.kp_cap == kp_cap &&
+        S.raw_cap == raw_cap && S.cand_cap == cand_cap && S.surv_cap == surv_cap && S.fb >= fb && S.with_operands == with_operands)
+        return VO_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    sift_free(S);
+    S.h = h; S.w = w; S.prm = *p; S.max_frames = max_frames; S.kp_cap = kp_cap; S.raw_cap = raw_cap; S.cand_cap = cand_cap; S.surv_cap = surv_cap;
+    S.fb = fb; S.with_operands = with_operands; S.cap_x = desc_x_rows(kp_cap);
+    S.fstride = align_up(w, 4);
+    const int L = p->n_octave_layers;
+    SiftGeom& P = S.P; memset(&P, 0, sizeof(P));
+    P.nLayers = L;
+    int nOct = (int)lrint(log((double)(2 * (w < h ? w : h))) / log(2.) - 2) + 1;
+    if (nOct < 1) nOct = 1;
+    if (nOct > SIFT_MAX_OCT) nOct = SIFT_MAX_OCT;
+    size_t gtot = 0, dtot = 0;
+    for (int o = 0; o < nOct; o++) {
+        P.w[o] = o ? P.w[o - 1] / 2 : 2 * w; P.h[o] = o ? P.h[o - 1] / 2 : 2 * h;
+        if (P.w[o] < 1 || P.h[o] < 1) { nOct = o; break; }
+        P.stride[o] = align_up(P.w[o], 16);
+        P.plane[o] = (size_t)P.stride[o] * P.h[o];
+        P.goff[o] = gtot; P.doff[o] = dtot;
+        gtot += (size_t)(L + 2) * P.plane[o]; dtot += (size_t)(L + 2) * P.plane[o];
+    }
+    P.nOct = nOct; P.gframe = gtot; P.dframe = dtot;
+    // Gaussian taps of the base image (createInitialImage) and of the incremental blurs (buildGaussianPyramid)
+    {
+        const double k = pow(2., 1. / L);
+        const float sd = sqrtf(fmaxf((float)(p->sigma * p->sigma - 0.5 * 0.5 * 4), 0.01f));
+        S.ntaps[0] = sift_gauss_taps((double)sd, S.taps[0]);
+        for (int i = 1; i < L + 3; i++) {
+            const double sp = pow(k, (double)(i - 1)) * p->sigma, st = sp * k;
+            S.ntaps[i] = sift_gauss_taps(sqrt(st * st - sp * sp), S.taps[i]);
+        }
+        for (int i = 0; i < L + 3; i++) if (S.ntaps[i] < 0 || S.ntaps[i] > 63) FAIL(VO_ERR_UNSUPPORTED, "SIFT: blur kernel wider than 63 taps");
+    }
+    for (int i = 0; i < 64; i++) S.E.tab[i] = (float)pow(2.0, i / 64.0);
+    const size_t F = (size_t)max_frames, B = (size_t)fb;
+    HIPCHK(dmalloc(&S.frames, F * S.fstride * h + 64));
+    HIPCHK(dmalloc(&S.kp_xy, F * kp_cap * 2)); HIPCHK(dmalloc(&S.kp_size, F * kp_cap)); HIPCHK(dmalloc(&S.kp_angle, F * kp_cap));
+    HIPCHK(dmalloc(&S.kp_resp, F * kp_cap)); HIPCHK(dmalloc(&S.kp_oct, F * kp_cap));
+    HIPCHK(dmalloc(&S.kp_count, F)); HIPCHK(dmalloc(&S.flags, F));
+    HIPCHK(hipMemset(S.kp_count, 0, F * sizeof(int))); HIPCHK(hipMemset(S.flags, 0, F * sizeof(int)));
+    HIPCHK(dmalloc(&S.desc, F * kp_cap * 128));
+    if (with_operands) {
+        HIPCHK(dmalloc(&S.desc_x, F * (size_t)S.cap_x * 128)); HIPCHK(dmalloc(&S.norms, F * (size_t)S.cap_x));
+        HIPCHK(hipMemset(S.desc_x, 0, F * (size_t)S.cap_x * 128)); HIPCHK(hipMemset(S.norms, 0, F * (size_t)S.cap_x * sizeof(int)));
+    }
+    HIPCHK(dmalloc(&S.G, B * gtot)); HIPCHK(dmalloc(&S.D, B * dtot)); HIPCHK(dmalloc(&S.up, B * P.plane[0]));
+    HIPCHK(dmalloc(&S.cand, B * cand_cap)); HIPCHK(dmalloc(&S.surv, B * surv_cap));
+    HIPCHK(dmalloc(&S.kraw, B * raw_cap)); HIPCHK(dmalloc(&S.ksorted, B * raw_cap)); HIPCHK(dmalloc(&S.kfin, B * kp_cap));
+    HIPCHK(dmalloc(&S.rank, B * raw_cap)); HIPCHK(dmalloc(&S.counts, B * 4)); HIPCHK(dmalloc(&S.fin_count, B)); HIPCHK(dmalloc(&S.fin_flags, B));
+    HIPCHK(hipDeviceSynchronize());
+    S.configured = true;
+    return VO_OK;
+}
+
+// Scale space, extrema, refinement, orientation, sort + duplicate removal of the frames src[0..F) (F <= S.fb): everything up to the
+// final keypoint list S.kfin / S.counts[.][3], enqueued on the context's stream, no host round trip.
+static int sift_detect_enqueue(vo_ctx* ctx, SiftState& S, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int F)
+{
+    hipStream_t s = ctx->stream;
+    const SiftGeom& P = S.P;
+    const int L = P.nLayers;
+    HIPCHK(hipMemsetAsync(S.counts, 0, (size_t)F * 4 * sizeof(int), s));
+    {
+        StageTimer t(ctx, ST_SIFT_SCALE);
+        launch_sb_base(s, src, channels, row_stride, frame_stride, S.w, S.h, S.up, P.stride[0], P.plane[0], F);
+        if (launch_sb_sweep(s, S.up, P.plane[0], S.G + P.goff[0], P.gframe, nullptr, 0, P.w[0], P.h[0], P.stride[0], F, S.taps[0], S.ntaps[0]))
+            FAIL(VO_ERR_UNSUPPORTED, "SIFT: unsupported blur size");
+    }
+    const float threshold = (float)(int)floor(0.5 * S.prm.contrast_threshold / L * 255);
+    for (int o = 0; o < P.nOct; o++) {
+        {
+            StageTimer t(ctx, ST_SIFT_SCALE);
+            float* g0 = S.G + P.goff[o];
+            if (o > 0) launch_sb_half(s, S.G + P.goff[o - 1] + (size_t)L * P.plane[o - 1], P.gframe, P.w[o - 1], P.h[o - 1], P.stride[o - 1],
+                                      g0, P.gframe, P.w[o], P.h[o], P.stride[o], F);
+            for (int i = 1; i < L + 3; i++) {
+                // G[i] = blur(G[i-1]) and D[i-1] = G[i] - G[i-1] in one pass; the last Gaussian of the octave is not stored
+                float* gi = i < L + 2 ? g0 + (size_t)i * P.plane[o] : nullptr;
+                launch_sb_sweep(s, g0 + (size_t)(i - 1) * P.plane[o], P.gframe, gi, P.gframe, S.D + P.doff[o] + (size_t)(i - 1) * P.plane[o], P.dframe,
+                                P.w[o], P.h[o], P.stride[o], F, S.taps[i], S.ntaps[i]);
+            }
+        }
+        { StageTimer t(ctx, ST_SIFT_EXTREMA); launch_sb_extrema(s, P, S.D, o, threshold, S.cand, S.counts, S.cand_cap, F); }
+    }
+    const int waves = 2048 / (F < 8 ? F : 8) > 64 ? 2048 / (F < 8 ? F : 8) : 64;        // persistent wavefronts per frame for the wave-per-item kernels
+    {
+        StageTimer t(ctx, ST_SIFT_ORIENT);
+        launch_sb_refine_orient(s, P, S.G, S.D, S.cand, S.cand_cap, (float)S.prm.contrast_threshold, (float)S.prm.edge_threshold, (float)S.prm.sigma, S.E,
+                                S.surv, S.surv_cap, S.kraw, S.raw_cap, S.counts, F, waves);
+    }
+    {
+        StageTimer t(ctx, ST_SIFT_SORT);
+        launch_sb_sort_emit(s, S.kraw, S.raw_cap, S.counts, S.rank, S.ksorted, S.kfin, S.kp_cap, S.fin_count, S.fin_flags, S.cand_cap, S.surv_cap, F);
+    }
+    HIPCHK(hipGetLastError());
+    return VO_OK;
+}
+
+// descriptors of the final keypoints of the sub-batch into slots first_slot.. + the SoA arrays the pair stage reads
+static int sift_describe_enqueue(vo_ctx* ctx, SiftState& S, int first_slot, int F)
+{
+    hipStream_t s = ctx->stream;
+    const int waves = 2048 / (F < 8 ? F : 8) > 64 ? 2048 / (F < 8 ? F : 8) : 64;
+    {
+        StageTimer t(ctx, ST_SIFT_SORT);
+        launch_sb_unpack(s, S.kfin, S.kp_cap, S.counts, first_slot, S.kp_xy, S.kp_size, S.kp_angle, S.kp_resp, S.kp_oct, S.kp_count, S.fin_count, S.fin_flags, S.flags, F);
+    }
+    { StageTimer t(ctx, ST_SIFT_DESC); launch_sb_descriptor(s, S.P, S.G, S.kfin, S.kp_cap, S.counts, S.E, S.desc, S.desc_x, S.cap_x, S.norms, S.flags, first_slot, F, waves); }
+    HIPCHK(hipGetLastError());
+    return VO_OK;
+}
+
 extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h, int w, int channels, int row_stride, const vo_sift_params* p,
                                           float* kp_xy, float* kp_size, float* kp_angle, float* kp_response, int32_t* kp_octave, float* desc,
                                           int cap, int32_t* n_out)
@@ -1688,131 +1877,156 @@ extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h
     if (!p) p = &def;
     if (!img || !n_out || h < 2 || w < 2 || (channels != 1 && channels != 3 && channels != 4) || row_stride < w * channels || cap < 0)
         FAIL(VO_ERR_INVALID, "bad arguments");
-    if (p->n_octave_layers < 1 || p->n_octave_layers > 8 || !(p->sigma > 0.5) || p->nfeatures < 0)
-        FAIL(VO_ERR_UNSUPPORTED, "SIFT: nOctaveLayers 1..8, sigma > 0.5 and nfeatures >= 0 are built");
     HIPCHK(hipSetDevice(ctx->device));
-    const int L = p->n_octave_layers, per = L + 3;
-    SiftPyr P; memset(&P, 0, sizeof(P));
-    P.nLayers = L;
-    int nOct = (int)lrint(log((double)(2 * (w < h ? w : h))) / log(2.) - 2) + 1;
-    if (nOct < 1) nOct = 1;
-    if (nOct > SIFT_MAX_OCT) nOct = SIFT_MAX_OCT;
-    size_t gtot = 0, dtot = 0;
-    for (int o = 0; o < nOct; o++) {
-        P.w[o] = o ? P.w[o - 1] / 2 : 2 * w; P.h[o] = o ? P.h[o - 1] / 2 : 2 * h;
-        if (P.w[o] < 1 || P.h[o] < 1) { nOct = o; break; }
-        P.goff[o] = gtot; P.doff[o] = dtot;
-        gtot += (size_t)per * P.w[o] * P.h[o]; dtot += (size_t)(L + 2) * P.w[o] * P.h[o];
-    }
-    P.nOct = nOct;
-    // Gaussian taps of the incremental blurs (buildGaussianPyramid) and of the base image (createInitialImage)
-    float taps[16][SIFT_MAX_TAPS]; int ntaps[16];
-    {
-        const double k = pow(2., 1. / L);
-        const float sd = sqrtf(fmaxf((float)(p->sigma * p->sigma - 0.5 * 0.5 * 4), 0.01f));
-        ntaps[0] = sift_gauss_taps((double)sd, taps[0]);
-        for (int i = 1; i < per; i++) {
-            const double sp = pow(k, (double)(i - 1)) * p->sigma, st = sp * k;
-            ntaps[i] = sift_gauss_taps(sqrt(st * st - sp * sp), taps[i]);
-        }
-        for (int i = 0; i < per; i++) if (ntaps[i] < 0) FAIL(VO_ERR_UNSUPPORTED, "SIFT: blur kernel wider than %d taps", SIFT_MAX_TAPS);
-    }
-    SiftExpTab E;
-    for (int i = 0; i < 64; i++) E.tab[i] = (float)pow(2.0, i / 64.0);
-    const size_t base_px = (size_t)4 * w * h, img_bytes = ((size_t)row_stride * h + 255) & ~(size_t)255;
-    const int cand_cap = 1 << 20, kp_cap = 1 << 18;
-    // layout: [gauss][dog][tmp (one base-size image)][up-sampled base][candidates][keypoints][2 counters][image bytes][descriptors]
-    size_t off = 0;
-    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_g = take(gtot * 4), o_d = take(dtot * 4), o_tmp = take(base_px * 4), o_up = take(base_px * 4),
-                 o_cand = take((size_t)cand_cap * sizeof(SiftCand)), o_kp = take((size_t)kp_cap * sizeof(SiftKp)), o_cnt = take(256),
-                 o_surv = take((size_t)kp_cap * sizeof(SiftSurv)),
-                 o_img = take(img_bytes), o_desc = take((size_t)kp_cap * 128 * 4);
-    int rc = ensure_bytes(ctx, &ctx->sift_buf, &ctx->sift_buf_n, off); if (rc) return rc;
-    uint8_t* B = ctx->sift_buf;
-    float *G = (float*)(B + o_g), *Dg = (float*)(B + o_d), *tmp = (float*)(B + o_tmp), *up = (float*)(B + o_up), *ddesc = (float*)(B + o_desc);
-    SiftCand* dcand = (SiftCand*)(B + o_cand); SiftKp* dkp = (SiftKp*)(B + o_kp); int* dcnt = (int*)(B + o_cnt); SiftSurv* dsurv = (SiftSurv*)(B + o_surv);
-    P.gauss = G; P.dog = Dg;
+    // the single-image call = the batched pipeline with one frame; capacities as generous as the per-image lists of cv2 need
+    SiftState& S = ctx->sift1;
+    int rc = sift_setup(ctx, S, h, w, p, 1, 1 << 18, 1 << 18, 1 << 20, 1 << 18, 1, false);
+    if (rc) return rc;
     hipStream_t s = ctx->stream;
-    HIPCHK(hipMemcpyAsync(B + o_img, img, (size_t)row_stride * h, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(dcnt, 0, 256, s));
-    {
-        StageTimer t(ctx, ST_MISC);
-        launch_sift_base(s, B + o_img, channels, row_stride, w, h, up);
-        for (int o = 0; o < nOct; o++) {
-            const size_t plane = (size_t)P.w[o] * P.h[o];
-            float* g0 = G + P.goff[o];
-            if (o == 0) launch_sift_blur(s, up, tmp, g0, P.w[0], P.h[0], taps[0], ntaps[0]);
-            else launch_sift_half(s, G + P.goff[o - 1] + (size_t)L * P.w[o - 1] * P.h[o - 1], P.w[o - 1], P.h[o - 1], g0, P.w[o], P.h[o]);
-            for (int i = 1; i < per; i++) launch_sift_blur(s, g0 + (size_t)(i - 1) * plane, tmp, g0 + (size_t)i * plane, P.w[o], P.h[o], taps[i], ntaps[i]);
-            launch_sift_dog(s, g0, g0 + plane, Dg + P.doff[o], (size_t)(L + 2) * plane);       // every DoG image of the octave in one launch
-        }
-        const float threshold = (float)(int)floor(0.5 * p->contrast_threshold / L * 255);
-        for (int o = 0; o < nOct; o++) launch_sift_extrema(s, Dg + P.doff[o], P.w[o], P.h[o], L, o, threshold, dcand, dcnt, cand_cap);
-    }
-    HIPCHK(hipGetLastError());
-    int counts[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(counts, dcnt, sizeof(int), hipMemcpyDeviceToHost, s));
+    const size_t img_bytes = (size_t)row_stride * h;
+    rc = ensure_bytes(ctx, &ctx->sift_img, &ctx->sift_img_n, img_bytes); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->sift_img, img, img_bytes, hipMemcpyHostToDevice, s));
+    rc = sift_detect_enqueue(ctx, S, ctx->sift_img, channels, row_stride, 0, 1); if (rc) return rc;
+    int counts[4] = {0, 0, 0, 0}, fin = 0, fl = 0;
+    HIPCHK(hipMemcpyAsync(counts, S.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&fin, S.fin_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&fl, S.fin_flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    int warn = VO_OK;
-    int ncand = counts[0];
-    if (ncand > cand_cap) { ncand = cand_cap; warn = VO_WARN_CAPACITY; }
-    { StageTimer t(ctx, ST_MISC); launch_sift_refine(s, P, dcand, ncand, (float)p->contrast_threshold, (float)p->edge_threshold, (float)p->sigma, E, dsurv, dcnt + 2, kp_cap, dkp, dcnt + 1, kp_cap); }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(counts + 1, dcnt + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    int nk = counts[1];
-    if (nk > kp_cap) { nk = kp_cap; warn = VO_WARN_CAPACITY; }
-    std::vector<SiftKp> kps((size_t)nk);
-    if (nk) HIPCHK(hipMemcpy(kps.data(), dkp, (size_t)nk * sizeof(SiftKp), hipMemcpyDeviceToHost));
-    // KeyPointsFilter::removeDuplicatedSorted: KeyPoint_LessThan order, then drop repeats of (pt, size, angle).  The kernel
-    // appends keypoints in no fixed order; the comparator's last key (the index) only separates identical records.
-    std::sort(kps.begin(), kps.end(), [](const SiftKp& a, const SiftKp& b) {
-        if (a.x != b.x) return a.x < b.x;
-        if (a.y != b.y) return a.y < b.y;
-        if (a.size != b.size) return a.size > b.size;
-        if (a.angle != b.angle) return a.angle < b.angle;
-        if (a.response != b.response) return a.response > b.response;
-        if (a.octave != b.octave) return a.octave > b.octave;
-        return false;
-    });
-    int m = 0;
-    for (int i = 0; i < nk; i++) {
-        if (m > 0 && kps[i].x == kps[m - 1].x && kps[i].y == kps[m - 1].y && kps[i].size == kps[m - 1].size && kps[i].angle == kps[m - 1].angle) continue;
-        kps[m++] = kps[i];
-    }
+    int warn = fl ? VO_WARN_CAPACITY : VO_OK;
+    int m = counts[3];
+    std::vector<SiftKp> kps;
     if (p->nfeatures > 0 && m > p->nfeatures) {
         // KeyPointsFilter::retainBest(keypoints, nfeatures): literally what cv2 runs — libstdc++'s nth_element on the response,
         // then every tie with the n-th response kept by partition; the list stays in that permutation
+        kps.resize((size_t)m);
+        HIPCHK(hipMemcpy(kps.data(), S.kfin, (size_t)m * sizeof(SiftKp), hipMemcpyDeviceToHost));
         auto greater = [](const SiftKp& a, const SiftKp& b) { return a.response > b.response; };
         std::nth_element(kps.begin(), kps.begin() + p->nfeatures - 1, kps.begin() + m, greater);
         const float amb = kps[(size_t)p->nfeatures - 1].response;
         auto new_end = std::partition(kps.begin() + p->nfeatures, kps.begin() + m, [amb](const SiftKp& k) { return k.response >= amb; });
         m = (int)(new_end - kps.begin());
-    }
-    for (int i = 0; i < m; i++) {                                 // firstOctave = -1: back to the coordinates of the input image
-        kps[i].octave = (kps[i].octave & ~255) | ((kps[i].octave - 1) & 255);
-        kps[i].x *= 0.5f; kps[i].y *= 0.5f; kps[i].size *= 0.5f;
+        HIPCHK(hipMemcpyAsync(S.kfin, kps.data(), (size_t)m * sizeof(SiftKp), hipMemcpyHostToDevice, s));
+        counts[3] = m;
+        HIPCHK(hipMemcpyAsync(S.counts + 3, &counts[3], sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(S.fin_count, &counts[3], sizeof(int), hipMemcpyHostToDevice, s));
     }
     *n_out = m;
     const int nw = m < cap ? m : cap;
-    if (nw > 0 && desc) {
-        HIPCHK(hipMemcpyAsync(dkp, kps.data(), (size_t)nw * sizeof(SiftKp), hipMemcpyHostToDevice, s));
-        { StageTimer t(ctx, ST_BRIEF); launch_sift_descriptor(s, P, dkp, nw, E, ddesc); }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(desc, ddesc, (size_t)nw * 128 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (nw > 0) {
+        rc = sift_describe_enqueue(ctx, S, 0, 1); if (rc) return rc;
         HIPCHK(hipStreamSynchronize(s));
-    }
-    for (int i = 0; i < nw; i++) {
-        if (kp_xy) { kp_xy[2 * i] = kps[i].x; kp_xy[2 * i + 1] = kps[i].y; }
-        if (kp_size) kp_size[i] = kps[i].size;
-        if (kp_angle) kp_angle[i] = kps[i].angle;
-        if (kp_response) kp_response[i] = kps[i].response;
-        if (kp_octave) kp_octave[i] = kps[i].octave;
+        if (kp_xy) HIPCHK(hipMemcpy(kp_xy, S.kp_xy, (size_t)nw * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_size) HIPCHK(hipMemcpy(kp_size, S.kp_size, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_angle) HIPCHK(hipMemcpy(kp_angle, S.kp_angle, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_response) HIPCHK(hipMemcpy(kp_response, S.kp_resp, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_octave) HIPCHK(hipMemcpy(kp_octave, S.kp_oct, (size_t)nw * sizeof(int), hipMemcpyDeviceToHost));
+        if (desc) {
+            std::vector<uint8_t> d8((size_t)nw * 128);
+            HIPCHK(hipMemcpy(d8.data(), S.desc, d8.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < d8.size(); i++) desc[i] = (float)d8[i];     // cv2 hands the integer bin values out as float32
+        }
     }
     if (ctx->prof) prof_collect(ctx);
     if (m > cap) warn = VO_WARN_CAPACITY;
     return warn;
+}
+
+// ---- SIFT as the detector of the batched, HBM-resident path (vo_frames_upload / _detect / vo_pairs_run dispatch on it)
+extern "C" int vo_batch_configure_sift(vo_ctx* ctx, int h, int w, const vo_sift_params* params, int max_frames, int max_pairs, int kp_cap)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    vo_sift_params def = {0, 3, 0.04, 10.0, 1.6};
+    if (!params) params = &def;
+    if (h < 2 || w < 2 || max_frames < 1 || max_pairs < 1 || kp_cap < 0) FAIL(VO_ERR_INVALID, "bad sizes");
+    if (params->nfeatures != 0) FAIL(VO_ERR_UNSUPPORTED, "the batched SIFT path keeps every keypoint (nfeatures = 0, cv2.SIFT_create()'s default, as the reference runs it)");
+    if (kp_cap == 0) {                                          // default: ~2.5x what a textured frame of this size yields, at least 1024
+        const long long px = (long long)h * w;
+        kp_cap = (int)(px / 100 < 1024 ? 1024 : px / 100);
+    }
+    kp_cap = align_up(kp_cap, 256);
+    if (kp_cap > 65536) FAIL(VO_ERR_INVALID, "kp_cap > 65536");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const char* ev = getenv("VO_SIFT_SUBBATCH");
+    int fb = ev ? atoi(ev) : 16;
+    if (fb < 1) fb = 1;
+    if (fb > max_frames) fb = max_frames;
+    // the intermediate lists (sub-batch scratch) are generous whatever kp_cap is: only the final list is cut at kp_cap, in cv2's
+    // list order, as long as they do not overflow themselves (flagged)
+    const int raw_cap = 2 * kp_cap > 16384 ? 2 * kp_cap : 16384, cand_cap = 8 * kp_cap > 65536 ? 8 * kp_cap : 65536;
+    int rc = sift_setup(ctx, ctx->sift, h, w, params, max_frames, kp_cap, raw_cap, cand_cap, raw_cap, fb, true);
+    if (rc) return rc;
+    if (ctx->pb_pairs < max_pairs || ctx->pb_cap != kp_cap) {
+        free_pairbuf(ctx->pb);
+        HIPCHK(alloc_pairbuf(ctx->pb, max_pairs, kp_cap, false));
+        ctx->pb_pairs = max_pairs; ctx->pb_cap = kp_cap;
+    }
+    ctx->sift_pairs = max_pairs;
+    ctx->detector = 1;
+    return VO_OK;
+}
+
+extern "C" int vo_frame_features_sift(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
+                                      int32_t* kp_octave, uint8_t* desc, int cap, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    SiftState& S = ctx->sift;
+    if (ctx->detector != 1 || !S.configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure_sift has not been called");
+    if (slot < 0 || slot >= S.max_frames || !n_out) FAIL(VO_ERR_INVALID, "bad slot");
+    HIPCHK(hipSetDevice(ctx->device));
+    int n = 0, flags = 0;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(&n, S.kp_count + slot, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&flags, S.flags + slot, sizeof(int), hipMemcpyDeviceToHost));
+    int warn = (flags & 1) ? VO_WARN_CAPACITY : VO_OK;
+    if (n > S.kp_cap) n = S.kp_cap;
+    if (n > cap) { n = cap; warn = VO_WARN_CAPACITY; }
+    *n_out = n;
+    const size_t o = (size_t)slot * S.kp_cap;
+    if (n > 0) {
+        if (kp_xy) HIPCHK(hipMemcpy(kp_xy, S.kp_xy + o * 2, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_size) HIPCHK(hipMemcpy(kp_size, S.kp_size + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_angle) HIPCHK(hipMemcpy(kp_angle, S.kp_angle + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_response) HIPCHK(hipMemcpy(kp_response, S.kp_resp + o, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (kp_octave) HIPCHK(hipMemcpy(kp_octave, S.kp_oct + o, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (desc) HIPCHK(hipMemcpy(desc, S.desc + o * 128, (size_t)n * 128, hipMemcpyDeviceToHost));
+    }
+    if (flags & 2) FAIL(VO_ERR_INVALID, "a SIFT descriptor row broke the norm bound of the integer matcher (slot %d)", slot);
+    return warn;
+}
+
+static int sift_frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
+{
+    SiftState& S = ctx->sift;
+    if (!frames || F < 0 || first_slot < 0 || first_slot + F > S.max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (row_stride < S.w) FAIL(VO_ERR_INVALID, "row_stride < width");
+    if (F == 0) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t fbytes = (size_t)S.fstride * S.h;
+    uint8_t* dst0 = S.frames + (size_t)first_slot * fbytes;
+    if (row_stride == S.w && S.fstride == S.w && frame_stride >= (int64_t)S.w * S.h) {
+        HIPCHK(hipMemcpy2DAsync(dst0, fbytes, frames, (size_t)frame_stride, fbytes, F, hipMemcpyHostToDevice, ctx->stream));
+        return VO_OK;
+    }
+    for (int f = 0; f < F; f++)
+        HIPCHK(hipMemcpy2DAsync(dst0 + (size_t)f * fbytes, S.fstride, frames + (size_t)f * frame_stride, row_stride, S.w, S.h, hipMemcpyHostToDevice, ctx->stream));
+    return VO_OK;
+}
+
+static int sift_frames_detect_enqueue(vo_ctx* ctx, int first_slot, int F)
+{
+    SiftState& S = ctx->sift;
+    if (F < 0 || first_slot < 0 || first_slot + F > S.max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t fbytes = (size_t)S.fstride * S.h;
+    for (int f0 = 0; f0 < F; f0 += S.fb) {
+        const int n = F - f0 < S.fb ? F - f0 : S.fb;
+        int rc = sift_detect_enqueue(ctx, S, S.frames + (size_t)(first_slot + f0) * fbytes, 1, S.fstride, (int64_t)fbytes, n);
+        if (rc) return rc;
+        rc = sift_describe_enqueue(ctx, S, first_slot + f0, n);
+        if (rc) return rc;
+    }
+    return VO_OK;
 }
 
 // ------------------------------------------------------------------ "next" row: JPEG decode (cv2.imread, visual_slam.py:346)
@@ -2041,6 +2255,20 @@ extern "C" const char* vo_stage_name(int stage)
 // input once and writes its output once; padding columns are not counted).
 extern "C" double vo_stage_bytes(vo_ctx* ctx, int stage, int F)
 {
+    if (ctx && ctx->detector == 1 && ctx->sift.configured) {
+        // SIFT: float planes.  One layer sweep reads its source plane and writes a Gaussian and a DoG plane; per octave
+        // nLayers + 2 sweeps (the last one writes no Gaussian); the base image: u8 in, float out, one blur; next-octave seeds.
+        const SiftState& S = ctx->sift;
+        const int L = S.P.nLayers;
+        double px = 0;
+        for (int o = 0; o < S.P.nOct; o++) px += (double)S.P.w[o] * S.P.h[o];
+        const double p0 = (double)S.P.w[0] * S.P.h[0];
+        double b = 0;
+        if (stage == ST_SIFT_SCALE) b = (double)S.w * S.h + 4.0 * p0 * 3 + 4.0 * px * ((L + 2) + (L + 1) + (L + 2)) + 4.0 * (px - p0) * 1.25;
+        else if (stage == ST_SIFT_EXTREMA) b = 4.0 * px * (L + 2);
+        else if (stage == ST_MATCH_NN) b = 2.0 * S.kp_cap * 128;
+        return b * F;
+    }
     if (!ctx || !ctx->configured) return 0.0;
     const PyrGeom& g = ctx->g;
     double px[VO_MAX_LEVELS], total = 0;

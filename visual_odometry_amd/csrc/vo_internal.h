@@ -8,7 +8,7 @@
 enum {
     ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_SELECT_FAST, ST_HARRIS, ST_SELECT_HARRIS, ST_ANGLE,
     ST_BLUR, ST_BRIEF, ST_MATCH_NN, ST_MATCH_SELECT, ST_RANSAC, ST_POSE, ST_TRIANGULATE,
-    ST_MISC, ST_RESERVED
+    ST_MISC, ST_RESERVED, ST_SIFT_SCALE, ST_SIFT_EXTREMA, ST_SIFT_ORIENT, ST_SIFT_SORT, ST_SIFT_DESC, ST_CV2_ORDER, ST_GATHER, ST_RESERVED2
 };
 
 // ---- pyramid / work geometry, passed to kernels by value ------------------------------------
@@ -173,29 +173,42 @@ void launch_resize_linear(hipStream_t st, const uint8_t* src, int sw, int sh, in
                           const int* xofs, const void* xa, const int* yofs, const void* yb, int area2, int F);
 void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride, uint8_t* dst, int dw, int dh, int dstride,
                         int isx, int isy, const int* xsi, const float* xal, const int* xst, const int* ysi, const float* yal, const int* yst);
-// ---- SIFT (sift_kernels.hip): the reference's live detector, cv2.SIFT_create()
+// ---- SIFT (sift_batch.hip): the reference's live detector, cv2.SIFT_create(), frame-batched
 #define SIFT_IMG_BORDER 5
 #define SIFT_MAX_INTERP_STEPS 5
 #define SIFT_MAX_OCT 16
 #define SIFT_MAX_TAPS 64
-struct SiftPyr {                 // one frame's Gaussian and DoG pyramids: octave o holds nLayers + 3 / nLayers + 2 images of w[o] x h[o]
-    const float* gauss; const float* dog;
+// One frame's Gaussian and DoG pyramids (floats): octave o holds nLayers + 2 Gaussian and nLayers + 2 DoG planes of w[o] x h[o]
+// with a row pitch of stride[o] floats (a multiple of 16: every row starts on a 64-byte boundary).  The (nLayers + 3)rd
+// Gaussian image of an octave is never stored: it only feeds the last DoG plane, inside the kernel that computes it.
+struct SiftGeom {
     int nOct, nLayers;
-    int w[SIFT_MAX_OCT], h[SIFT_MAX_OCT];
-    size_t goff[SIFT_MAX_OCT], doff[SIFT_MAX_OCT];      // float offsets of the octave's first image
+    int w[SIFT_MAX_OCT], h[SIFT_MAX_OCT], stride[SIFT_MAX_OCT];
+    size_t plane[SIFT_MAX_OCT];                         // stride * h
+    size_t goff[SIFT_MAX_OCT], doff[SIFT_MAX_OCT];      // float offset of the octave's first plane inside a frame's block
+    size_t gframe, dframe;                              // floats per frame
 };
 struct SiftCand { int o, layer, r, c; };
 struct SiftKp { float x, y, size, angle, response; int octave; };
 struct SiftSurv { SiftKp kp; int o, layer, r, c; };      // a refined extremum awaiting its orientation(s)
 struct SiftExpTab { float tab[64]; };                   // 2^(i/64), the table of cv::hal::exp32f
-void launch_sift_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int sw, int sh, float* dst);
-void launch_sift_blur(hipStream_t s, const float* src, float* tmp, float* dst, int w, int h, const float* taps, int ntaps);
-void launch_sift_half(hipStream_t s, const float* src, int sw, int sh, float* dst, int dw, int dh);
-void launch_sift_dog(hipStream_t s, const float* a, const float* b, float* d, size_t n);
-void launch_sift_extrema(hipStream_t s, const float* dog_octave, int w, int h, int nLayers, int o, float threshold, SiftCand* cand, int* ncand, int cap);
-void launch_sift_refine(hipStream_t s, const SiftPyr& P, const SiftCand* cand, int ncand, float contrastThr, float edgeThr, float sigma,
-                        const SiftExpTab& E, SiftSurv* surv, int* nsurv, int cap_surv, SiftKp* kps, int* nkp, int cap);
-void launch_sift_descriptor(hipStream_t s, const SiftPyr& P, const SiftKp* kps, int nkp, const SiftExpTab& E, float* desc);
+// per-frame counters of a sub-batch: counts[f][4] = {extrema candidates, refined extrema, oriented keypoints, final keypoints}
+void launch_sb_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh, float* dst, int dstride, size_t dframe, int F);
+void launch_sb_half(hipStream_t s, const float* src, size_t sframe, int sw, int sh, int sstride, float* dst, size_t dframe, int dw, int dh, int dstride, int F);
+int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
+                    const float* taps, int ntaps);
+void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o, float threshold, SiftCand* cand, int* counts, int cap, int F);
+void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr,
+                             float edgeThr, float sigma, const SiftExpTab& E, SiftSurv* surv, int surv_cap, SiftKp* kps, int kp_cap, int* counts, int F, int waves);
+void launch_sb_sort_emit(hipStream_t s, const SiftKp* kps, int kp_cap, int* counts, int* rank, SiftKp* sorted, SiftKp* out, int out_cap, int* out_count,
+                         int* out_flags, int cand_cap, int surv_cap, int F);
+void launch_sb_descriptor(hipStream_t s, const SiftGeom& P, const float* gauss, const SiftKp* kps, int kp_cap, const int* counts, const SiftExpTab& E,
+                          uint8_t* desc, uint8_t* desc_x, int cap_x, int* norms, int* flags, int first_slot, int F, int waves);
+void launch_sb_unpack(hipStream_t s, const SiftKp* kps, int kp_cap, const int* counts, int first_slot, float* kp_xy, float* kp_size, float* kp_angle,
+                      float* kp_resp, int* kp_oct, int* kp_count, const int* fin_count, const int* fin_flags, int* flags, int F);
+// L2 nearest neighbours of integer-valued (0..255) 128-element descriptors on the matrix cores (match_kernels.hip)
+void launch_match_nn_l2i8(hipStream_t s, const uint8_t* desc_x, const int* norms, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,
+                          int dirs_mask, int knn2);
 
 // ---- JPEG decode (jpeg_kernels.hip, jpeg_host.cpp): cv2.imread in front of the path
 #include "jpeg_host.h"
@@ -227,7 +240,7 @@ void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, 
 void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_count, int kp_cap, PairBuf pb, int P,
                               int dirs_mask, int knn2);
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
-                         int mode, double ratio, const double* K);
+                         int mode, double ratio, const double* K, int l2 = 0);   // l2: nn_dist holds squared L2 distances, reported as sqrtf
 
 void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist, unsigned long long* key);
 

@@ -1,6 +1,8 @@
-"""Batched, device-resident front end: frames live in HBM, ORB + matching + E-RANSAC + pose (+ DLT) run
+"""Batched, device-resident front end: frames live in HBM, detection + matching + E-RANSAC + pose (+ DLT) run
 batch-major through the C ABI with no host round trip between stages.  This is the throughput path
-bench.py measures; the per-pair order is that of src/visual_slam.py:294-298."""
+bench.py measures; the per-pair order is that of src/visual_slam.py:294-298.  detector="orb" is the north-star
+instantiation (ORB + Hamming, src/image_and_keypoints.py:8-9); detector="sift" is the configuration the reference runs
+live (cv2.SIFT_create() + BFMatcher(NORM_L2, crossCheck=True), src/visual_slam.py:17,19)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -16,15 +18,30 @@ MATCH_CROSSCHECK, MATCH_RATIO, MATCH_CROSSCHECK_LEGACY = 0, 1, 2
 
 class FrontEnd:
     def __init__(self, height, width, max_frames, max_pairs, nfeatures=500, nlevels=8, device=0, ctx=None,
-                 keypoint_order="canonical", **orb_kw):
+                 keypoint_order="canonical", detector="orb", kp_cap=0, **det_kw):
         self.ctx = ctx or _lib.Context(device)
-        self.ctx.set_keypoint_order(keypoint_order)       # 'cv2': keypoint / match indices as cv2.ORB + BFMatcher number them
         self.h, self.w = int(height), int(width)
         self.max_frames, self.max_pairs = int(max_frames), int(max_pairs)
-        self.params = make_params(nfeatures=nfeatures, nlevels=nlevels, **orb_kw)
+        self.detector = detector
         c = self.ctx
-        c.check(c.lib.vo_batch_configure(c.handle, self.h, self.w, C.addressof(self.params), self.max_frames,
-                                         self.max_pairs))
+        if detector == "sift":
+            # cv2.SIFT_create(nfeatures=0, nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6); kp_cap: keypoints
+            # kept per frame (0 = a default from the frame size; more are truncated and flagged)
+            self.params = _lib.SiftParams(0, int(det_kw.pop("nOctaveLayers", 3)), float(det_kw.pop("contrastThreshold", 0.04)),
+                                          float(det_kw.pop("edgeThreshold", 10.0)), float(det_kw.pop("sigma", 1.6)))
+            if det_kw:
+                raise TypeError(f"unknown SIFT arguments {sorted(det_kw)}")
+            rc = c.lib.vo_batch_configure_sift(c.handle, self.h, self.w, C.addressof(self.params), self.max_frames, self.max_pairs, int(kp_cap))
+            if rc == _lib.VO_ERR_UNSUPPORTED:
+                raise NotImplementedError(c.last_error())
+            c.check(rc)
+        elif detector == "orb":
+            self.ctx.set_keypoint_order(keypoint_order)       # 'cv2': keypoint / match indices as cv2.ORB + BFMatcher number them
+            self.params = make_params(nfeatures=nfeatures, nlevels=nlevels, **det_kw)
+            c.check(c.lib.vo_batch_configure(c.handle, self.h, self.w, C.addressof(self.params), self.max_frames,
+                                             self.max_pairs))
+        else:
+            raise ValueError("detector must be 'orb' or 'sift'")
         self.kp_cap = int(c.lib.vo_batch_kp_capacity(c.handle))
         self._res = _lib.PinnedArray((self.max_pairs,), _lib.PAIR_RESULT_DTYPE)      # page-locked result buffers,
         self._X = None                                                                # reused by every run_pairs call
@@ -97,16 +114,21 @@ class FrontEnd:
         c.check(fn(c.handle, int(first_slot), int(count)))
 
     def features(self, slot):
+        """Keypoints and descriptors of a detected slot.  ORB: desc [n, 32] uint8; SIFT: desc [n, 128] float32 (the integer bin
+        values 0..255 cv2 returns as floats)."""
         cap = self.kp_cap
+        sift = self.detector == "sift"
         xy = np.empty((cap, 2), np.float32); size = np.empty(cap, np.float32); ang = np.empty(cap, np.float32)
-        resp = np.empty(cap, np.float32); octv = np.empty(cap, np.int32); desc = np.empty((cap, 32), np.uint8)
+        resp = np.empty(cap, np.float32); octv = np.empty(cap, np.int32); desc = np.empty((cap, 128 if sift else 32), np.uint8)
         n = C.c_int32(0)
         c = self.ctx
-        rc = c.check(c.lib.vo_frame_features(c.handle, int(slot), xy.ctypes.data, size.ctypes.data, ang.ctypes.data,
-                                             resp.ctypes.data, octv.ctypes.data, desc.ctypes.data, cap, C.addressof(n)))
+        fn = c.lib.vo_frame_features_sift if sift else c.lib.vo_frame_features
+        rc = c.check(fn(c.handle, int(slot), xy.ctypes.data, size.ctypes.data, ang.ctypes.data,
+                        resp.ctypes.data, octv.ctypes.data, desc.ctypes.data, cap, C.addressof(n)))
         k = n.value
+        d = desc[:k].astype(np.float32) if sift else desc[:k].copy()
         return dict(xy=xy[:k].copy(), size=size[:k].copy(), angle=ang[:k].copy(), response=resp[:k].copy(),
-                    octave=octv[:k].copy(), desc=desc[:k].copy(), truncated=(rc == _lib.VO_WARN_CAPACITY))
+                    octave=octv[:k].copy(), desc=d, truncated=(rc == _lib.VO_WARN_CAPACITY))
 
     def make_opts(self, match_mode=MATCH_CROSSCHECK, ratio=0.75, prob=0.99, thresh=1.0, max_iters=1000,
                   seed=OPENCV_RNG_SEED, dist_thresh=50.0, want_points=False):
