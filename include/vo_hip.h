@@ -218,6 +218,11 @@ int vo_comm_destroy(vo_ctx* ctx);
  * the asynchronous form, world * B * VO_RECORD_DOUBLES doubles, rank-major) is valid after the call (wait != 0) or
  * after the next vo_sync(ctx).  Without vo_comm_init (single process) it degenerates to the local records. */
 int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait);
+/* Rows at and beyond the pair count of that run (a short or empty last block) arrive as zeros with VO_ERR_NOT_CONFIGURED in the
+ * n_inl column.  vo_comm_allgather_f64: synchronous all-gather of n <= 4096 host doubles per rank over the same communicator
+ * (recv: world * n, rank-major) — a launcher's barrier and timing reduction without another communication library; without
+ * a communicator it copies send to recv. */
+int vo_comm_allgather_f64(vo_ctx* ctx, const double* send, int n, double* recv);
 
 /* ------------------------------------------------------------------ "next" row
  * Map.remove_observations_with_reprojection_errors_above_threshold / calculate_reprojection_error —

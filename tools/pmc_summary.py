@@ -1,5 +1,11 @@
-"""Summarise rocprofv3 --pmc CSV output: mean counter value per kernel name."""
-import csv, glob, sys, collections
+"""Summarise rocprofv3 --pmc CSV output per kernel name: mean over the launches and the value of the largest launch
+(the launches of one kernel differ by orders of magnitude where a stage runs once per pyramid octave).
+usage: pmc_summary.py <dir> [kernel name filter]"""
+import collections
+import csv
+import glob
+import sys
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(path)):
@@ -9,4 +15,4 @@ for k, cs in sorted(acc.items()):
         continue
     print(k)
     for c, v in sorted(cs.items()):
-        print(f"   {c:28s} mean {sum(v)/len(v):16.1f}  n={len(v)}")
+        print(f"   {c:28s} mean {sum(v)/len(v):16.1f}  max {max(v):16.1f}  n={len(v)}")

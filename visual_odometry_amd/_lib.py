@@ -81,6 +81,7 @@ _SIGS = {
     "vo_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vo_comm_destroy": (C.c_int, [_P]),
     "vo_pairs_gather": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "vo_comm_allgather_f64": (C.c_int, [_P, _P, C.c_int, _P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
     "vo_reprojection_filter": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, _P, _P]),
     "vo_solve_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_double, C.c_double, C.c_uint64, _P, _P, _P, _P]),
@@ -176,6 +177,13 @@ class Context:
 
     def comm_destroy(self):
         self.check(self.lib.vo_comm_destroy(self.handle))
+
+    def allgather(self, values, world):
+        """Synchronous all-gather of a few float64 per rank over the context's communicator -> [world, n]."""
+        v = np.ascontiguousarray(values, np.float64).ravel()
+        out = np.empty((int(world), len(v)), np.float64)
+        self.check(self.lib.vo_comm_allgather_f64(self.handle, v.ctypes.data, len(v), out.ctypes.data))
+        return out
 
     def set_keypoint_order(self, kind):
         """'canonical' (default): keypoints in (octave, y, x) order; 'cv2': the order cv2.ORB returns them in

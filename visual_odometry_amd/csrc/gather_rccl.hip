@@ -81,11 +81,14 @@ const char* rccl_all_gather_f64(void* comm, const double* send, double* recv, si
 
 // vo_pair_result -> 16 float64: R (9), t (3), n_kp1, n_match, n_inl, n_good (pairs that failed keep their status as a
 // negative n_inl so the receiver can tell)
-__global__ void k_pack_records(const vo_pair_result* res, int B, double* rec)
+// rows at and beyond `valid` (the pair count of the run that filled `res`) are padding of a short or empty block: zeros with
+// VO_ERR_NOT_CONFIGURED in the n_inl column, never whatever an earlier batch left in the buffer
+__global__ void k_pack_records(const vo_pair_result* res, int B, int valid, double* rec)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * VO_RECORD_DOUBLES) return;
     const int p = i / VO_RECORD_DOUBLES, k = i % VO_RECORD_DOUBLES;
+    if (p >= valid) { rec[i] = k == 14 ? (double)VO_ERR_NOT_CONFIGURED : 0.0; return; }
     const vo_pair_result& r = res[p];
     double v;
     if (k < 9) v = r.R[k];
@@ -97,8 +100,8 @@ __global__ void k_pack_records(const vo_pair_result* res, int B, double* rec)
     rec[i] = v;
 }
 
-void launch_pack_records(hipStream_t s, const vo_pair_result* res, int B, double* rec)
+void launch_pack_records(hipStream_t s, const vo_pair_result* res, int B, int valid, double* rec)
 {
     if (B <= 0) return;
-    hipLaunchKernelGGL(k_pack_records, dim3((B * VO_RECORD_DOUBLES + 255) / 256), dim3(256), 0, s, res, B, rec);
+    hipLaunchKernelGGL(k_pack_records, dim3((B * VO_RECORD_DOUBLES + 255) / 256), dim3(256), 0, s, res, B, valid, rec);
 }

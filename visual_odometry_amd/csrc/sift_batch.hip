@@ -117,7 +117,6 @@ struct SweepDims {
     static constexpr int RING = (NN + SW_RS - 1 + 7) & ~7;       // row-filtered rows kept
     static constexpr int CRING = (R + SW_RS + 7) & ~7;           // source centre rows kept (for the DoG)
     static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + CRING * SW_TW;
-    static constexpr int LOADS = (SW_RS * (INW / 4) + SW_THREADS - 1) / SW_THREADS;
 };
 
 template <int N>
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     float* s_in = s_dyn;                                   // [SW_RS][INP]
     float* s_ring = s_in + SW_RS * INP;                    // [RING][SW_TW]
     float* s_ctr = s_ring + RING * SW_TW;                  // [CRING][SW_TW]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * SW_TW, Y0 = blockIdx.y * seg, Y1 = min(h, Y0 + seg);
     if (Y0 >= h) return;
     src += (size_t)blockIdx.z * src_fs;
@@ -142,19 +141,19 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     if (dstD) dstD += (size_t)blockIdx.z * d_fs;
     const int xa = x0 - R4;                                // first source column of a segment (multiple of 4)
     const bool interior = xa >= 0 && xa + INW <= w;        // whole segments inside the image: aligned 16-byte loads, no reflection
-    const int per_row = INW / 4, items = SW_RS * per_row;
+    const int per_row = INW / 4;                           // 16-byte pieces of a row segment (<= 48)
     const int nsteps = (Y1 - Y0 + 2 * r + SW_RS - 1) / SW_RS;
 
-    float4 ld[DM::LOADS];
+    // loads: wavefront v brings rows v and v + 4 of a step's eight source rows, lane = 16-byte piece of the row; the row index
+    // (and its reflection at the image border) is a scalar
+    float4 ld[2];
     auto issue = [&](int k) {
 #pragma unroll
-        for (int q = 0; q < DM::LOADS; q++) {
-            const int it = q * SW_THREADS + tid;
-            if (it < items) {
-                const int row = it / per_row, c4 = it - row * per_row;
-                const int yy = reflect101(Y0 - r + k * SW_RS + row, h);
-                const float* p = src + (size_t)yy * stride;
-                const int x = xa + 4 * c4;
+        for (int q = 0; q < 2; q++) {
+            const int yy = reflect101(Y0 - r + k * SW_RS + wave + 4 * q, h);
+            const float* p = src + (size_t)yy * stride;
+            const int x = xa + 4 * lane;
+            if (lane < per_row) {
                 if (interior) ld[q] = *(const float4*)(p + x);
                 else { ld[q].x = p[reflect101(x, w)]; ld[q].y = p[reflect101(x + 1, w)]; ld[q].z = p[reflect101(x + 2, w)]; ld[q].w = p[reflect101(x + 3, w)]; }
             }
@@ -163,14 +162,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     issue(0);
     // thread roles
     const int rrow = tid >> 5, rx4 = (tid & 31) * 4;       // row pass: 4 consecutive columns of one of the 8 rows
-    const int cc = tid & (SW_TW - 1), crg = tid >> 7;      // column pass: 4 consecutive rows of one column
+    const int cc = tid & (SW_TW - 1), crg = wave >> 1;     // column pass: 4 consecutive rows (scalar: 4 crg ..) of one column
     const int woff = R4 - r;                               // window start inside the aligned span
+    const int x = x0 + cc;
     for (int k = 0; k < nsteps; k++) {
         // the segment of step k: registers -> LDS (all threads are past the row pass of step k - 1: second barrier below)
-#pragma unroll
-        for (int q = 0; q < DM::LOADS; q++) {
-            const int it = q * SW_THREADS + tid;
-            if (it < items) { const int row = it / per_row, c4 = it - row * per_row; *(float4*)(s_in + row * INP + 4 * c4) = ld[q]; }
+        if (lane < per_row) {
+            *(float4*)(s_in + wave * INP + 4 * lane) = ld[0];
+            *(float4*)(s_in + (wave + 4) * INP + 4 * lane) = ld[1];
         }
         if (k + 1 < nsteps) issue(k + 1);                  // in flight during this step's arithmetic
         __syncthreads();
@@ -205,16 +204,17 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
             }
         }
         __syncthreads();
-        // ---- column pass: output rows m = 8 k - 2 r + 4 crg + q (relative to Y0) have their whole window in the ring now
+        // ---- column pass: output rows m = 8 k - 2 r + 4 crg + q (relative to Y0) have their whole window in the ring now.
+        //      m0 and every ring row index are scalars (crg is a wavefront's property)
         {
             const int m0 = k * SW_RS - 2 * r + 4 * crg;
-            const int x = x0 + cc;
             if (m0 + 3 >= 0 && Y0 + m0 < Y1 && x < w) {
                 float acc[4];
+                const int rb0 = (m0 + 4 * RING) % RING;
                 if (N > 0) {
                     float win[N + 3];
 #pragma unroll
-                    for (int i = 0; i < N + 3; i++) win[i] = s_ring[((m0 + i + 4 * DM::RING) % DM::RING) * SW_TW + cc];
+                    for (int i = 0; i < N + 3; i++) { int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; win[i] = s_ring[ri * SW_TW + cc]; }
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[q] = t.k[DM::R] * win[DM::R + q];
 #pragma unroll
@@ -224,19 +224,21 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[q] = t.k[r] * s_ring[((m0 + r + q + 4 * RING) % RING) * SW_TW + cc];
+                    for (int q = 0; q < 4; q++) acc[q] = t.k[r] * s_ring[((rb0 + r + q) % RING) * SW_TW + cc];
                     for (int i = 1; i <= r; i++) {
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            acc[q] += t.k[r + i] * (s_ring[((m0 + r + q + i + 4 * RING) % RING) * SW_TW + cc] + s_ring[((m0 + r + q - i + 4 * RING) % RING) * SW_TW + cc]);
+                            acc[q] += t.k[r + i] * (s_ring[((rb0 + r + q + i) % RING) * SW_TW + cc] + s_ring[((rb0 + r + q - i) % RING) * SW_TW + cc]);
                     }
                 }
+                const int cb0 = (m0 + r + 4 * CRING) % CRING;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int m = m0 + q, y = Y0 + m;
                     if (m >= 0 && y < Y1) {
-                        if (dstG) dstG[(size_t)y * stride + x] = acc[q];
-                        if (dstD) dstD[(size_t)y * stride + x] = acc[q] - s_ctr[((m + r) % CRING) * SW_TW + cc];
+                        const size_t o = (size_t)y * stride + x;
+                        if (dstG) dstG[o] = acc[q];
+                        if (dstD) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dstD[o] = acc[q] - s_ctr[ci * SW_TW + cc]; }
                     }
                 }
             }
@@ -247,53 +249,63 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 }
 
 // ------------------------------------------------------------------ extrema
-#define EX_TW 64
-#define EX_TH 16
-#define EX_MAXP 10                     // DoG planes of an octave held in the tile (nOctaveLayers + 2 <= 10)
-__global__ __launch_bounds__(256) void k_sb_extrema(const float* dog, size_t d_fs, size_t plane, int w, int h, int stride, int nLayers, int o,
+// A pixel of DoG layer l is a candidate iff |v| > threshold and v >= (<=) all 26 neighbours, i.e. v equals the maximum
+// (minimum) of the 3 x 3 x 3 block around it.  Streaming form, no LDS: a WAVEFRONT owns 62 columns (lanes 1..62; lanes 0 and 63
+// carry the halo columns) and sweeps a segment of rows top to bottom.  Per row and plane one coalesced load; the row's
+// 3-wide maximum / minimum comes from the two neighbouring lanes; the last three rows of (row maximum, row minimum, centre)
+// of every plane stay in registers, so the 3 x 3 x 3 extremes of the row above are three more max / min per plane.
+#define EX_COLS 62
+#define EX_SEG 32
+#define EX_MAXP 10                     // DoG planes of an octave (nOctaveLayers + 2 <= 10)
+template <int NP>
+__global__ __launch_bounds__(256) void k_sb_extrema(const float* dog, size_t d_fs, size_t plane, int w, int h, int stride, int o,
                                                     float threshold, SiftCand* cand, int* counts /*[F][4]*/, int cap)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_ex[];        // [planes][EX_TH + 2][EX_TW + 2]
-    const int PW = EX_TW + 2, PH = EX_TH + 2, np = nLayers + 2;
-    const int f = blockIdx.z, tid = threadIdx.x;
-    const int c0 = SIFT_IMG_BORDER + blockIdx.x * EX_TW, r0 = SIFT_IMG_BORDER + blockIdx.y * EX_TH;
-    const float* D = dog + (size_t)f * d_fs;
-    for (int i = tid; i < np * PH * PW; i += 256) {
-        const int pl = i / (PH * PW), rem = i - pl * (PH * PW), yy = rem / PW, xx = rem - yy * PW;
-        const int y = min(r0 - 1 + yy, h - 1), x = min(c0 - 1 + xx, w - 1);          // (r0, c0 >= 5: never negative)
-        s_ex[i] = D[(size_t)pl * plane + (size_t)y * stride + x];
-    }
-    __syncthreads();
-    const int lx = tid & 63;
-    for (int ly = tid >> 6; ly < EX_TH; ly += 4) {
-        const int c = c0 + lx, r = r0 + ly;
-        if (c >= w - SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) continue;
-        // 3 x 3 max / min of every plane at this pixel, then the three layers
-        float mx[EX_MAXP], mn[EX_MAXP], ctr[EX_MAXP];
+    const int f = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    const int c = SIFT_IMG_BORDER + strip * EX_COLS + lane - 1;       // this lane's column (lane 0 / 63: halo)
+    if (SIFT_IMG_BORDER + strip * EX_COLS >= w - SIFT_IMG_BORDER) return;
+    const int ys = SIFT_IMG_BORDER + blockIdx.y * EX_SEG, ye = min(ys + EX_SEG, h - SIFT_IMG_BORDER);      // output rows [ys, ye)
+    const float* D = dog + (size_t)f * d_fs + min(c, w - 1);
+    const bool out_lane = lane >= 1 && lane <= EX_COLS && c < w - SIFT_IMG_BORDER;
+    float hmx[3][NP], hmn[3][NP], ctr[3][NP], nxt[NP];
+    auto load = [&](int y) {
+        const float* p = D + (size_t)min(y, h - 1) * stride;
 #pragma unroll
-        for (int pl = 0; pl < EX_MAXP; pl++) {
-            if (pl < np) {
-                const float* p = s_ex + pl * (PH * PW) + (ly + 1) * PW + lx + 1;
-                float a = p[-PW - 1], b = a;
-                const float v[8] = {p[-PW], p[-PW + 1], p[-1], p[0], p[1], p[PW - 1], p[PW], p[PW + 1]};
+        for (int pl = 0; pl < NP; pl++) nxt[pl] = p[(size_t)pl * plane];
+    };
+    auto rowext = [&](int slot) {                         // nxt -> slot: the 3-wide extremes of the row just loaded
 #pragma unroll
-                for (int q = 0; q < 8; q++) { a = fmaxf(a, v[q]); b = fminf(b, v[q]); }
-                mx[pl] = a; mn[pl] = b; ctr[pl] = p[0];
-            }
+        for (int pl = 0; pl < NP; pl++) {
+            const float v = nxt[pl], l = __shfl_up(v, 1, 64), r = __shfl_down(v, 1, 64);
+            hmx[slot][pl] = fmaxf(fmaxf(l, v), r); hmn[slot][pl] = fminf(fminf(l, v), r); ctr[slot][pl] = v;
         }
+    };
+    auto emit = [&](int y, int sa, int sb, int sc) {      // outputs of row y: slots sa (row y - 1), sb (row y), sc (row y + 1)
+        float mx[NP], mn[NP];
 #pragma unroll
-        for (int layer = 1; layer <= EX_MAXP - 2; layer++) {
-            if (layer <= nLayers) {
-                const float val = ctr[layer];
-                if (fabsf(val) > threshold) {
-                    const float hi = fmaxf(fmaxf(mx[layer - 1], mx[layer]), mx[layer + 1]), lo = fminf(fminf(mn[layer - 1], mn[layer]), mn[layer + 1]);
-                    if (val > 0 ? val >= hi : val <= lo) {
-                        const int slot = atomicAdd(counts + 4 * f, 1);
-                        if (slot < cap) { SiftCand cd; cd.o = o; cd.layer = layer; cd.r = r; cd.c = c; cand[(size_t)f * cap + slot] = cd; }
-                    }
+        for (int pl = 0; pl < NP; pl++) { mx[pl] = fmaxf(fmaxf(hmx[sa][pl], hmx[sb][pl]), hmx[sc][pl]); mn[pl] = fminf(fminf(hmn[sa][pl], hmn[sb][pl]), hmn[sc][pl]); }
+#pragma unroll
+        for (int layer = 1; layer <= NP - 2; layer++) {
+            const float val = ctr[sb][layer];
+            if (out_lane && fabsf(val) > threshold) {
+                const float hi = fmaxf(fmaxf(mx[layer - 1], mx[layer]), mx[layer + 1]), lo = fminf(fminf(mn[layer - 1], mn[layer]), mn[layer + 1]);
+                if (val > 0 ? val >= hi : val <= lo) {
+                    const int slot = atomicAdd(counts + 4 * f, 1);
+                    if (slot < cap) { SiftCand cd; cd.o = o; cd.layer = layer; cd.r = y; cd.c = c; cand[(size_t)f * cap + slot] = cd; }
                 }
             }
         }
+    };
+    // rows ys - 1 and ys fill slots 0 and 1; from then on every new row y + 1 completes the block around row y
+    load(ys - 1); rowext(0);
+    load(ys); rowext(1);
+    load(ys + 1);
+    for (int y = ys; y < ye; y += 3) {
+        rowext(2); load(y + 2);
+        emit(y, 0, 1, 2);
+        if (y + 1 < ye) { rowext(0); load(y + 3); emit(y + 1, 1, 2, 0); }
+        if (y + 2 < ye) { rowext(1); load(y + 4); emit(y + 2, 2, 0, 1); }
     }
 }
 
@@ -461,41 +473,59 @@ __device__ __forceinline__ bool kp_less(const SiftKp& a, const SiftKp& b)
     return false;
 }
 
-#define RK_TILE 512
-__global__ __launch_bounds__(256) void k_sb_rank(const SiftKp* kps, int kp_cap, const int* counts, int* rank)
+// Sort by buckets: x is cut into RK_NB integer buckets (a monotone map, so bucket order is part of the sort order); one
+// workgroup per frame counts the buckets in LDS, scans them and deals the records into bucket order; then every record ranks
+// itself against the few records of its own bucket with the full comparator and goes to its final place.
+#define RK_NB 4096
+__device__ __forceinline__ int kp_bucket(float x) { const int b = (int)x; return b < 0 ? 0 : b > RK_NB - 1 ? RK_NB - 1 : b; }
+
+__global__ __launch_bounds__(1024) void k_sb_bucket(const SiftKp* kps, int kp_cap, const int* counts, SiftKp* tmp, int* bstart /*[F][RK_NB + 1]*/)
 {
-    __shared__ unsigned long long s_key[RK_TILE];
-    __shared__ SiftKp s_rec[RK_TILE];
-    const int f = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    __shared__ int s_cnt[RK_NB];
+    __shared__ int s_wsum[16];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nk = min(counts[4 * f + 2], kp_cap);
-    if ((int)(blockIdx.x * 256) >= nk) return;
     const SiftKp* K = kps + (size_t)f * kp_cap;
-    SiftKp me = K[i < nk ? i : 0];
-    const unsigned long long mykey = ((unsigned long long)f2ord(me.x) << 32) | f2ord(me.y);
-    int rk = 0;
-    for (int base = 0; base < nk; base += RK_TILE) {
-        __syncthreads();
-        for (int j = tid; j < RK_TILE; j += 256)
-            if (base + j < nk) { const SiftKp q = K[base + j]; s_rec[j] = q; s_key[j] = ((unsigned long long)f2ord(q.x) << 32) | f2ord(q.y); }
-        __syncthreads();
-        const int lim = min(RK_TILE, nk - base);
-        for (int j = 0; j < lim; j++) {
-            const unsigned long long kj = s_key[j];
-            if (kj < mykey) rk++;
-            else if (kj == mykey) {                            // same (x, y): the full comparator, then the index
-                const SiftKp q = s_rec[j];
-                if (kp_less(q, me) || (!kp_less(me, q) && base + j < i)) rk++;
-            }
-        }
-    }
-    if (i < nk) rank[(size_t)f * kp_cap + i] = rk;
+    for (int b = tid; b < RK_NB; b += 1024) s_cnt[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < nk; i += 1024) atomicAdd(&s_cnt[kp_bucket(K[i].x)], 1);
+    __syncthreads();
+    // exclusive scan of the 4096 counts: 4 consecutive buckets per thread, wave scan, scan of the 16 wave totals
+    const int c0 = s_cnt[4 * tid], c1 = s_cnt[4 * tid + 1], c2 = s_cnt[4 * tid + 2], c3 = s_cnt[4 * tid + 3];
+    const int mine = c0 + c1 + c2 + c3;
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) s_wsum[wid] = inc;
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) off += q < wid ? s_wsum[q] : 0;
+    const int e0 = off + inc - mine;
+    __syncthreads();
+    s_cnt[4 * tid] = e0; s_cnt[4 * tid + 1] = e0 + c0; s_cnt[4 * tid + 2] = e0 + c0 + c1; s_cnt[4 * tid + 3] = e0 + c0 + c1 + c2;
+    int* bs = bstart + (size_t)f * (RK_NB + 1);
+    bs[4 * tid] = e0; bs[4 * tid + 1] = e0 + c0; bs[4 * tid + 2] = e0 + c0 + c1; bs[4 * tid + 3] = e0 + c0 + c1 + c2;
+    if (tid == 0) bs[RK_NB] = nk;
+    __syncthreads();
+    for (int i = tid; i < nk; i += 1024) { const SiftKp q = K[i]; tmp[(size_t)f * kp_cap + atomicAdd(&s_cnt[kp_bucket(q.x)], 1)] = q; }
 }
 
-__global__ __launch_bounds__(256) void k_sb_scatter(const SiftKp* kps, int kp_cap, const int* counts, const int* rank, SiftKp* sorted)
+__global__ __launch_bounds__(256) void k_sb_rank(const SiftKp* tmp, int kp_cap, const int* counts, const int* bstart, SiftKp* sorted)
 {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int nk = min(counts[4 * f + 2], kp_cap);
-    if (i < nk) sorted[(size_t)f * kp_cap + rank[(size_t)f * kp_cap + i]] = kps[(size_t)f * kp_cap + i];
+    if (i >= nk) return;
+    const SiftKp* T = tmp + (size_t)f * kp_cap;
+    const SiftKp me = T[i];
+    const int b = kp_bucket(me.x);
+    const int lo = bstart[(size_t)f * (RK_NB + 1) + b], hi = bstart[(size_t)f * (RK_NB + 1) + b + 1];
+    int rk = lo;
+    for (int j = lo; j < hi; j++) {
+        const SiftKp q = T[j];
+        if (kp_less(q, me) || (!kp_less(me, q) && j < i)) rk++;       // (records identical in every field: any order, the duplicate filter merges them)
+    }
+    sorted[(size_t)f * kp_cap + rk] = me;
 }
 
 // drop the records that repeat (pt, size, angle) of their predecessor; firstOctave = -1: back to input-image coordinates;
@@ -547,29 +577,58 @@ __global__ __launch_bounds__(256) void k_sb_emit(const SiftKp* sorted, int kp_ca
 // One WAVEFRONT per keypoint.  calcSIFTDescriptor adds every sample of the (2 radius + 1)^2 window, in row-major order, into 8
 // bins of a 6 x 6 x 10 histogram of which only the inner 4 x 4 cells (and orientation bins 0..8) are ever read; float addition
 // is not associative, so each bin must receive its contributions in that order.
-//  (1) the window is scanned 64 positions at a time with the cheap tests only (rotated position inside the grid, pixel inside
-//      the image); the positions that pass are appended IN ORDER to an LDS queue (ballot + prefix count);
-//  (2) whenever the queue holds 64 positions they are evaluated one per lane (gradient, fastAtan2, exp32f weight, trilinear
-//      split -> 8 values) and every sample sets its bit in the masks of the owner lanes it feeds;
-//  (3) the 64 lanes OWN the histogram: lane = inner cell (a, b) x q, q = orientation bins {2q, 2q+1} (+ bin 8 for q = 3), kept
-//      in registers; an owner walks the set bits of its mask, lowest (= earliest sample) first, and adds.
+//  (0) Which window positions take part is decided by four float comparisons on the rotated position and by the image border.
+//      Along a window row every one of those quantities is a monotone function of the column (a rounded product with a constant
+//      plus a constant), so the valid positions of a row form ONE interval: each lane finds the exact interval ends of its rows
+//      by bisection on the very same float expressions, a wave scan turns the interval lengths into the row-major numbering of the
+//      valid samples — no scan over the window, no queue;
+//  (1) the valid samples are evaluated 64 at a time, one per lane (gradient, fastAtan2, exp32f weight, trilinear split -> 8
+//      values), SD_SUB such batches per routing round; every sample sets its bit in the masks of the owner lanes it feeds;
+//  (2) the 64 lanes OWN the histogram: lane = inner cell (a, b) x q, q = orientation bins {2q, 2q+1} (+ bin 8 for q = 3), kept
+//      in registers; an owner walks the set bits of its masks, lowest (= earliest sample) first, and adds (branch-free: a
+//      contribution that does not concern an accumulator adds +0.0, which changes nothing in a sum of non-negative terms).
 // Same additions, same order as the scalar loop; no read-modify-write chain through memory.
 #define SD_D 4
 #define SD_N 8
+#ifndef SD_SUB
+#define SD_SUB 2                       // 64-sample batches per routing round
+#endif
+#define SD_NS (64 * SD_SUB)
+#define SD_ROWS 128                    // window rows per chunk (two per lane)
+
+struct SdRot { float cos_t, sin_t; };
+__device__ __forceinline__ void sd_bins(const SdRot& R, int i, int j, float& c_rot, float& r_rot, float& rbin, float& cbin)
+{
+    c_rot = (float)j * R.cos_t - (float)i * R.sin_t; r_rot = (float)j * R.sin_t + (float)i * R.cos_t;
+    rbin = r_rot + (float)(SD_D / 2) - 0.5f; cbin = c_rot + (float)(SD_D / 2) - 0.5f;
+}
+
+// first j in [jl, jh] with pred(j), pred monotone false -> true over the range; jh + 1 if there is none
+template <typename P>
+__device__ __forceinline__ int sd_first_true(int jl, int jh, P pred)
+{
+    int lo = jl, hi = jh + 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (pred(mid)) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+
 __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* gauss, const SiftKp* kps, int kp_cap, const int* counts, SiftExpTab E,
                                                       uint8_t* desc, uint8_t* desc_x, int cap_x, int* norms, int* flags, int first_slot)
 {
     __shared__ float s_tab[64];
-    __shared__ unsigned int s_q[128];                           // queue of window positions (i + 32768) << 16 | (j + 32768)
-    __shared__ float s_v[8][64];                                // s_v[(dr * 2 + dc) * 2 + dori][sample]
-    __shared__ unsigned int s_code[64];                         // A | B << 4 | o0 << 8  (A = r0 + 1, B = c0 + 1 in 0..4)
-    __shared__ unsigned long long s_own[64];
+    __shared__ int s_rstart[SD_ROWS + 1];                       // row-major number of a row's first valid sample (chunk-relative rows)
+    __shared__ int s_rjlo[SD_ROWS];                             // its column
+    __shared__ float s_v[8][SD_NS];                             // s_v[(dr * 2 + dc) * 2 + dori][sample of the round]
+    __shared__ unsigned int s_code[SD_NS];                      // A * 4 + B * 2 | o0 << 8  (A = r0 + 1, B = c0 + 1 in 0..4)
+    __shared__ unsigned long long s_own[SD_SUB][64];
     __shared__ __attribute__((aligned(16))) float s_fin[128];
+    __shared__ float s_x[64];
     const int lane = threadIdx.x, f = blockIdx.y;
     const int nkp = min(counts[4 * f + 3], kp_cap);
     s_tab[lane] = E.tab[lane];
     // owner role of this lane
     const int own_a = 1 + (lane >> 4), own_b = 1 + ((lane >> 2) & 3), own_q = lane & 3;
+    const int own_code = own_a * 4 + own_b * 2;
     const int d = SD_D, n = SD_N;
     for (int id = blockIdx.x; id < nkp; id += gridDim.x) {
         const SiftKp kp = kps[(size_t)f * kp_cap + id];         // already in input-image coordinates (firstOctave = -1 applied)
@@ -589,99 +648,127 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
         const int rmax = (int)sqrt((double)w * w + (double)h * h);
         if (radius > rmax) radius = rmax;
         cos_t /= hist_width; sin_t /= hist_width;
-        const int side = 2 * radius + 1, total = side * side;
+        const SdRot R = {cos_t, sin_t};
+        const int side = 2 * radius + 1;
         float e0 = 0.f, e1 = 0.f, e2 = 0.f;                     // bins 2q, 2q+1 (and 8 for q = 3) of cell (own_a, own_b)
-        int qn = 0;                                             // queue fill (wave-uniform)
-        __syncthreads();
-        // one dense batch: `cnt` queue entries starting at s_q[0]
-        auto process = [&](int cnt) {
-            s_own[lane] = 0ull;
+        for (int i0 = 0; i0 < side; i0 += SD_ROWS) {            // (one chunk unless the window has more than 128 rows)
+            const int nrows = min(SD_ROWS, side - i0);
             __syncthreads();
-            if (lane < cnt) {
-                const unsigned int pk = s_q[lane];
-                const int i = (int)(pk >> 16) - 32768, j = (int)(pk & 0xffffu) - 32768;
-                const float c_rot = (float)j * cos_t - (float)i * sin_t, r_rot = (float)j * sin_t + (float)i * cos_t;
-                float rbin = r_rot + (float)(d / 2) - 0.5f, cbin = c_rot + (float)(d / 2) - 0.5f;
-                const int r = py + i, c = px + j;
-                const float dx = img[(size_t)r * st + c + 1] - img[(size_t)r * st + c - 1], dy = img[(size_t)(r - 1) * st + c] - img[(size_t)(r + 1) * st + c];
-                const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
-                const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
-                float obin = (Ori - ori) * bins_per_rad;
-                const float mag = Mag * Wq;
-                const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-                int o0 = (int)floorf(obin);
-                rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
-                if (o0 < 0) o0 += n;
-                if (o0 >= n) o0 -= n;
-                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-                s_v[0][lane] = v_rco000; s_v[1][lane] = v_rco001; s_v[2][lane] = v_rco010; s_v[3][lane] = v_rco011;
-                s_v[4][lane] = v_rco100; s_v[5][lane] = v_rco101; s_v[6][lane] = v_rco110; s_v[7][lane] = v_rco111;
-                const int A = r0 + 1, B = c0 + 1;               // cells (A, B), (A, B+1), (A+1, B), (A+1, B+1) of the 6 x 6 grid
-                s_code[lane] = (unsigned)A | ((unsigned)B << 4) | ((unsigned)o0 << 8);
-                // owners fed: orientation group(s) of o0 — even o0 = 2q: q (both of its bins); odd o0 = 2q+1: q (bin 2q+1) and
-                // q+1 (bin 2q+2), except o0 = 7 whose upper bin 8 also belongs to q = 3
-                const int qa = o0 >> 1, qb = (o0 & 1) && o0 < 7 ? qa + 1 : -1;
-                const unsigned long long bit = 1ull << lane;
+            // ---- (0) the valid interval of every row of the chunk
+            int len[2], jl[2];
 #pragma unroll
-                for (int dr = 0; dr < 2; dr++)
+            for (int u = 0; u < 2; u++) {
+                const int rl = lane + 64 * u, i = i0 + rl - radius, r = py + i;
+                int jlo = max(-radius, 1 - px), jhi = min(radius, w - 2 - px);
+                if (rl < nrows && r > 0 && r < h - 1 && jlo <= jhi) {
+                    float cr, rr, rb, cb;
+                    // rbin along the row: increasing with j iff sin_t >= 0; cbin: iff cos_t >= 0
+                    int ja, jb;
+                    if (sin_t >= 0) { ja = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return rb > -1; });
+                                      jb = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return !(rb < d); }) - 1; }
+                    else { ja = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return rb < d; });
+                           jb = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return !(rb > -1); }) - 1; }
+                    jlo = max(jlo, ja); jhi = min(jhi, jb);
+                    if (jlo <= jhi) {
+                        if (cos_t >= 0) { ja = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return cb > -1; });
+                                          jb = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return !(cb < d); }) - 1; }
+                        else { ja = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return cb < d; });
+                               jb = sd_first_true(jlo, jhi, [&](int j) { sd_bins(R, i, j, cr, rr, rb, cb); return !(cb > -1); }) - 1; }
+                        jlo = max(jlo, ja); jhi = min(jhi, jb);
+                    }
+                } else jhi = jlo - 1;
+                len[u] = max(0, jhi - jlo + 1); jl[u] = jlo;
+            }
+            int inc0 = len[0], inc1 = len[1];
 #pragma unroll
-                    for (int dc = 0; dc < 2; dc++) {
-                        const int a = A + dr, b = B + dc;
-                        if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
-                            const int ow = ((a - 1) << 4) | ((b - 1) << 2);
-                            atomicOr(&s_own[ow | qa], bit);
-                            if (qb >= 0) atomicOr(&s_own[ow | qb], bit);
+            for (int dd = 1; dd < 64; dd <<= 1) { const int t0 = __shfl_up(inc0, dd, 64), t1 = __shfl_up(inc1, dd, 64); if (lane >= dd) { inc0 += t0; inc1 += t1; } }
+            const int tot0 = __shfl(inc0, 63, 64), T = tot0 + __shfl(inc1, 63, 64);
+            s_rstart[lane] = inc0 - len[0]; s_rstart[64 + lane] = tot0 + inc1 - len[1];
+            s_rjlo[lane] = jl[0]; s_rjlo[64 + lane] = jl[1];
+            if (lane == 0) s_rstart[SD_ROWS] = T;
+            __syncthreads();
+            // ---- (1) + (2): rounds of SD_NS samples
+            int row[SD_SUB];
+#pragma unroll
+            for (int u = 0; u < SD_SUB; u++) row[u] = 0;
+            for (int s0 = 0; s0 < T; s0 += SD_NS) {
+#pragma unroll
+                for (int u = 0; u < SD_SUB; u++) s_own[u][lane] = 0ull;
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < SD_SUB; u++) {
+                    const int sidx = s0 + 64 * u + lane, slot = 64 * u + lane;
+                    if (sidx < T) {
+                        int rw = row[u];
+                        while (sidx >= s_rstart[rw + 1]) rw++;          // (rows without valid samples are skipped: their start equals the next one's)
+                        row[u] = rw;
+                        const int i = i0 + rw - radius, j = s_rjlo[rw] + (sidx - s_rstart[rw]);
+                        float c_rot, r_rot, rbin, cbin;
+                        sd_bins(R, i, j, c_rot, r_rot, rbin, cbin);
+                        const int idx = (py + i) * st + px + j;
+                        const float dx = img[idx + 1] - img[idx - 1], dy = img[idx - st] - img[idx + st];
+                        const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
+                        const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
+                        float obin = (Ori - ori) * bins_per_rad;
+                        const float mag = Mag * Wq;
+                        const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                        int o0 = (int)floorf(obin);
+                        rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
+                        if (o0 < 0) o0 += n;
+                        if (o0 >= n) o0 -= n;
+                        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                        const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                        const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                        s_v[0][slot] = v_rco000; s_v[1][slot] = v_rco001; s_v[2][slot] = v_rco010; s_v[3][slot] = v_rco011;
+                        s_v[4][slot] = v_rco100; s_v[5][slot] = v_rco101; s_v[6][slot] = v_rco110; s_v[7][slot] = v_rco111;
+                        const int A = r0 + 1, B = c0 + 1;       // cells (A, B), (A, B+1), (A+1, B), (A+1, B+1) of the 6 x 6 grid
+                        s_code[slot] = (unsigned)(A * 4 + B * 2) | ((unsigned)o0 << 8);
+                        // owners fed: orientation group(s) of o0 — even o0 = 2q: q (both of its bins); odd o0 = 2q+1: q (bin 2q+1) and
+                        // q+1 (bin 2q+2), except o0 = 7 whose upper bin 8 also belongs to q = 3
+                        const int qa = o0 >> 1, qb = (o0 & 1) && o0 < 7 ? qa + 1 : -1;
+                        const unsigned long long bit = 1ull << lane;
+#pragma unroll
+                        for (int dr = 0; dr < 2; dr++)
+#pragma unroll
+                            for (int dc = 0; dc < 2; dc++) {
+                                const int a = A + dr, b = B + dc;
+                                if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
+                                    const int ow = ((a - 1) << 4) | ((b - 1) << 2);
+                                    atomicOr(&s_own[u][ow | qa], bit);
+                                    if (qb >= 0) atomicOr(&s_own[u][ow | qb], bit);
+                                }
+                            }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < SD_SUB; u++) {
+                    const unsigned long long m64 = s_own[u][lane];
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        unsigned int m = hh ? (unsigned int)(m64 >> 32) : (unsigned int)m64;
+                        while (m) {
+                            const int t = 64 * u + 32 * hh + __ffs((int)m) - 1;
+                            m &= m - 1;
+                            const unsigned int code = s_code[t];
+                            const int sel = own_code - (int)(code & 255u);      // ((own_a - A) * 2 + (own_b - B)) * 2
+                            const int rel = (int)(code >> 8) - 2 * own_q;       // -1, 0 or 1
+                            const float v0 = s_v[0][sel * SD_NS + t], v1 = s_v[1][sel * SD_NS + t];
+                            e0 += rel == 0 ? v0 : rel < 0 ? v1 : 0.f;
+                            e1 += rel == 0 ? v1 : rel > 0 ? v0 : 0.f;
+                            e2 += rel > 0 ? v1 : 0.f;                           // (only read for q = 3: o0 = 7 -> bin 8)
                         }
                     }
-            }
-            __syncthreads();
-            unsigned long long m = s_own[lane];
-            while (m) {
-                const int t = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const unsigned int code = s_code[t];
-                const int A = code & 15, B = (code >> 4) & 15, o0 = code >> 8;
-                const int sel = ((own_a - A) * 2 + (own_b - B)) * 2;
-                const float v0 = s_v[sel][t], v1 = s_v[sel + 1][t];
-                const int rel = o0 - 2 * own_q;                 // -1, 0 or 1
-                if (rel == 0) { e0 += v0; e1 += v1; }
-                else if (rel == 1) { e1 += v0; e2 += v1; }      // (e2 is only read for q = 3: o0 = 7 -> bin 8)
-                else e0 += v1;
-            }
-            __syncthreads();
-        };
-        for (int q0 = 0; q0 < total; q0 += 64) {
-            // (1) cheap tests, ordered append
-            const int q = q0 + lane;
-            bool ok = false; unsigned int pk = 0;
-            if (q < total) {
-                const int i = q / side - radius, j = q % side - radius;
-                const float c_rot = (float)j * cos_t - (float)i * sin_t, r_rot = (float)j * sin_t + (float)i * cos_t;
-                const float rbin = r_rot + (float)(d / 2) - 0.5f, cbin = c_rot + (float)(d / 2) - 0.5f;
-                const int r = py + i, c = px + j;
-                ok = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1;
-                pk = ((unsigned)(i + 32768) << 16) | (unsigned)(j + 32768);
-            }
-            const unsigned long long bal = __ballot(ok);
-            if (ok) s_q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = pk;
-            qn += __popcll(bal);
-            __syncthreads();
-            if (qn >= 64) {
-                process(64);
-                if (lane < qn - 64) { const unsigned int v = s_q[64 + lane]; s_q[lane] = v; }     // (same lane reads then writes: no overlap hazard within 64)
-                qn -= 64;
+                }
                 __syncthreads();
             }
         }
-        if (qn > 0) process(qn);
         // finalisation: hist[.][0] += hist[.][8] (hist[.][9] is never written), then the strictly sequential norm / clip / norm chain
         // of calcSIFTDescriptor on one lane; element order (cell row, cell column, bin)
-        s_v[0][lane] = e2;                                      // bin 8 of (cell, q = 3) -> read by q = 0
+        s_x[lane] = e2;                                          // bin 8 of (cell, q = 3) -> added to bin 0 by the lane with q = 0
         __syncthreads();
-        if (own_q == 0) e0 += s_v[0][lane + 3];
+        if (own_q == 0) e0 += s_x[lane + 3];
         s_fin[(lane >> 2) * 8 + own_q * 2] = e0; s_fin[(lane >> 2) * 8 + own_q * 2 + 1] = e1;
         __syncthreads();
         if (lane == 0) {
@@ -690,11 +777,11 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
             const float thr = sqrtf(nrm2) * 0.2f;
             nrm2 = 0;
             for (int k = 0; k < 128; k++) { float v = s_fin[k]; v = v < thr ? v : thr; s_fin[k] = v; nrm2 += v * v; }
-            s_v[1][0] = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
+            s_x[0] = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
         }
         __syncthreads();
         {
-            const float sc = s_v[1][0];
+            const float sc = s_x[0];
             const int u0 = min(max(__float2int_rn(s_fin[2 * lane] * sc), 0), 255), u1 = min(max(__float2int_rn(s_fin[2 * lane + 1] * sc), 0), 255);
             const size_t slot = (size_t)(first_slot + f);
             if (desc) *(uint16_t*)(desc + (slot * kp_cap + id) * 128 + 2 * lane) = (uint16_t)(u0 | (u1 << 8));
@@ -774,9 +861,13 @@ void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o
 {
     const int w = P.w[o], h = P.h[o];
     if (w <= 2 * SIFT_IMG_BORDER || h <= 2 * SIFT_IMG_BORDER) return;
-    const size_t lds = (size_t)(P.nLayers + 2) * (EX_TH + 2) * (EX_TW + 2) * 4;
-    hipLaunchKernelGGL(k_sb_extrema, dim3((w - 2 * SIFT_IMG_BORDER + EX_TW - 1) / EX_TW, (h - 2 * SIFT_IMG_BORDER + EX_TH - 1) / EX_TH, F), dim3(256), lds, s,
-                       dog + P.doff[o], P.dframe, P.plane[o], w, h, P.stride[o], P.nLayers, o, threshold, cand, counts, cap);
+    const int strips = (w - 2 * SIFT_IMG_BORDER + EX_COLS - 1) / EX_COLS;
+    const dim3 grid((strips + 3) / 4, (h - 2 * SIFT_IMG_BORDER + EX_SEG - 1) / EX_SEG, F);
+    switch (P.nLayers + 2) {
+#define EX_CASE(NP) case NP: hipLaunchKernelGGL(k_sb_extrema<NP>, grid, dim3(256), 0, s, dog + P.doff[o], P.dframe, P.plane[o], w, h, P.stride[o], o, threshold, cand, counts, cap); break;
+        EX_CASE(3) EX_CASE(4) EX_CASE(5) EX_CASE(6) EX_CASE(7) EX_CASE(8) EX_CASE(9) EX_CASE(10)
+#undef EX_CASE
+    }
 }
 
 void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr,
@@ -786,11 +877,14 @@ void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gaus
     hipLaunchKernelGGL(k_sb_orient, dim3(waves, F), dim3(64), 0, s, P, gauss, surv, surv_cap, E, kps, kp_cap, counts);
 }
 
-void launch_sb_sort_emit(hipStream_t s, const SiftKp* kps, int kp_cap, int* counts, int* rank, SiftKp* sorted, SiftKp* out, int out_cap, int* out_count,
-                         int* out_flags, int cand_cap, int surv_cap, int F)
+void launch_sb_sort_emit(hipStream_t s, const SiftKp* kps, int kp_cap, int* counts, int* rank, void* rank_tmp, SiftKp* sorted, SiftKp* out, int out_cap,
+                         int* out_count, int* out_flags, int cand_cap, int surv_cap, int F)
 {
-    hipLaunchKernelGGL(k_sb_rank, dim3((kp_cap + 255) / 256, F), dim3(256), 0, s, kps, kp_cap, counts, rank);
-    hipLaunchKernelGGL(k_sb_scatter, dim3((kp_cap + 255) / 256, F), dim3(256), 0, s, kps, kp_cap, counts, rank, sorted);
+    // `rank` doubles as the bucket-start table [F][RK_NB + 1]; `out` (the final list, not written before k_sb_emit) holds the
+    // bucket-ordered copy in between when it is large enough, else the records are ranked against the whole frame's bucket table in place
+    SiftKp* tmp = (SiftKp*)rank_tmp;
+    hipLaunchKernelGGL(k_sb_bucket, dim3(F), dim3(1024), 0, s, kps, kp_cap, counts, tmp, rank);
+    hipLaunchKernelGGL(k_sb_rank, dim3((kp_cap + 255) / 256, F), dim3(256), 0, s, tmp, kp_cap, counts, rank, sorted);
     hipLaunchKernelGGL(k_sb_emit, dim3(F), dim3(256), 0, s, sorted, kp_cap, counts, out, out_cap, out_count, out_flags, cand_cap, surv_cap);
 }
 

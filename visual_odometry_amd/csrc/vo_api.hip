@@ -949,6 +949,7 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
     for (int i = 0; i < 2 * B; i++)
         if (pair_slots[i] < 0 || pair_slots[i] >= max_frames) FAIL(VO_ERR_INVALID, "pair slot %d out of range", pair_slots[i]);
     *whole_x_out = false;
+    ctx->last_pairs = B;
     if (B == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1090,7 +1091,7 @@ extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
     }
     hipStream_t s = ctx->stream;
     StageTimer t(ctx, ST_GATHER);
-    launch_pack_records(s, ctx->pb.res, B, ctx->rec_send);
+    launch_pack_records(s, ctx->pb.res, B, ctx->last_pairs, ctx->rec_send);
     HIPCHK(hipGetLastError());
     const double* src = ctx->rec_send;
     if (ctx->comm) {
@@ -1100,6 +1101,25 @@ extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
     }
     HIPCHK(hipMemcpyAsync(gathered, src, n * world * sizeof(double), hipMemcpyDeviceToHost, s));
     if (wait) HIPCHK(hipStreamSynchronize(s));
+    return VO_OK;
+}
+
+// A small all-gather of host doubles over the context's communicator, synchronous: what a launcher needs for its
+// barrier (n = 1) and for the max-over-ranks of a timing, without any other communication library.
+extern "C" int vo_comm_allgather_f64(vo_ctx* ctx, const double* send, int n, double* recv)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!send || !recv || n < 1 || n > 4096) FAIL(VO_ERR_INVALID, "bad all-gather arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int world = ctx->comm ? ctx->comm_world : 1;
+    if (!ctx->comm) { memcpy(recv, send, (size_t)n * sizeof(double)); return VO_OK; }
+    int rc = ensure_raw_d(ctx, (size_t)n * (world + 1)); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemcpyAsync(ctx->raw_d, send, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    const char* e = rccl_all_gather_f64(ctx->comm, ctx->raw_d, ctx->raw_d + n, (size_t)n, s);
+    if (e) FAIL(VO_ERR_HIP, "ncclAllGather failed: %s", e);
+    HIPCHK(hipMemcpyAsync(recv, ctx->raw_d + n, (size_t)n * world * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return VO_OK;
 }
 
@@ -1804,7 +1824,7 @@ static int sift_setup(vo_ctx* ctx, SiftState& S, int h, int w, const vo_sift_par
     HIPCHK(dmalloc(&S.G, B * gtot)); HIPCHK(dmalloc(&S.D, B * dtot)); HIPCHK(dmalloc(&S.up, B * P.plane[0]));
     HIPCHK(dmalloc(&S.cand, B * cand_cap)); HIPCHK(dmalloc(&S.surv, B * surv_cap));
     HIPCHK(dmalloc(&S.kraw, B * raw_cap)); HIPCHK(dmalloc(&S.ksorted, B * raw_cap)); HIPCHK(dmalloc(&S.kfin, B * kp_cap));
-    HIPCHK(dmalloc(&S.rank, B * raw_cap)); HIPCHK(dmalloc(&S.counts, B * 4)); HIPCHK(dmalloc(&S.fin_count, B)); HIPCHK(dmalloc(&S.fin_flags, B));
+    HIPCHK(dmalloc(&S.rank, B * 4097)); HIPCHK(dmalloc(&S.counts, B * 4)); HIPCHK(dmalloc(&S.fin_count, B)); HIPCHK(dmalloc(&S.fin_flags, B));
     HIPCHK(hipDeviceSynchronize());
     S.configured = true;
     return VO_OK;
@@ -1848,7 +1868,8 @@ static int sift_detect_enqueue(vo_ctx* ctx, SiftState& S, const uint8_t* src, in
     }
     {
         StageTimer t(ctx, ST_SIFT_SORT);
-        launch_sb_sort_emit(s, S.kraw, S.raw_cap, S.counts, S.rank, S.ksorted, S.kfin, S.kp_cap, S.fin_count, S.fin_flags, S.cand_cap, S.surv_cap, F);
+        // (the survivor list is dead once the orientations are assigned: its memory holds the bucket-ordered copy of the records)
+        launch_sb_sort_emit(s, S.kraw, S.raw_cap, S.counts, S.rank, S.surv, S.ksorted, S.kfin, S.kp_cap, S.fin_count, S.fin_flags, S.cand_cap, S.surv_cap, F);
     }
     HIPCHK(hipGetLastError());
     return VO_OK;
@@ -1947,8 +1968,10 @@ extern "C" int vo_batch_configure_sift(vo_ctx* ctx, int h, int w, const vo_sift_
     if (kp_cap > 65536) FAIL(VO_ERR_INVALID, "kp_cap > 65536");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    // frames per launch chain: the small octaves' launches are latency-bound (a dependent chain of ~60 launches per sub-batch),
+    // so the more frames share them the better; 64 frames = 13.5 GB of scale-space scratch at 1280 x 720
     const char* ev = getenv("VO_SIFT_SUBBATCH");
-    int fb = ev ? atoi(ev) : 16;
+    int fb = ev ? atoi(ev) : 64;
     if (fb < 1) fb = 1;
     if (fb > max_frames) fb = max_frames;
     // the intermediate lists (sub-batch scratch) are generous whatever kp_cap is: only the final list is cut at kp_cap, in cv2's

@@ -150,7 +150,7 @@ const char* rccl_unique_id(uint8_t* id128);
 const char* rccl_comm_init(void** comm, const uint8_t* id128, int rank, int world);
 void rccl_comm_destroy(void* comm);
 const char* rccl_all_gather_f64(void* comm, const double* send, double* recv, size_t count, hipStream_t s);
-void launch_pack_records(hipStream_t s, const vo_pair_result* res, int B, double* rec);
+void launch_pack_records(hipStream_t s, const vo_pair_result* res, int B, int valid, double* rec);
 
 // ---- launchers (defined in the .hip files) --------------------------------------------------
 void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
@@ -200,8 +200,8 @@ int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG,
 void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o, float threshold, SiftCand* cand, int* counts, int cap, int F);
 void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr,
                              float edgeThr, float sigma, const SiftExpTab& E, SiftSurv* surv, int surv_cap, SiftKp* kps, int kp_cap, int* counts, int F, int waves);
-void launch_sb_sort_emit(hipStream_t s, const SiftKp* kps, int kp_cap, int* counts, int* rank, SiftKp* sorted, SiftKp* out, int out_cap, int* out_count,
-                         int* out_flags, int cand_cap, int surv_cap, int F);
+void launch_sb_sort_emit(hipStream_t s, const SiftKp* kps, int kp_cap, int* counts, int* rank /*[F][4097]*/, void* rank_tmp /*[F][kp_cap] records*/, SiftKp* sorted,
+                         SiftKp* out, int out_cap, int* out_count, int* out_flags, int cand_cap, int surv_cap, int F);
 void launch_sb_descriptor(hipStream_t s, const SiftGeom& P, const float* gauss, const SiftKp* kps, int kp_cap, const int* counts, const SiftExpTab& E,
                           uint8_t* desc, uint8_t* desc_x, int cap_x, int* norms, int* flags, int first_slot, int F, int waves);
 void launch_sb_unpack(hipStream_t s, const SiftKp* kps, int kp_cap, const int* counts, int first_slot, float* kp_xy, float* kp_size, float* kp_angle,

@@ -55,6 +55,49 @@ def run_sharded(n_items: int, rank: int, world: int, chunk: int, process_chunk, 
     return out
 
 
+def run_sharded_pipelined(n_items: int, rank: int, world: int, chunk: int, pipeline, plan_chunk) -> np.ndarray:
+    """run_sharded on the chunk pipeline (pipeline.ChunkPipeline: several contexts, page-locked uploads, detection and
+    geometry of different chunks overlapping, the record gather issued behind each chunk): the loop that runs BASELINE
+    configs 4 and 5 at the GPU's streamed rate.  plan_chunk(a, b) -> dict(pairs=[b - a, 2] slot indices, n_frames=slots to
+    detect, uploads=[(page-locked frames, first_slot), ...]) describes items [a, b) of this rank's block; a rank whose block
+    is exhausted submits empty chunks so that every rank issues the same collectives.  Returns the records of ALL items in
+    global order, identical on every rank."""
+    lo, hi = shard_range(n_items, rank, world)
+    _, rounds = sharded_plan(n_items, world, chunk)
+    out = np.full((n_items, RECORD_WIDTH), np.nan)
+
+    def place(ret):
+        c = ret.tag
+        everyone = ret.gathered if ret.gathered is not None else ret.records()[None]
+        for r in range(everyone.shape[0]):
+            rlo, rhi = shard_range(n_items, r if everyone.shape[0] > 1 else rank, world)
+            ra = min(rlo + c * chunk, rhi); rb = min(ra + chunk, rhi)
+            out[ra:rb] = everyone[r, :rb - ra]
+
+    for c in range(rounds):
+        a = min(lo + c * chunk, hi); b = min(a + chunk, hi)
+        spec = plan_chunk(a, b) if b > a else dict(pairs=np.zeros((0, 2), np.int32), n_frames=0, uploads=None)
+        ret = pipeline.submit(spec["pairs"], spec["n_frames"], spec.get("uploads"), tag=c)
+        if ret is not None:
+            place(ret)
+    for ret in pipeline.drain():
+        place(ret)
+    return out
+
+
+def ring_uploads(ring, first_view: int, count: int):
+    """`count` consecutive views of a closed flight starting at `first_view`, as slices of the page-locked array `ring`
+    ([D, H, W]: every rendered view once) -> [(slice, first_slot), ...] for ChunkPipeline.submit: no host copy, at most two
+    DMA transfers per wrap of the ring."""
+    D = len(ring)
+    out, slot, v = [], 0, first_view % D
+    while count > 0:
+        n = min(count, D - v)
+        out.append((ring[v:v + n], slot))
+        slot += n; count -= n; v = 0
+    return out
+
+
 def records_to_trajectory(rec: np.ndarray):
     """Chain the gathered relative poses x_{k+1} ~ R_k x_k + t_k (unit-norm t) into camera centres; pairs whose
     n_inl column is negative (failed) repeat the previous step.  Returns (centres [n+1, 3], number of failed pairs)."""
