@@ -140,7 +140,7 @@ def orb_detect_and_compute(img, params, cap=None):
 
 
 def set_keypoint_order(order):
-    """'canonical' (default): keypoints in (octave, y, x) order; 'cv2': KeyPointsFilter::retainBest's libstdc++ order."""
+    """'cv2' (default): KeyPointsFilter::retainBest's libstdc++ order, the list cv2.ORB returns; 'canonical': (octave, y, x) order."""
     lib().voo_set_keypoint_order({"canonical": 0, "cv2": 1}[order])
 
 

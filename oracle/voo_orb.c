@@ -337,7 +337,7 @@ static int cmp_desc_f(const void* a, const void* b)
     return fa > fb ? -1 : (fa < fb ? 1 : 0);
 }
 
-static int g_cv2_order = 0;
+static int g_cv2_order = 1;                 /* default: cv2's own list order (the faithful algorithm); 0 = canonical (level, y, x) */
 void voo_set_keypoint_order(int cv2_order) { g_cv2_order = cv2_order != 0; }
 int voo_get_keypoint_order(void) { return g_cv2_order; }
 

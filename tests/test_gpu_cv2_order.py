@@ -42,13 +42,13 @@ def test_detect_and_compute_in_cv2_order(oracle, seq_small):
     img = seq_small["frames"][0]
     for nf, nl in ((500, 8), (1500, 5)):
         p = oracle.orb_params(nfeatures=nf, nlevels=nl)
-        canon = oracle.orb_detect_and_compute(img, p)
-        oracle.set_keypoint_order("cv2")
+        ref = oracle.orb_detect_and_compute(img, p)                         # cv2's order: the default of oracle and library
+        oracle.set_keypoint_order("canonical")
         try:
-            ref = oracle.orb_detect_and_compute(img, p)
+            canon = oracle.orb_detect_and_compute(img, p)
         finally:
-            oracle.set_keypoint_order("canonical")
-        got = OrbDetector(nfeatures=nf, nlevels=nl, keypoint_order="cv2").detect_arrays(img)
+            oracle.set_keypoint_order("cv2")
+        got = OrbDetector(nfeatures=nf, nlevels=nl).detect_arrays(img)
         assert not got["truncated"]
         for key in ("xy", "octave", "angle", "response", "size", "desc"):
             assert np.array_equal(got[key], ref[key]), key                 # same keypoints at the same INDICES
@@ -56,8 +56,10 @@ def test_detect_and_compute_in_cv2_order(oracle, seq_small):
         k1 = sorted(map(tuple, np.c_[canon["octave"], canon["xy"]].tolist()))
         k2 = sorted(map(tuple, np.c_[got["octave"], got["xy"]].tolist()))
         assert k1 == k2                                                     # same SET in both modes
-        again = OrbDetector(nfeatures=nf, nlevels=nl).detect_arrays(img)   # switching back restores the canonical order
+        again = OrbDetector(nfeatures=nf, nlevels=nl, keypoint_order="canonical").detect_arrays(img)   # the other mode on the same context
         assert np.array_equal(again["xy"], canon["xy"]) and np.array_equal(again["desc"], canon["desc"])
+        back = OrbDetector(nfeatures=nf, nlevels=nl).detect_arrays(img)    # ... and switching back restores cv2's
+        assert np.array_equal(back["xy"], ref["xy"]) and np.array_equal(back["desc"], ref["desc"])
 
 
 def test_pairs_in_cv2_order_have_cv2_match_indices(oracle):
@@ -68,15 +70,15 @@ def test_pairs_in_cv2_order_have_cv2_match_indices(oracle):
     from visual_odometry_amd.frontend import FrontEnd
     seq = synth.sequence(3, 1280, 720, cache_dir="/tmp")
     frames, K = seq["frames"], seq["K"]
-    fe = FrontEnd(720, 1280, max_frames=3, max_pairs=2, nfeatures=2000, nlevels=8, keypoint_order="cv2")
+    fe = FrontEnd(720, 1280, max_frames=3, max_pairs=2, nfeatures=2000, nlevels=8)                 # keypoint_order="cv2" is the default
     fe.upload(frames); fe.detect(0, 3)
     res, X = fe.run_pairs([[0, 1], [1, 2]], K, fe.make_opts(want_points=True))
     p = oracle.orb_params(nfeatures=2000, nlevels=8)
-    oracle.set_keypoint_order("cv2"); oracle.set_dk_early_exit(True)
+    oracle.set_dk_early_exit(True)
     try:
         ref = [oracle_pair_stages(oracle, frames[i], frames[i + 1], p, K) for i in range(2)]
     finally:
-        oracle.set_keypoint_order("canonical"); oracle.set_dk_early_exit(False)
+        oracle.set_dk_early_exit(False)
     for k, r in enumerate(ref):
         if k == 0:
             got = fe.features(0)

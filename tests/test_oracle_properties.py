@@ -65,9 +65,23 @@ def test_detect_keeps_border_and_quota(oracle):
         assert x.min() >= 30.99 and x.max() < lw[l] - 31 + 0.01 and y.min() >= 30.99 and y.max() < lh[l] - 31 + 0.01
         assert m.sum() >= min(q[l], m.sum())
         key = np.rint(y).astype(np.int64) * 100000 + np.rint(x).astype(np.int64)
-        assert np.all(np.diff(key) > 0)                        # canonical (y, x) order inside a level
+        assert len(np.unique(key)) == len(key)                 # (cv2's own list order, the default: a permutation, no repeats)
     assert np.all(np.diff(d["octave"]) >= 0)
     assert np.all((d["angle"] >= 0) & (d["angle"] < 360.001))
+    # the canonical order is the same SET, sorted by (y, x) inside a level
+    oracle.set_keypoint_order("canonical")
+    try:
+        c = oracle.orb_detect_and_compute(img, p)
+    finally:
+        oracle.set_keypoint_order("cv2")
+    assert len(c["xy"]) == len(d["xy"])
+    for l in range(8):
+        m = c["octave"] == l
+        if m.any():
+            key = np.rint(c["xy"][m, 1] / ls[l]).astype(np.int64) * 100000 + np.rint(c["xy"][m, 0] / ls[l]).astype(np.int64)
+            assert np.all(np.diff(key) > 0)
+    a = {tuple(r) for r in np.c_[d["xy"], d["octave"]].tolist()}; b = {tuple(r) for r in np.c_[c["xy"], c["octave"]].tolist()}
+    assert a == b
 
 
 def test_descriptor_rotation_covariance(oracle):
@@ -254,3 +268,27 @@ def test_cv2_order_unit_is_libstdcxx_retain_best(oracle):
             if f == l: break
             a[f], a[l] = a[l], a[f]; f += 1
         assert got.tolist() == [i for _, i in a[:f]], (it, n, n_points)
+
+
+def test_sqrtf_is_strictly_increasing_on_integers_below_2_pow_22():
+    """The matrix-core L2 matcher of SIFT rows (k_nn_l2i8) selects on the exact integer d^2, cv2's batchDistance on
+    sqrtf(d^2) with strict `<`: the same selection iff no two integers in range share a float square root.  True below 2^22
+    (and k_sb_descriptor flags any row whose norm would allow a larger d^2); false further up, which is why the bound exists."""
+    n = np.arange(0, (1 << 22) + 1, dtype=np.float32)
+    r = np.sqrt(n)
+    assert r.dtype == np.float32 and np.all(np.diff(r) > 0)
+    hi = np.sqrt(np.arange(1 << 23, (1 << 23) + 4096, dtype=np.float32))
+    assert np.any(np.diff(hi) == 0)                                   # beyond the bound neighbouring integers do collide
+
+
+def test_l2_distance_of_integer_rows_is_exact_in_any_order(oracle):
+    """normL2Sqr_ on SIFT rows (integers 0..255 as float32): every partial sum is an integer below 2^24, so the float sum is the
+    exact integer d^2 whatever the order — the identity the int8 matrix-core matcher rests on."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (40, 128)).astype(np.float32); b = rng.integers(0, 256, (50, 128)).astype(np.float32)
+    qi, ti, d = oracle.match_l2(a, b, 0)
+    d2 = ((a[:, None, :].astype(np.int64) - b[None, :, :].astype(np.int64)) ** 2).sum(2)
+    assert np.array_equal(ti, d2.argmin(1)) and np.array_equal(d, np.sqrt(d2.min(1).astype(np.float32)))
+    shifted = ((a[:, None, :].astype(np.int64) - 128) * (b[None, :, :].astype(np.int64) - 128)).sum(2)
+    na = ((a.astype(np.int64) - 128) ** 2).sum(1); nb = ((b.astype(np.int64) - 128) ** 2).sum(1)
+    assert np.array_equal(na[:, None] + nb[None, :] - 2 * shifted, d2)

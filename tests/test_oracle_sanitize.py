@@ -51,7 +51,7 @@ fq = np.random.default_rng(2).random((70, 128)).astype(np.float32); ft = np.rand
 for mode in (0, 1, 2):
     O.match_l2(fq, ft, mode); O.match_l2(fq[:, :61].copy(), ft[:, :61].copy(), mode)
 O.retain_best_cv2(np.random.default_rng(4).integers(0, 9, 500).astype(np.float32), 100)
-O.set_keypoint_order("cv2"); O.orb_detect_and_compute(f[0], p); O.set_keypoint_order("canonical")
+O.set_keypoint_order("canonical"); O.orb_detect_and_compute(f[0], p); O.set_keypoint_order("cv2")
 gp = np.load(os.path.join(G, "pnp_240.npz"))
 rc, rv, tv, mk, ni = O.solve_pnp_ransac(gp["obj"], gp["img"], gp["K"])
 assert rc == 0 and ni == int(gp["n_inl"])

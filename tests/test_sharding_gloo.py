@@ -125,3 +125,128 @@ def test_ate_alignment_removes_similarity():
     q *= np.sign(np.linalg.det(q))
     assert ate_after_alignment(2.5 * p @ q.T + [3, -1, 2], p) < 1e-9
     assert ate_after_alignment(p + rng.normal(0, 0.1, p.shape), p) > 0.05
+
+
+class _FakeFrontEnd:
+    """Stands in for frontend.FrontEnd in the CPU tests of the chunk pipeline: same methods, results computed on the host from
+    the 'frames' it was handed (a frame = one byte holding its global index), delivered only at wait() like the real, asynchronous one."""
+
+    def __init__(self, max_frames, max_pairs, log):
+        from visual_odometry_amd import _lib
+        self.max_frames, self.max_pairs, self.log = max_frames, max_pairs, log
+        self.slots = np.full(max_frames, -1, np.int64)
+        self._res = np.zeros(max_pairs, _lib.PAIR_RESULT_DTYPE)
+        self._pending = None
+        self.detected = 0
+
+    def make_opts(self, **kw):
+        return None
+
+    def upload(self, arr, first_slot=0, wait=True):
+        assert not wait and first_slot + len(arr) <= self.max_frames
+        self.slots[first_slot:first_slot + len(arr)] = np.asarray(arr).reshape(len(arr), -1)[:, 0]
+        self.log.append(("upload", first_slot, len(arr)))
+
+    def detect(self, first, count, wait=True, after=None):
+        assert not wait
+        self.detected += count
+
+    def run_pairs(self, pairs, K, opts, wait=True):
+        assert not wait and self._pending is None
+        self._pending = np.array(pairs, np.int64).reshape(-1, 2)
+        return self._res, None
+
+    def wait(self):
+        if self._pending is None:
+            return
+        p, self._pending = self._pending, None
+        r = self._res
+        r[:] = 0
+        for i, (a, b) in enumerate(p):
+            ga, gb = self.slots[a], self.slots[b]
+            r["R"][i] = np.eye(3).ravel(); r["t"][i] = [1.0, 0.0, 0.0]
+            r["n_kp1"][i] = ga; r["n_match"][i] = gb; r["n_inl"][i] = 100 + ga; r["n_good"][i] = 7
+
+
+def _pipelined_worker(rank, world, port, q, n_frames, chunk, n_ctx, workload):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from visual_odometry_amd import sharding
+    from visual_odometry_amd.pipeline import ChunkPipeline
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = 10                                                           # ten distinct views, walked cyclically
+    ring = (np.arange(D, dtype=np.uint8)[:, None, None] * np.ones((1, 2, 3), np.uint8))
+    log = []
+    nf = 2 * chunk if workload == "batch" else chunk + 1
+    fes = [_FakeFrontEnd(nf, chunk, log) for _ in range(n_ctx)]
+
+    def gather(rec):                                                 # the callable form of the gather: gloo
+        out = torch.empty((world * chunk, sharding.RECORD_WIDTH), dtype=torch.float64)
+        dist.all_gather_into_tensor(out, torch.from_numpy(np.ascontiguousarray(rec)))
+        return out.numpy().reshape(world, chunk, sharding.RECORD_WIDTH)
+
+    pipe = ChunkPipeline(fes, np.eye(3), opts="unused", world=world, rank=rank, gather=gather, gather_rows=chunk)
+    n_items = n_frames - 1 if workload == "sequence" else n_frames
+
+    def plan(a, b):
+        n = b - a
+        if workload == "sequence":
+            return dict(pairs=np.stack([np.arange(n), np.arange(n) + 1], 1), n_frames=n + 1, uploads=sharding.ring_uploads(ring, a, n + 1))
+        return dict(pairs=np.stack([2 * np.arange(n), 2 * np.arange(n) + 1], 1), n_frames=2 * n, uploads=sharding.ring_uploads(ring, 2 * a, 2 * n))
+
+    rec = sharding.run_sharded_pipelined(n_items, rank, world, chunk, pipe, plan)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, rec, sum(f.detected for f in fes), log))
+
+
+@pytest.mark.parametrize("n,chunk,n_ctx,workload", [(24, 4, 3, "sequence"), (11, 8, 2, "sequence"), (3, 4, 1, "sequence"), (9, 2, 3, "batch")])
+def test_pipelined_sharded_driver_world_size_2_gloo(n, chunk, n_ctx, workload):
+    """sharding.run_sharded_pipelined + pipeline.ChunkPipeline at world size 2: contexts alternate, chunks retire out of band,
+    exhausted ranks pad the collective, ring uploads wrap — and every rank still ends with every record in global order."""
+    import torch.multiprocessing as mp
+    from visual_odometry_amd import sharding
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q, n, chunk, n_ctx, workload)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, rec, detected, log = q.get(timeout=120)
+        got[r] = (rec, detected, log)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0][0], got[1][0])
+    rec = got[0][0]
+    n_items = n - 1 if workload == "sequence" else n
+    assert rec.shape == (n_items, 16) and not np.isnan(rec).any()
+    g = np.arange(n_items)
+    if workload == "sequence":                                        # pair g = frames (g, g + 1) = views (g % 10, (g + 1) % 10)
+        assert np.array_equal(rec[:, 12], g % 10) and np.array_equal(rec[:, 13], (g + 1) % 10)
+    else:                                                             # pair p = views (2p, 2p + 1)
+        assert np.array_equal(rec[:, 12], (2 * g) % 10) and np.array_equal(rec[:, 13], (2 * g + 1) % 10)
+    assert np.array_equal(rec[:, 14], 100 + rec[:, 12])
+    for r in range(2):
+        lo, hi = sharding.shard_range(n_items, r, 2)
+        per = (hi - lo) + (-(-(hi - lo) // chunk) if workload == "sequence" else (hi - lo))      # frames detected: pairs + one halo per chunk / two per pair
+        assert got[r][1] == per
+
+
+def test_file_rendezvous_two_processes(tmp_path):
+    """rendezvous.FileRendezvous: rank 0's bytes reach the other rank, barriers meet, the directory goes away at close."""
+    import subprocess
+    import sys
+    code = ("import os,sys; sys.path.insert(0, %r); from visual_odometry_amd.rendezvous import FileRendezvous\n"
+            "r=int(sys.argv[1]); rdv=FileRendezvous(r, 2, key='t', root=sys.argv[2], timeout=30)\n"
+            "rdv.barrier('a'); a=rdv.broadcast(b'x'*128 if r==0 else b'', 'id'); b=rdv.broadcast(bytes(range(7)) if r==0 else b'')\n"
+            "rdv.barrier(); print(len(a), a[:1], list(b)); rdv.barrier('end')\n"
+            "import time; time.sleep(0.2 if r == 0 else 0); rdv.close()\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ps = [subprocess.Popen([sys.executable, "-c", code, str(r), str(tmp_path)], stdout=subprocess.PIPE, text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=60)[0].strip() for p in ps]
+    assert all(p.returncode == 0 for p in ps)
+    assert outs[0] == outs[1] == "128 b'x' [0, 1, 2, 3, 4, 5, 6]"
+    assert not os.path.exists(os.path.join(str(tmp_path), "vo_rdv_t"))

@@ -173,7 +173,18 @@ class Context:
 
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         buf = (C.c_uint8 * VO_COMM_ID_BYTES).from_buffer_copy(unique_id)
-        self.check(self.lib.vo_comm_init(self.handle, buf, int(rank), int(world)))
+        # RCCL prints a version banner on the process's STDOUT when the first communicator is created; a launcher's stdout is a
+        # data channel (bench.py prints one JSON line), so the banner is sent to stderr: fd 1 points at fd 2 for the call
+        import sys
+        sys.stdout.flush()
+        keep = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = self.lib.vo_comm_init(self.handle, buf, int(rank), int(world))
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+        self.check(rc)
 
     def comm_destroy(self):
         self.check(self.lib.vo_comm_destroy(self.handle))
@@ -186,7 +197,7 @@ class Context:
         return out
 
     def set_keypoint_order(self, kind):
-        """'canonical' (default): keypoints in (octave, y, x) order; 'cv2': the order cv2.ORB returns them in
+        """'cv2' (default): the order cv2.ORB returns the keypoints in; 'canonical': (octave, y, x) order, the same set;
         (KeyPointsFilter::retainBest's libstdc++ permutation), so keypoint and match indices equal cv2's."""
         self.check(self.lib.vo_set_keypoint_order(self.handle, {"canonical": 0, "cv2": 1}[kind]))
 

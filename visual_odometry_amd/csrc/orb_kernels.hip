@@ -970,13 +970,14 @@ __global__ __launch_bounds__(64) void k_sel_threshold(PyrGeom g, FrameFeat ff, i
 
 // One wavefront per (frame, level, row of FAST tiles).  COUNT: how many listed winners reach the threshold.
 // EMIT: the kept winners of the tile row are gathered into LDS (ballot + prefix), each one's rank among them in
-// (y, x) order is counted against the LDS copy (keys are unique), and it is written at base + rank, base = the kept
-// counts of the tile rows above: canonical raster order without sorting and without touching a score map.
+// (y, x) order comes from a bitmap of the tile row's pixels (set bits in front of its own: keys are unique), and it is
+// written at base + rank, base = the kept counts of the tile rows above: canonical raster order without sorting, without
+// comparing winners with one another and without touching a score map.
 template <bool EMIT>
 __global__ __launch_bounds__(64) void k_sel_rows(const uint32_t* tile_list, const int* tile_count, PyrGeom g, FrameFeat ff,
-                                                 const int* thr, int* chunk_count, int lds_cap)
+                                                 const int* thr, int* chunk_count)
 {
-    extern __shared__ uint32_t s_sel[];               // EMIT: keys [lds_cap] then scores [lds_cap]
+    extern __shared__ uint32_t s_sel[];               // EMIT: [NW] bitmap of the tile row's pixels, then [NW] set bits in front of each word
     const int f = blockIdx.y, lane = threadIdx.x;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].sel_chunk_base) l++;
@@ -991,55 +992,84 @@ __global__ __launch_bounds__(64) void k_sel_rows(const uint32_t* tile_list, cons
         return;
     }
     const size_t tile0 = (size_t)f * g.ftiles_total + lv.ftile_base + (size_t)chunk * lv.ftiles_x;
+    if (!EMIT) {
+        int n = 0;                                    // wave-uniform: kept winners of this tile row
+        for (int t = 0; t < lv.ftiles_x; t++) {
+            const int cnt = min(tile_count[tile0 + t], FT_LISTCAP);
+            const uint32_t* lst = tile_list + (tile0 + t) * FT_LISTCAP;
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                const int j = j0 + lane;
+                const uint32_t e = j < cnt ? lst[j] : 0u;
+                n += (int)__popcll(__ballot(j < cnt && (int)(e >> 16) >= T));
+            }
+        }
+        if (lane == 0) *my_count = n;
+        return;
+    }
     int base = 0;
-    if (EMIT) {
+    {
         const int* cc = chunk_count + (size_t)f * g.sel_chunks_total + lv.sel_chunk_base;
         for (int c = lane; c < chunk; c += 64) base += cc[c];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) base += __shfl_xor(base, d, 64);
     }
-    int n = 0;                                        // wave-uniform: kept winners of this tile row
+    // Rank of every kept winner in (y, x) order without comparing winners with one another and without a copy of them: a bit
+    // per pixel of the tile row (FAST_TH rows x level width) is set for every kept winner, the words' population counts are
+    // scanned, and a winner's rank is the number of set bits in front of its own.  The tile lists are read twice (L2).
+    const int W32 = (lv.w + 31) >> 5, NW = FAST_TH * W32;
+    uint32_t* s_bm = s_sel;
+    uint32_t* s_pf = s_sel + NW;
+    for (int i = lane; i < NW; i += 64) s_bm[i] = 0u;
+    __syncthreads();
     for (int t = 0; t < lv.ftiles_x; t++) {
         const int cnt = min(tile_count[tile0 + t], FT_LISTCAP);
         const uint32_t* lst = tile_list + (tile0 + t) * FT_LISTCAP;
-        for (int j0 = 0; j0 < cnt; j0 += 64) {
-            const int j = j0 + lane;
-            const uint32_t e = j < cnt ? lst[j] : 0u;
-            const bool kept = j < cnt && (int)(e >> 16) >= T;
-            const unsigned long long m = __ballot(kept);
-            if (EMIT) {
-                const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (kept && slot < lds_cap) {
-                    const uint32_t gy = (uint32_t)(chunk * FAST_TH) + ((e >> 8) & 255u), gx = (uint32_t)(t * FAST_TW) + (e & 255u);
-                    s_sel[slot] = (gy << 16) | gx;
-                    s_sel[lds_cap + slot] = e >> 16;
-                }
-            }
-            n += (int)__popcll(m);
+        for (int j = lane; j < cnt; j += 64) {
+            const uint32_t e = lst[j];
+            if ((int)(e >> 16) >= T) { const uint32_t gx = (uint32_t)(t * FAST_TW) + (e & 255u); atomicOr(&s_bm[((e >> 8) & 255u) * W32 + (gx >> 5)], 1u << (gx & 31u)); }
         }
     }
-    if (!EMIT) {
-        if (lane == 0) *my_count = n;
-        return;
-    }
-    bool overflow = n > lds_cap;
-    const int nk = min(n, lds_cap);
     __syncthreads();
+    int n;
+    {
+        const int per = (NW + 63) / 64, w0 = lane * per, w1 = min(NW, w0 + per);
+        int own = 0;
+        for (int wd = w0; wd < w1; wd++) own += __popc(s_bm[wd]);
+        int inc = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+        n = __shfl(inc, 63, 64);
+        int acc = inc - own;
+        for (int wd = w0; wd < w1; wd++) { s_pf[wd] = (uint32_t)acc; acc += __popc(s_bm[wd]); }
+    }
+    __syncthreads();
+    bool overflow = false;
     uint32_t* out_pos = ff.cand_pos + (size_t)f * g.cand_total + lv.cand_off;
     float* out_resp = ff.cand_resp + (size_t)f * g.cand_total + lv.cand_off;
-    for (int i0 = 0; i0 < nk; i0 += 64) {
-        const int i = i0 + lane;
-        const uint32_t key = s_sel[min(i, nk - 1)];
-        int rank = 0;
-        for (int j = 0; j < nk; j++) rank += s_sel[j] < key ? 1 : 0;       // wave-wide broadcast reads
-        const int pos = base + rank;
-        if (i < nk) {
-            if (pos < lv.cand_cap) { out_pos[pos] = key; out_resp[pos] = (float)s_sel[lds_cap + i]; }
-            else overflow = true;
+    for (int t = 0; t < lv.ftiles_x; t++) {
+        const int cnt = min(tile_count[tile0 + t], FT_LISTCAP);
+        const uint32_t* lst = tile_list + (tile0 + t) * FT_LISTCAP;
+        for (int j = lane; j < cnt; j += 64) {
+            const uint32_t e = lst[j];
+            if ((int)(e >> 16) >= T) {
+                const uint32_t ly = (e >> 8) & 255u, gx = (uint32_t)(t * FAST_TW) + (e & 255u);
+                const int wd = (int)(ly * W32 + (gx >> 5));
+                const int pos = base + (int)s_pf[wd] + __popc(s_bm[wd] & ((1u << (gx & 31u)) - 1u));
+                if (pos < lv.cand_cap) { out_pos[pos] = (((uint32_t)(chunk * FAST_TH) + ly) << 16) | gx; out_resp[pos] = (float)(e >> 16); }
+                else overflow = true;
+            }
         }
     }
     if (overflow) atomicOr(&ff.flags[f], 1);
     if (chunk == nchunks - 1 && lane == 0) ff.cand_count[f * VO_MAX_LEVELS + l] = min(base + n, lv.cand_cap);
+}
+
+// LDS of k_sel_rows<emit>: one bit per pixel of a row of FAST tiles + the scanned word counts
+static size_t sel_bitmap_bytes(const PyrGeom& g)
+{
+    int w = 0;
+    for (int l = 0; l < g.nlevels; l++) w = g.lv[l].w > w ? g.lv[l].w : w;
+    return (size_t)2 * FAST_TH * ((w + 31) / 32) * 4;
 }
 
 void launch_select_fast(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, int* thr, int* chunk_count,
@@ -1047,11 +1077,8 @@ void launch_select_fast(hipStream_t s, const PyrGeom& g, FrameFeat ff, int F, in
 {
     hipLaunchKernelGGL(k_sel_threshold, dim3(g.nlevels, F), dim3(64), 0, s, g, ff, thr);
     if (g.sel_chunks_total <= 0) return;
-    int cap = 0;
-    for (int l = 0; l < g.nlevels; l++) cap = g.lv[l].cand_cap > cap ? g.lv[l].cand_cap : cap;
-    if (cap > 7680) cap = 7680;                       // 60 KB of LDS; a tile row holding more kept corners is truncated and flagged
-    hipLaunchKernelGGL(k_sel_rows<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, tile_list, tile_count, g, ff, thr, chunk_count, cap);
-    hipLaunchKernelGGL(k_sel_rows<true>, dim3(g.sel_chunks_total, F), dim3(64), (size_t)cap * 8, s, tile_list, tile_count, g, ff, thr, chunk_count, cap);
+    hipLaunchKernelGGL(k_sel_rows<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, tile_list, tile_count, g, ff, thr, chunk_count);
+    hipLaunchKernelGGL(k_sel_rows<true>, dim3(g.sel_chunks_total, F), dim3(64), sel_bitmap_bytes(g), s, tile_list, tile_count, g, ff, thr, chunk_count);
 }
 
 // cv2-order mode: the same two kernels with threshold 1 and the all-winner list geometry give the raster-ordered list
@@ -1060,14 +1087,12 @@ void launch_all_winners(hipStream_t s, const PyrGeom& g, FrameFeat ff, const Cv2
 {
     if (g.sel_chunks_total <= 0) return;
     PyrGeom ga = g;
-    int cap = 0;
-    for (int l = 0; l < g.nlevels; l++) { ga.lv[l].cand_off = cb.all_off[l]; ga.lv[l].cand_cap = cb.all_cap[l]; cap = cb.all_cap[l] > cap ? cb.all_cap[l] : cap; }
+    for (int l = 0; l < g.nlevels; l++) { ga.lv[l].cand_off = cb.all_off[l]; ga.lv[l].cand_cap = cb.all_cap[l]; }
     ga.cand_total = cb.all_total;
     FrameFeat fa = ff;
     fa.cand_pos = cb.all_pos; fa.cand_resp = cb.all_resp; fa.cand_count = cb.all_count;
-    if (cap > 7680) cap = 7680;                       // a row of FAST tiles holding more winners is truncated and flagged
-    hipLaunchKernelGGL(k_sel_rows<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, tile_list, tile_count, ga, fa, cb.ones, cb.chunk_count, cap);
-    hipLaunchKernelGGL(k_sel_rows<true>, dim3(g.sel_chunks_total, F), dim3(64), (size_t)cap * 8, s, tile_list, tile_count, ga, fa, cb.ones, cb.chunk_count, cap);
+    hipLaunchKernelGGL(k_sel_rows<false>, dim3(g.sel_chunks_total, F), dim3(64), 0, s, tile_list, tile_count, ga, fa, cb.ones, cb.chunk_count);
+    hipLaunchKernelGGL(k_sel_rows<true>, dim3(g.sel_chunks_total, F), dim3(64), sel_bitmap_bytes(g), s, tile_list, tile_count, ga, fa, cb.ones, cb.chunk_count);
 }
 
 // ------------------------------------------------------------------ Harris response (orb.cpp HarrisResponses)

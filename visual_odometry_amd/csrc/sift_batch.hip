@@ -107,6 +107,9 @@ struct SiftTaps { int n; float k[SIFT_MAX_TAPS]; };
 
 // N > 0: tap count known at compile time (windows in registers); N == 0: any odd tap count <= SW_NMAX, taken from t.n
 #define SW_NMAX 63
+#ifndef SW_CTR_LDS
+#define SW_CTR_LDS 1                   // (measured: 7.87 vs 8.64 ms per 64 frames) 1: the source rows' centre columns wait in an LDS ring for the DoG; 0: they are read again (L2) when the row is written
+#endif
 template <int N>
 struct SweepDims {
     static constexpr int NN = N > 0 ? N : SW_NMAX;
@@ -116,7 +119,7 @@ struct SweepDims {
     static constexpr int INP = INW + 4;                          // LDS pitch of s_in
     static constexpr int RING = (NN + SW_RS - 1 + 7) & ~7;       // row-filtered rows kept
     static constexpr int CRING = (R + SW_RS + 7) & ~7;           // source centre rows kept (for the DoG)
-    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + CRING * SW_TW;
+    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + (SW_CTR_LDS ? CRING * SW_TW : 0);
 };
 
 template <int N>
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[q] += t.k[i] * win[WO + i + q];
                 }
-                *(float4*)(s_ctr + (seq % DM::CRING) * SW_TW + rx4) = make_float4(win[DM::R4], win[DM::R4 + 1], win[DM::R4 + 2], win[DM::R4 + 3]);
+                if (SW_CTR_LDS) *(float4*)(s_ctr + (seq % DM::CRING) * SW_TW + rx4) = make_float4(win[DM::R4], win[DM::R4 + 1], win[DM::R4 + 2], win[DM::R4 + 3]);
                 *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             } else {
 #pragma unroll
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[q] += t.k[i] * in[woff + i + q];
                 }
-                *(float4*)(s_ctr + (seq % CRING) * SW_TW + rx4) = make_float4(in[R4], in[R4 + 1], in[R4 + 2], in[R4 + 3]);
+                if (SW_CTR_LDS) *(float4*)(s_ctr + (seq % CRING) * SW_TW + rx4) = make_float4(in[R4], in[R4 + 1], in[R4 + 2], in[R4 + 3]);
                 *(float4*)(s_ring + (seq % RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
@@ -238,7 +241,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
                     if (m >= 0 && y < Y1) {
                         const size_t o = (size_t)y * stride + x;
                         if (dstG) dstG[o] = acc[q];
-                        if (dstD) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dstD[o] = acc[q] - s_ctr[ci * SW_TW + cc]; }
+                        if (dstD) {
+                            if (SW_CTR_LDS) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dstD[o] = acc[q] - s_ctr[ci * SW_TW + cc]; }
+                            else dstD[o] = acc[q] - src[o];     // this workgroup streamed the row through a moment ago: an L2 hit
+                        }
                     }
                 }
             }
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(256) void k_sb_emit(const SiftKp* sorted, int kp_ca
 #define SD_D 4
 #define SD_N 8
 #ifndef SD_SUB
-#define SD_SUB 2                       // 64-sample batches per routing round
+#define SD_SUB 1                       // 64-sample batches per routing round (1 / 2 / 4: 7.6 / 8.0 / 10.7 ms per 64 frames: LDS per wave, i.e. occupancy, outweighs the better balance of longer rounds)
 #endif
 #define SD_NS (64 * SD_SUB)
 #define SD_ROWS 128                    // window rows per chunk (two per lane)
@@ -838,7 +844,7 @@ static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG,
     while (seg > 64 && (long long)strips * ((h + seg - 1) / seg) * F < 2048) seg >>= 1;
     const int n = N > 0 ? N : t.n, r = n / 2, R4 = (r + 3) & ~3;
     const size_t lds = N > 0 ? (size_t)SweepDims<N>::LDS_FLOATS * 4
-                             : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + ((r + SW_RS + 7) & ~7)) * SW_TW) * 4;
+                             : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + (SW_CTR_LDS ? ((r + SW_RS + 7) & ~7) : 0)) * SW_TW) * 4;
     hipLaunchKernelGGL(k_sb_sweep<N>, dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t);
 }
 

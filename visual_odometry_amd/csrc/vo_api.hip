@@ -86,7 +86,7 @@ struct vo_ctx {
     int matcher_kernel = 2;               // 2: block-scaled FP4 MFMA (default), 0: int8 MFMA on +127/-127 bytes, 1: XOR + popcount
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;          // RCCL communicator of the trajectory gather
     double *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0;
-    int kp_order = 0;                     // 0: canonical (octave, y, x) keypoint order, 1: cv2's retainBest order
+    int kp_order = 1;                     // 1 (default): cv2's retainBest order — keypoint / match indices as cv2 numbers them; 0: canonical (octave, y, x)
     Cv2Buf cv2{};
     bool cv2_ready = false;
     int dk_early = 1;                     // five-point polynomial roots: 1 = noise-floor exit (default), 0 = fixed 300 sweeps
@@ -115,6 +115,7 @@ template <typename T>
 static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
 
 static int ensure_raw_d(vo_ctx* ctx, size_t n);
+static int ensure_bytes(vo_ctx* ctx, uint8_t** p, size_t* have, size_t need);
 
 // ------------------------------------------------------------------ profiling brackets
 struct StageTimer {
@@ -533,6 +534,16 @@ static int frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int 
         // dense frames and an unpadded level 0: the whole batch is ONE strided copy (a "row" = a frame)
         HIPCHK(hipMemcpy2DAsync(dst0, ctx->g.frame_bytes, frames, (size_t)frame_stride, (size_t)ctx->w * ctx->h, F,
                                 hipMemcpyHostToDevice, ctx->stream));
+        return VO_OK;
+    }
+    if (row_stride == ctx->w && frame_stride >= (int64_t)ctx->w * ctx->h) {
+        // dense frames, padded level-0 rows (width not a multiple of 64, e.g. KITTI's 1241): ONE transfer of the dense bytes into
+        // a staging buffer, then a kernel lays the rows out (a 2-D copy per frame runs at a fraction of the PCIe rate)
+        const size_t per = (size_t)ctx->w * ctx->h;
+        int rc = ensure_bytes(ctx, &ctx->staging, &ctx->staging_bytes, per * F); if (rc) return rc;
+        HIPCHK(hipMemcpy2DAsync(ctx->staging, per, frames, (size_t)frame_stride, per, F, hipMemcpyHostToDevice, ctx->stream));
+        launch_gray(ctx->stream, ctx->staging, 1, ctx->w, (int64_t)per, ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes, ctx->g, F);
+        HIPCHK(hipGetLastError());
         return VO_OK;
     }
     for (int f = 0; f < F; f++)
@@ -1781,7 +1792,7 @@ static int sift_setup(vo_ctx* ctx, SiftState& S, int h, int w, const vo_sift_par
     sift_free(S);
     S.h = h; S.w = w; S.prm = *p; S.max_frames = max_frames; S.kp_cap = kp_cap; S.raw_cap = raw_cap; S.cand_cap = cand_cap; S.surv_cap = surv_cap;
     S.fb = fb; S.with_operands = with_operands; S.cap_x = desc_x_rows(kp_cap);
-    S.fstride = align_up(w, 4);
+    S.fstride = w;                                             // dense rows: a batch of frames is one transfer (k_sb_base reads bytes)
     const int L = p->n_octave_layers;
     SiftGeom& P = S.P; memset(&P, 0, sizeof(P));
     P.nLayers = L;

@@ -25,7 +25,7 @@ def make_params(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, fir
 class OrbDetector:
     def __init__(self, nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, WTA_K=2,
                  scoreType=HARRIS_SCORE, patchSize=31, fastThreshold=20, ctx: _lib.Context | None = None,
-                 keypoint_order: str = "canonical"):
+                 keypoint_order: str = "cv2"):
         self.params = make_params(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType,
                                   patchSize, fastThreshold)
         self._ctx = ctx
@@ -103,8 +103,9 @@ class OrbDetector:
 
 
 def ORB_create(nfeatures=500, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, WTA_K=2,
-               scoreType=HARRIS_SCORE, patchSize=31, fastThreshold=20, keypoint_order="canonical") -> OrbDetector:
-    """cv2.ORB_create look-alike.  keypoint_order='cv2' returns the keypoints in cv2's own list order."""
+               scoreType=HARRIS_SCORE, patchSize=31, fastThreshold=20, keypoint_order="cv2") -> OrbDetector:
+    """cv2.ORB_create look-alike.  keypoint_order='cv2' (default) returns the keypoints in cv2's own list order (so keypoint and
+    match indices are cv2's); 'canonical' = (level, y, x) order, the same set, 0.36 ms per 257 frames cheaper."""
     return OrbDetector(nfeatures, scaleFactor, nlevels, edgeThreshold, firstLevel, WTA_K, scoreType, patchSize,
                        fastThreshold, keypoint_order=keypoint_order)
 

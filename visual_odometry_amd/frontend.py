@@ -18,7 +18,7 @@ MATCH_CROSSCHECK, MATCH_RATIO, MATCH_CROSSCHECK_LEGACY = 0, 1, 2
 
 class FrontEnd:
     def __init__(self, height, width, max_frames, max_pairs, nfeatures=500, nlevels=8, device=0, ctx=None,
-                 keypoint_order="canonical", detector="orb", kp_cap=0, **det_kw):
+                 keypoint_order="cv2", detector="orb", kp_cap=0, **det_kw):
         self.ctx = ctx or _lib.Context(device)
         self.h, self.w = int(height), int(width)
         self.max_frames, self.max_pairs = int(max_frames), int(max_pairs)
