@@ -970,20 +970,25 @@ __device__ void decompose_essential(const double* E, double* R1, double* R2, dou
 // image_pair.py:288-290), then the four (R, t) candidates are cheirality-tested on them: one workgroup per
 // pair, every thread triangulates its share of the points (4x4 Jacobi SVD per point and candidate), the
 // per-candidate counts are wavefront ballots + popcounts summed through LDS.
-__device__ __forceinline__ bool cheirality(const double* P0, const double* P, const double* a, const double* b, double dist)
+// recoverPose's test of one point for the candidates (R, t) [pos] and (R, -t) [neg] from ONE triangulation.  With P0 = [I | 0]
+// the DLT matrix of (R, -t) is the matrix of (R, t) with its fourth column negated; the one-sided Jacobi SVD (jacobi_svd above)
+// is sign-symmetric — a negated column only negates dot products, rotation sines / cosines and rows, never a magnitude — so
+// its null vector for (R, -t) is +-(Q0, Q1, Q2, -Q3) with the same bits, and so are the quotients and the depth sum below
+// (z' = -z exactly: every term changes sign).  An overall sign of Q cancels in every test.
+__device__ __forceinline__ void cheirality2(const double* P0, const double* P, const double* a, const double* b, double dist, bool& pos, bool& neg)
 {
     double Q[4];
     triangulate_one(P0, P, a[0], a[1], b[0], b[1], Q);
-    bool m = Q[2] * Q[3] > 0;
+    const double w = Q[2] * Q[3];
     const double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
-    m = m && (q2 < dist);
     const double z = P[8] * q0 + P[9] * q1 + P[10] * q2 + P[11] * q3;
-    return m && (z > 0) && (z < dist);
+    pos = w > 0 && q2 < dist && z > 0 && z < dist;
+    neg = w < 0 && -q2 < dist && -z > 0 && -z < dist;
 }
 
-// 1024 threads: the inlier compaction uses the first 256; then the four (R, t) candidates are tested in parallel, four
-// wavefronts each, so every SIMD holds four waves of independent f64 Jacobi sweeps instead of one (the kernel is
-// bound by the dependent-issue latency of those sweeps).
+// 1024 threads: the inlier compaction uses the first 256; then the two rotations are tested in parallel, eight wavefronts
+// each, every triangulation serving both signs of t, so every SIMD holds four waves of independent f64 Jacobi sweeps
+// (the kernel is bound by the dependent-issue latency of those sweeps).
 __global__ __launch_bounds__(1024) void k_pose(PairBuf pb, int kp_cap, RansacParams rp)
 {
     __shared__ int s_w[4];
@@ -1049,23 +1054,24 @@ __global__ __launch_bounds__(1024) void k_pose(PairBuf pb, int kp_cap, RansacPar
     for (int k = 0; k < 3; k++) tt[k] = s_dec[18 + k];
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     {
-        const int c = cand;                              // wave-uniform: four waves per candidate
-        const double* Rc = (c & 1) ? R2 : R1;
-        const double sgn = c >= 2 ? -1.0 : 1.0;
+        const int c = threadIdx.x >> 9, t512 = threadIdx.x & 511;        // wave-uniform: candidates c (R, t) and c + 2 (R, -t), R = R1 / R2
+        const double* Rc = c ? R2 : R1;
         double P[12];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
 #pragma unroll
             for (int k = 0; k < 3; k++) P[r * 4 + k] = Rc[r * 3 + k];
-            P[r * 4 + 3] = sgn * tt[r];
+            P[r * 4 + 3] = tt[r];
         }
-        int g = 0;
-        for (int b = 0; b < ninl; b += 256) {
-            const int i = b + tid;
-            const bool m = i < ninl && cheirality(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh);
-            g += __popcll(__ballot(m));
+        int gp = 0, gn = 0;
+        for (int b = 0; b < ninl; b += 512) {
+            const int i = b + t512;
+            bool mp = false, mn = false;
+            if (i < ninl) cheirality2(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh, mp, mn);
+            gp += __popcll(__ballot(mp)); gn += __popcll(__ballot(mn));
         }
-        if (lane == 0 && g) atomicAdd(&s_good[c], g);
+        if (lane == 0 && gp) atomicAdd(&s_good[c], gp);
+        if (lane == 0 && gn) atomicAdd(&s_good[c + 2], gn);
     }
     __syncthreads();
     const int g0 = s_good[0], g1 = s_good[1], g2 = s_good[2], g3 = s_good[3];
@@ -1074,18 +1080,21 @@ __global__ __launch_bounds__(1024) void k_pose(PairBuf pb, int kp_cap, RansacPar
     else if (g1 >= g0 && g1 >= g2 && g1 >= g3) best = 1;
     else if (g2 >= g0 && g2 >= g1 && g2 >= g3) best = 2;
     else best = 3;
-    if (pb.pose_mask) {      // single-call cv2.recoverPose mask: rebuild the winning candidate's test
+    if (pb.pose_mask) {      // single-call cv2.recoverPose mask: the winning candidate's test again
         const double* Rc = (best & 1) ? R2 : R1;
-        const double sgn = best >= 2 ? -1.0 : 1.0;
         double P[12];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
 #pragma unroll
             for (int k = 0; k < 3; k++) P[r * 4 + k] = Rc[r * 3 + k];
-            P[r * 4 + 3] = sgn * tt[r];
+            P[r * 4 + 3] = tt[r];
         }
         uint8_t* pm = pb.pose_mask + (size_t)p * kp_cap;
-        for (int i = threadIdx.x; i < ninl; i += 1024) pm[i] = cheirality(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh) ? 255 : 0;
+        for (int i = threadIdx.x; i < ninl; i += 1024) {
+            bool mp, mn;
+            cheirality2(P0, P, in1 + 2 * i, in2 + 2 * i, rp.dist_thresh, mp, mn);
+            pm[i] = (best >= 2 ? mn : mp) ? 255 : 0;
+        }
     }
     if (first && tid == 0) {
         const double* Rb = (best & 1) ? R2 : R1;
