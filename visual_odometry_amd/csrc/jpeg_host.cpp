@@ -82,6 +82,23 @@ static bool build_tables(const uint8_t* counts /*16*/, const uint8_t* vals, int 
         } else T->maxcode[slot][l] = -1;
         code <<= 1;
     }
+    // second level for the codes of 11 .. 16 bits: walk them in canonical order, one 64-entry table per 10-bit prefix
+    memset(T->sub[slot], 0, sizeof(T->sub[slot]));
+    {
+        int c2 = 0, k2 = 0, nsub = 0, last_prefix = -1;
+        for (int l = 1; l <= 16; l++) {
+            const int cnt = counts[l - 1];
+            for (int i = 0; i < cnt; i++, c2++, k2++) {
+                if (l <= JPG_LOOK) continue;
+                const int prefix = c2 >> (l - JPG_LOOK);
+                if (prefix != last_prefix) { last_prefix = prefix; nsub++; if (nsub <= JPG_LONG) lut[prefix] = (uint16_t)(0x8000u | (uint32_t)(nsub - 1)); }
+                if (nsub > JPG_LONG) continue;
+                const int low = (c2 << (16 - l)) & 63;                     // the code's bits 10 .. 15, left-aligned in 6 bits
+                for (int j = 0; j < (1 << (16 - l)); j++) T->sub[slot][nsub - 1][low + j] = (uint16_t)((l << 8) | vals[k2]);
+            }
+            c2 <<= 1;
+        }
+    }
     T->maxcode[slot][17] = 0x7fffffff; T->valoff[slot][17] = 0;
     T->maxcode[slot][0] = -1; T->valoff[slot][0] = 0;
     return k == nvals;

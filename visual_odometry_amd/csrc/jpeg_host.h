@@ -6,6 +6,7 @@
 
 #define JPG_NT 512               // threads of the two entropy kernels = subsequences per image
 #define JPG_LOOK 10              // bits of Huffman look-ahead table
+#define JPG_LONG 4                // long-code prefixes per table with a second-level table
 #define JPG_PAD 16               // zero bytes after every clean stream
 #define JPG_MAX_BPM 10           // blocks per MCU (T.81 limit)
 struct JpegImage {               // one file of a batch: geometry from the headers + where its data lives in the batch buffers
@@ -22,7 +23,13 @@ struct JpegImage {               // one file of a batch: geometry from the heade
 };
 struct JpegTables {
     uint16_t q[4][64];                           // quantisation tables, natural order
-    uint16_t lut[8][1 << JPG_LOOK];              // slots 0-3: DC tables, 4-7: AC tables; (code length << 8) | symbol, 0 = longer code
+    // slots 0-3: DC tables, 4-7: AC tables, indexed by the next JPG_LOOK bits of the stream: (code length << 8) | symbol for the
+    // codes that fit; 0x8000 | n for a prefix of longer codes that has second-level table n; 0 = longer code without one
+    uint16_t lut[8][1 << JPG_LOOK];
+    // codes longer than the look-ahead: the first JPG_LONG prefixes (of JPG_LOOK bits) that lead to such codes get a table over the
+    // next 6 bits ((code length << 8) | symbol, 0 = no such code).  A code book with more long prefixes than that leaves the
+    // rest at 0 (the canonical walk over the lengths, maxcode / valoff)
+    uint16_t sub[8][JPG_LONG][64];
     int32_t maxcode[8][18], valoff[8][18];
     uint8_t vals[8][256];
 };

@@ -140,42 +140,27 @@ struct JReader {
 
 struct JLocal {                                           // LDS copies of what the decoding loop reads per symbol
     uint16_t lut[8][1 << JPG_LOOK];
+    uint16_t sub[8][JPG_LONG][64];
     int32_t maxcode[8][18];
     int32_t valoff[8][18];
     uint8_t vals[8][256];
     uint8_t zigzag[64];
     uint8_t dc_slot[JPG_MAX_BPM], ac_slot[JPG_MAX_BPM];
+    unsigned long long slots;                            // 4 bits per block of the MCU: DC table | (AC table - 4) << 2
     int32_t bpm, ri, nrst, total_blocks;
     uint32_t clean_len;
 };
 
-__device__ __forceinline__ int jpg_symbol(JReader& r, const JLocal& T, int slot)
-{
-    const uint32_t top = (uint32_t)(r.buf >> 48);                         // next 16 bits
-    const uint32_t e = T.lut[slot][top >> (16 - JPG_LOOK)];
-    if (e) { r.skip((int)(e >> 8)); return (int)(e & 255u); }
-    int l = JPG_LOOK + 1;
-    while (l <= 16 && (int)(top >> (16 - l)) > T.maxcode[slot][l]) l++;
-    if (l > 16) { r.skip(17); return 0; }                                 // no such code (damaged data): libjpeg reads on to its sentinel length 17 and returns 0
-    const int sym = T.vals[slot][(T.valoff[slot][l] + (int)(top >> (16 - l))) & 255];
-    r.skip(l);
-    return sym;
-}
-
-__device__ __forceinline__ int jpg_value(JReader& r, int s)               // s value bits, sign-extended the JPEG way; s = 0 -> 0
-{
-    const int v = (int)((uint32_t)(r.buf >> 33) >> (31 - s));
-    r.skip(s);
-    return v < ((1 << s) >> 1) ? v - (1 << s) + 1 : v;
-}
-
 // Decodes symbols from state st until the bit position reaches `boundary` (or max_done blocks are complete).  Returns
 // the number of blocks completed; WRITE stores the coefficients of block blk, blk + 1, ... (DC as the raw difference).
-// DC and AC symbols take the same path (table, run and store position selected arithmetically): the 64 lanes of a
-// wavefront are at different places of their blocks.
-template <bool WRITE>
-__device__ __forceinline__ int jpg_span(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
-                                        JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done = 0x7fffffff)
+// The 64 lanes of a wavefront are at different places of their blocks, so the loop body is ONE path for DC and AC symbols,
+// end of block, zero runs and block ends, written with selects instead of branches: a wavefront with two resident waves
+// per SIMD pays ~20 cycles for every compare -> exec mask -> branch chain (283 k instructions per wave at 21 cycles each
+// with the branchy form).  Branches remain only around memory instructions and for the rare long codes; HAS_RST compiles the
+// restart-interval handling out for the files that have none.
+template <bool WRITE, bool HAS_RST>
+__device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
+                                          JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done)
 {
     JReader r; r.p = clean; r.limit = T.clean_len + JPG_PAD;
     if (st.bit >= boundary) return 0;
@@ -184,18 +169,18 @@ __device__ __forceinline__ int jpg_span(const JLocal& T, const uint8_t* clean, c
     // the first restart position after the start (positions are clean-stream byte offsets)
     uint32_t ri_next = 0xffffffffu; int rj = 0;
     const int nrst = T.nrst, bpm = T.bpm;
-    if (T.ri && nrst) {
+    if (HAS_RST) {
         int lo = 0, hi = nrst;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (rst[mid] * 8u > st.bit) hi = mid; else lo = mid + 1; }
         rj = lo; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
     }
     const uint32_t total = (uint32_t)T.total_blocks;
+    const unsigned long long slots = T.slots;
     uint32_t pos = st.bit;
-    int slot_dc = T.dc_slot[b], slot_ac = T.ac_slot[b];     // table slots of the current block's component
     while (pos < boundary && done < max_done) {
         r.refill();
         const bool dc = k == 0;
-        if (dc && b == 0 && pos + 8 > ri_next) {
+        if (HAS_RST && dc && b == 0 && pos + 8 > ri_next) {
             // an MCU boundary inside the last byte before a restart: the rest of the byte is padding (all ones —
             // no Huffman code is all ones, so a real MCU cannot start like that)
             const int rem = (int)(ri_next - pos);
@@ -205,24 +190,51 @@ __device__ __forceinline__ int jpg_span(const JLocal& T, const uint8_t* clean, c
                 continue;
             }
         }
-        const int sym = jpg_symbol(r, T, dc ? slot_dc : slot_ac);
-        const int s = sym & 15, run = dc ? 0 : sym >> 4;
-        const int v = jpg_value(r, s);
-        if (!dc && s == 0) k = run == 15 ? k + 16 : 64;     // ZRL / end of block
-        else {
-            k += run;
-            if (WRITE && k < 64 && blk + done < total) coef[(size_t)(blk + done) * 64 + T.zigzag[k]] = (int16_t)v;
-            k++;
+        const uint32_t sl = (uint32_t)(slots >> (4 * b));
+        const int slot = dc ? (int)(sl & 3u) : 4 + (int)((sl >> 2) & 3u);
+        const uint32_t e = T.lut[slot][(uint32_t)(r.buf >> (64 - JPG_LOOK))];
+        int l = (int)(e >> 8), sym = (int)(e & 255u);
+        if ((e & 0x8000u) || e == 0u) {                   // a code of 11 .. 16 bits: second-level table, or the canonical walk
+            const uint32_t e2 = e ? T.sub[slot][e & (JPG_LONG - 1)][(uint32_t)(r.buf >> 48) & 63u] : 0u;
+            if (e2) { l = (int)(e2 >> 8); sym = (int)(e2 & 255u); }
+            else {
+                const uint32_t top = (uint32_t)(r.buf >> 48);
+                l = JPG_LOOK + 1;
+                while (l <= 16 && (int)(top >> (16 - l)) > T.maxcode[slot][l]) l++;
+                if (l > 16) { l = 17; sym = 0; }          // no such code (damaged data): libjpeg reads on to its sentinel length 17 and returns 0
+                else sym = T.vals[slot][(T.valoff[slot][l] + (int)(top >> (16 - l))) & 255];
+            }
         }
-        if (k >= 64) { k = 0; b = b + 1 == bpm ? 0 : b + 1; done++; slot_dc = T.dc_slot[b]; slot_ac = T.ac_slot[b]; }
+        const int sz = sym & 15, run = dc ? 0 : sym >> 4;
+        // the sz value bits behind the code, sign-extended the JPEG way (sz = 0 -> 0)
+        const uint32_t after = (uint32_t)((r.buf << l) >> 32);
+        const int vb = (int)((after >> 1) >> (31 - sz));
+        const int v = vb < ((1 << sz) >> 1) ? vb - (1 << sz) + 1 : vb;
+        r.skip(l + sz);
+        const bool coefficient = dc || sz != 0;           // else ZRL (16 zeros) or end of block
+        const int adv = coefficient ? run + 1 : run == 15 ? 16 : 64;
+        k += adv;
+        if (WRITE && coefficient && k <= 64 && blk + done < total) coef[(size_t)(blk + done) * 64 + T.zigzag[k - 1]] = (int16_t)v;
+        const bool end = k >= 64;
+        k = end ? 0 : k;
+        b = end ? (b + 1 == bpm ? 0 : b + 1) : b;
+        done += end ? 1 : 0;
         pos = r.pos();
-        if (pos > ri_next) {                              // ran across a restart boundary: only a mis-synchronised thread does
-            r.seek(ri_next); pos = ri_next; b = 0; k = 0; slot_dc = T.dc_slot[0]; slot_ac = T.ac_slot[0];
+        if (HAS_RST && pos > ri_next) {                   // ran across a restart boundary: only a mis-synchronised thread does
+            r.seek(ri_next); pos = ri_next; b = 0; k = 0;
             rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
         }
     }
     st.bit = pos; st.bk = ((uint32_t)b << 8) | (uint32_t)k;
     return done;
+}
+
+template <bool WRITE>
+__device__ __forceinline__ int jpg_span(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
+                                        JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done = 0x7fffffff)
+{
+    if (T.ri && T.nrst) return jpg_span_t<WRITE, true>(T, clean, rst, st, boundary, coef, blk, max_done);
+    return jpg_span_t<WRITE, false>(T, clean, rst, st, boundary, coef, blk, max_done);
 }
 
 __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const JpegTables* tabs, const uint8_t* clean_all,
@@ -237,11 +249,17 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     const JpegImage& im = imgs[blockIdx.x];
     const JpegTables& G = tabs[blockIdx.x];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 8 * (1 << JPG_LOOK); i += JPG_NT) (&T.lut[0][0])[i] = (&G.lut[0][0])[i];
+    for (int i = tid; i < 8 * (1 << JPG_LOOK) / 2; i += JPG_NT) ((uint32_t*)&T.lut[0][0])[i] = ((const uint32_t*)&G.lut[0][0])[i];
+    for (int i = tid; i < 8 * JPG_LONG * 64 / 2; i += JPG_NT) ((uint32_t*)&T.sub[0][0][0])[i] = ((const uint32_t*)&G.sub[0][0][0])[i];
     for (int i = tid; i < 8 * 18; i += JPG_NT) { (&T.maxcode[0][0])[i] = (&G.maxcode[0][0])[i]; (&T.valoff[0][0])[i] = (&G.valoff[0][0])[i]; }
     for (int i = tid; i < 8 * 256; i += JPG_NT) (&T.vals[0][0])[i] = (&G.vals[0][0])[i];
     if (tid < 64) T.zigzag[tid] = d_zigzag[tid];
     if (tid < JPG_MAX_BPM) { const int c = im.blk_comp[tid]; T.dc_slot[tid] = (uint8_t)im.td[c]; T.ac_slot[tid] = (uint8_t)(4 + im.ta[c]); }
+    if (tid == 0) {
+        unsigned long long sl = 0;
+        for (int j = 0; j < JPG_MAX_BPM; j++) { const int c = im.blk_comp[j < im.bpm ? j : 0]; sl |= (unsigned long long)((im.td[c] & 3) | ((im.ta[c] & 3) << 2)) << (4 * j); }
+        T.slots = sl;
+    }
     if (tid == 0) { T.bpm = im.bpm; T.ri = im.ri; T.nrst = (int)im.nrst; T.total_blocks = im.total_blocks; T.clean_len = im.clean_len; }
     const int bpm = im.bpm, ri = im.ri, total_blocks = im.total_blocks, mcus_all = im.mx * im.my;
     uint8_t comp_of[JPG_MAX_BPM];
@@ -265,7 +283,10 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     // 2. propagate end states until they are stable: thread i restarts from thread i-1's end state
     JState used; used.bit = 0xffffffffu; used.bk = 0xffffffffu;      // the start state the current result was computed from
     if (tid == 0) { used.bit = 0; used.bk = 0; }
-    for (int round = 0; round < JPG_NT; round++) {
+#ifndef JPG_DBG_ROUNDS
+#define JPG_DBG_ROUNDS JPG_NT
+#endif
+    for (int round = 0; round < JPG_DBG_ROUNDS; round++) {
         JState prev; prev.bit = 0; prev.bk = 0;
         if (tid > 0) prev = s_st[tid - 1];
         const bool redo = live && tid > 0 && (prev.bit != used.bit || prev.bk != used.bk);
