@@ -89,22 +89,18 @@ def test_pyramid_and_blur_tiny_and_thin_images(oracle, ctx, h, w, nl):
         assert np.array_equal(got_f[l], oracle.fast_score_nms(lvl, 20)), (l, sizes[l])
 
 
-def test_staged_kernels_equal_direct_ones(oracle, ctx, monkeypatch):
-    """The LDS-staged pyramid / blur kernels stay in the library as fallbacks (VO_RESIZE_STRIP=1, VO_BLUR_DIRECT=0 and
-    levels under 16 x 8 pixels): same bytes as the direct (no-LDS) kernels that run by default."""
-    from visual_odometry_amd import _lib
-    img = random_image(9, 300, 517)
-    p = oracle.orb_params(nfeatures=500)
-    sizes = _level_sizes(oracle, 300, 517, p)
-    ref_p = _det().stage_levels("vo_stage_pyramid", img, sizes)
-    ref_b = _det().stage_levels("vo_stage_blur", img, sizes)
-    monkeypatch.setenv("VO_RESIZE_STRIP", "1"); monkeypatch.setenv("VO_BLUR_DIRECT", "0")
-    det = _det(ctx=_lib.Context(0))                               # a fresh context: the resize tables are built at configuration
-    got_p, got_b = det.stage_levels("vo_stage_pyramid", img, sizes), det.stage_levels("vo_stage_blur", img, sizes)
-    for l in range(len(sizes)):
-        assert np.array_equal(got_p[l], ref_p[l]) and np.array_equal(got_b[l], ref_b[l]), l
-    for l, lvl in enumerate(oracle.pyramid(img, p)):
-        assert np.array_equal(got_p[l], lvl) and np.array_equal(got_b[l], oracle.gaussian_blur7(lvl)), l
+def test_fallback_kernels_equal_the_oracle(oracle, ctx):
+    """The two fallbacks chosen at configuration time — the generic pyramid kernel (scale factors above 1.27, where the
+    direct kernel's window assumptions fail) and the LDS-tiled blur (pyramids with a level under 16 x 8 pixels) — against the
+    oracle; the direct kernels that run by default are covered by every other test of this file."""
+    for (h, w), kw in (((300, 517), dict(scaleFactor=1.5, nlevels=5)), ((120, 200), dict(scaleFactor=1.2, nlevels=16))):   # generic resize; 7 x 13 top level -> tiled blur
+        img = random_image(9, h, w)
+        p = oracle.orb_params(nfeatures=500, **{("scale_factor" if k == "scaleFactor" else k): v for k, v in kw.items()})
+        sizes = _level_sizes(oracle, h, w, p)
+        det = _det(**kw)
+        got_p, got_b = det.stage_levels("vo_stage_pyramid", img, sizes), det.stage_levels("vo_stage_blur", img, sizes)
+        for l, lvl in enumerate(oracle.pyramid(img, p)):
+            assert np.array_equal(got_p[l], lvl) and np.array_equal(got_b[l], oracle.gaussian_blur7(lvl)), (kw, l)
 
 
 @pytest.mark.parametrize("nfeatures,nlevels,h,w,seed", [(500, 8, 480, 640, 5), (2000, 8, 720, 1280, 6),

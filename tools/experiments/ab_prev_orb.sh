@@ -7,7 +7,7 @@ tags=""
 for f in orb_kernels_*.hip; do
   t=${f#orb_kernels_}; t=${t%.hip}; tags="$tags $t"
   hipcc -O3 -fPIC -std=c++17 -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function -c $f -o /tmp/orb_$t.o || exit 1
-  hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/libvo_$t.so vo_api.o /tmp/orb_$t.o match_kernels.o geom_kernels.o pnp_kernels.o cv2order_kernels.o gather_rccl.o jpeg_kernels.o sift_kernels.o -ldl
+  hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/libvo_$t.so vo_api.o /tmp/orb_$t.o match_kernels.o geom_kernels.o pnp_kernels.o cv2order_kernels.o gather_rccl.o jpeg_kernels.o sift_batch.o jpeg_host.o -ldl
 done
 cd $R
 for i in 1 2 3; do

@@ -1,6 +1,6 @@
 """Upload + three detections of N frames: a small target for rocprofv3 --pmc runs on single kernels."""
 import numpy as np, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from visual_odometry_amd import synth
 from visual_odometry_amd.frontend import FrontEnd
 seq = synth.sequence(17, 1280, 720, cache_dir="/tmp")

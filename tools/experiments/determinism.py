@@ -2,7 +2,7 @@
 reports which stage differs if not (features / matches).  The test-suite version is
 tests/test_gpu_pipeline.py::test_overlapped_contexts_are_deterministic."""
 import numpy as np, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from visual_odometry_amd import synth
 from visual_odometry_amd.frontend import FrontEnd
 C = 128

@@ -2,12 +2,12 @@
 # Diagnostic (GPU box): k_fast with other tile heights / queue capacities (LDS per wave decides the waves per SIMD).  Every
 # object is rebuilt with the same macros (the host geometry uses FAST_TH); each variant gets its own library copy.
 #   tools/fast_tile_variants.sh "TH QCAP" "TH QCAP" ...      (TH <= 30: the queue entries hold the row in 5 bits)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R/visual_odometry_amd/csrc
 for v in "$@"; do
   set -- $v; th=$1; qc=$2
   D=/tmp/ftv_${th}_${qc}; mkdir -p $D
-  for f in vo_api orb_kernels match_kernels geom_kernels pnp_kernels cv2order_kernels gather_rccl jpeg_kernels sift_kernels; do
+  for f in vo_api orb_kernels match_kernels geom_kernels pnp_kernels cv2order_kernels gather_rccl jpeg_kernels sift_batch jpeg_host; do
     hipcc -O3 -fPIC -std=c++17 -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function -DFAST_TH=$th -DFT_QCAP=$qc -c $f.hip -o $D/$f.o 2>/dev/null || { echo "build failed: $f TH=$th QCAP=$qc"; continue 2; } &
   done; wait
   hipcc -shared -fPIC --offload-arch=gfx950 -o $D/libvo.so $D/*.o -ldl || continue

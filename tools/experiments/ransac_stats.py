@@ -1,6 +1,6 @@
 """RANSAC iteration counts / matches / inliers of 16 consecutive pairs of the bench sequence."""
 import numpy as np, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from visual_odometry_amd import synth
 from visual_odometry_amd.frontend import FrontEnd
 seq = synth.sequence(17, 1280, 720, cache_dir="/tmp")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: SIFT tests, bench line and the rocprofv3 kernel summary of the same bench -> gpurun_out/sift/
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/sift
 rm -rf $O; mkdir -p $O
 cd $R

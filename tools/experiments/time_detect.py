@@ -1,6 +1,6 @@
 """Per-stage HIP-event times of the detection chain alone (257 frames 1280x720, 2000 features), three repeats."""
 import numpy as np, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from visual_odometry_amd import synth
 from visual_odometry_amd.frontend import FrontEnd
 seq = synth.sequence(17, 1280, 720, cache_dir="/tmp")

@@ -147,182 +147,6 @@ __global__ void k_resize(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom
     *(uint32_t*)(dp + (size_t)dy * dst.stride + dx0) = out;
 }
 
-// Tiled version for scale factors up to 4/3 (tab.tiled): a RS_TW x RS_TH destination tile per workgroup (vo_internal.h).
-// The source rows/columns the tile needs are staged in LDS with 16-byte loads; horizontal pass: one lane =
-// 4 destination pixels, their 4+4 source bytes are picked out of a 12-byte window with two v_perm_b32
-// (selector built once per lane from the offset table) and blended in 8.8 fixed point; the 16-bit row
-// results stay in LDS; vertical pass blends two of them per destination row (16.16, round half up).
-// Edge replication needs no special case: the tables hold (offset 0 / last, weight 0) there.
-
-__global__ __launch_bounds__(256) void k_resize_tiled(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom dst, ResizeTab tab)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_LH * RS_LW];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[RS_LH * RS_TW];
-    const int f = blockIdx.z, tid = threadIdx.x;
-    const int tiles_x = (dst.w + RS_TW - 1) / RS_TW;
-    const int bid = xcd_tile(blockIdx.x, gridDim.x);
-    const int x0 = (bid % tiles_x) * RS_TW, y0 = (bid / tiles_x) * RS_TH;
-    const int x_last = min(x0 + RS_TW, dst.w) - 1, y_last = min(y0 + RS_TH, dst.h) - 1;
-    const int sx0 = tab.xofs[x0] & ~15, sy0 = tab.yofs[y0];
-    const int nrows = min(tab.yofs[y_last] + 2 - sy0, RS_LH);
-    const int ncol16 = min((tab.xofs[x_last] + 2 - sx0 + 15) >> 4, RS_LW / 16);
-    const uint8_t* sp = pyr + (size_t)f * frame_bytes + src.off;
-    // all of a lane's 16-byte loads are issued before the first one is consumed (the kernel is bound by the latency
-    // of this staging step, not by its arithmetic)
-    constexpr int RS_NCH = RS_LW / 16, RS_RPS = 256 / RS_NCH, RS_NLD = (RS_LH + RS_RPS - 1) / RS_RPS;   // 12 chunks, 21 rows per step
-    const int sc = tid % RS_NCH, sr = tid / RS_NCH;
-    const bool s_ok = tid < RS_RPS * RS_NCH && sc < ncol16 && sx0 + 16 * sc + 16 <= src.stride;
-    const uint8_t* sbase = sp + min(sx0 + 16 * sc, src.stride - 16);
-    uint4 sv[RS_NLD];
-#pragma unroll
-    for (int k = 0; k < RS_NLD; k++) {
-        const int gy = sy0 + min(sr + RS_RPS * k, nrows - 1);          // rows the tile does not need re-read a needed one
-        const uint4 v = *(const uint4*)(sbase + (size_t)min(gy, src.h - 1) * src.stride);
-        sv[k] = s_ok && gy < src.h ? v : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < RS_NLD; k++)
-        if (tid < RS_RPS * RS_NCH && sr + RS_RPS * k < nrows) *(uint4*)(s_src + (sr + RS_RPS * k) * RS_LW + 16 * sc) = sv[k];
-    const int dxg = tid & 31, rl = tid >> 5, dx = x0 + 4 * dxg;
-    int o[4], c1[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const int xi = min(dx + i, dst.w - 1); o[i] = tab.xofs[xi] - sx0; c1[i] = tab.xc1[xi]; }
-    const int base = o[0] & ~3;
-    const uint32_t sel = (uint32_t)(o[0] - base) | ((uint32_t)(o[1] - base) << 8) | ((uint32_t)(o[2] - base) << 16) | ((uint32_t)(o[3] - base) << 24);
-    const uint32_t c1e = (uint32_t)c1[0] | ((uint32_t)c1[2] << 16), c1o = (uint32_t)c1[1] | ((uint32_t)c1[3] << 16);
-    __syncthreads();
-    // horizontal pass, two pixels per packed 16-bit operation: h = (a << 8) + c1 * (b - a) = (256 - c1) * a + c1 * b is
-    // at most 65280, so the low 16 bits of the packed multiply-add are the exact value.  Stored as (h0, h2), (h1, h3).
-    for (int r = rl; r < nrows; r += 8) {
-        const uint32_t* wp = (const uint32_t*)(s_src + r * RS_LW + base);
-        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-        const uint32_t lo = __builtin_amdgcn_perm(w1, w0, sel);
-        const uint32_t hi = __builtin_amdgcn_perm(__builtin_amdgcn_alignbyte(w2, w1, 1), __builtin_amdgcn_alignbyte(w1, w0, 1), sel);
-        const uint32_t a_e = lo & 0x00ff00ffu, a_o = (lo >> 8) & 0x00ff00ffu;
-        const uint32_t b_e = hi & 0x00ff00ffu, b_o = (hi >> 8) & 0x00ff00ffu;
-        const vo_u16x2 h_e = __builtin_bit_cast(vo_u16x2, c1e) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_e, a_e)) + __builtin_bit_cast(vo_u16x2, a_e << 8);
-        const vo_u16x2 h_o = __builtin_bit_cast(vo_u16x2, c1o) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_o, a_o)) + __builtin_bit_cast(vo_u16x2, a_o << 8);
-        *(uint2*)(s_h + r * RS_TW + 4 * dxg) = make_uint2(__builtin_bit_cast(uint32_t, h_e), __builtin_bit_cast(uint32_t, h_o));
-    }
-    __syncthreads();
-    // vertical pass: (upper row, lower row) of a pixel paired by v_perm_b32, blended by one v_dot2_u32_u16 (16.16, + 1/2)
-    uint8_t* dp = pyr + (size_t)f * frame_bytes + dst.off;
-    for (int rr = rl; rr < RS_TH; rr += 8) {
-        const int dy = y0 + rr;
-        if (dy >= dst.h) break;
-        const int r0 = tab.yofs[dy] - sy0;
-        const uint32_t w1 = tab.yc1[dy], wq = (256u - w1) | (w1 << 16);
-        const uint2 a = *(const uint2*)(s_h + r0 * RS_TW + 4 * dxg), b = *(const uint2*)(s_h + (r0 + 1) * RS_TW + 4 * dxg);
-        const vo_u16x2 wv = __builtin_bit_cast(vo_u16x2, wq);
-        const uint32_t v0 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.x, a.x, 0x05040100u)), wv, 32768u, false) >> 16;
-        const uint32_t v2 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.x, a.x, 0x07060302u)), wv, 32768u, false) >> 16;
-        const uint32_t v1 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.y, a.y, 0x05040100u)), wv, 32768u, false) >> 16;
-        const uint32_t v3 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(b.y, a.y, 0x07060302u)), wv, 32768u, false) >> 16;
-        if (dx < dst.stride)
-            *(uint32_t*)(dp + (size_t)dy * dst.stride + dx) = min(v0, 255u) | (min(v1, 255u) << 8) | (min(v2, 255u) << 16) | (min(v3, 255u) << 24);
-    }
-}
-
-// Strip version (tab.strip: scale factors up to 1.27, i.e. ORB's 1.2): the same arithmetic with the 16-bit row results
-// kept in REGISTERS.  A lane owns 4 destination columns and sweeps the source rows of its wavefront's 16 destination
-// rows from top to bottom: horizontal pass of source row r (its 8-byte window out of LDS, four v_perm_b32 with
-// per-lane selectors, packed 8.8 blend), and whenever r is the lower row of the next destination row, the vertical
-// 16.16 blend of the previous and the current row results and one coalesced dword store.  No second pass over an
-// LDS image of the row results, no per-row index arithmetic (row offsets and weights are wave-uniform scalars): about
-// 8 vector instructions per destination pixel instead of 20.
-__global__ __launch_bounds__(RS2_THREADS) void k_resize_strip(uint8_t* pyr, int frame_bytes, LevelGeom src, LevelGeom dst, ResizeTab tab)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS2_LH * RS2_LW];
-    const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (dst.w + RS2_WW - 1) / RS2_WW;
-    const int bid = xcd_tile(blockIdx.x, gridDim.x);
-    const int tx = bid % tiles_x, ty = bid / tiles_x;
-    const int x0 = tx * RS2_WW, y0 = ty * RS2_TH;
-    // window origin and height come with the kernel arguments (scalar, no table load in front of the staging loads)
-    const int sx0 = tab.strip_sx0[tx], sy0 = tab.strip_sy0[ty], nrows = tab.strip_rows[ty];
-    const uint8_t* sp = pyr + (size_t)f * frame_bytes + src.off;
-    // every global load of the workgroup is issued up front: the lane's column table entries, the wavefront's first row
-    // schedule entries, then the staging loads
-    const int dx = x0 + 4 * lane;
-    int o[4], c1[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const int xi = min(dx + i, dst.w - 1); o[i] = tab.xofs[xi] - sx0; c1[i] = tab.xc1[xi]; }
-    const int dy0 = y0 + wave * RS2_WH, dy1 = min(dy0 + RS2_WH, dst.h);
-    const int dyc = min(dy0, dst.h - 1);
-    const int yo_first = tab.yofs[dyc], yo_last = tab.yofs[max(dy1 - 1, dyc)];
-    const uint32_t wy_first = tab.yc1[dyc];
-    {   // stage the source window: every 16-byte load of a lane is in flight before the first is consumed
-        constexpr int NCH = RS2_LW / 16, RPS = RS2_THREADS / NCH, NLD = (RS2_LH + RPS - 1) / RPS;
-        const int sc = tid % NCH, sr = tid / NCH;
-        const bool s_ok = tid < RPS * NCH && sx0 + 16 * sc + 16 <= src.stride;
-        const uint8_t* sbase = sp + min(sx0 + 16 * sc, src.stride - 16);
-        uint4 sv[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int gy = sy0 + min(sr + RPS * k, nrows - 1);
-            const uint4 v = *(const uint4*)(sbase + (size_t)min(gy, src.h - 1) * src.stride);
-            sv[k] = s_ok ? v : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < NLD; k++)
-            if (tid < RPS * NCH && sr + RPS * k < nrows) *(uint4*)(s_src + (sr + RPS * k) * RS2_LW + 16 * sc) = sv[k];
-    }
-    // per-lane column constants: window start, byte shift, selectors of the 4 + 4 source bytes, 8.8 weights
-    const int base = o[0] & ~3, sh = o[0] - base;
-    const uint32_t q1 = (uint32_t)(o[1] - o[0]), q2 = (uint32_t)(o[2] - o[0]), q3 = (uint32_t)(o[3] - o[0]);
-    const uint32_t sel_ae = 0x0c000c00u | (q2 << 16), sel_ao = 0x0c000c00u | q1 | (q3 << 16);
-    const uint32_t sel_be = sel_ae + 0x00010001u, sel_bo = sel_ao + 0x00010001u;
-    const uint32_t c1e = (uint32_t)c1[0] | ((uint32_t)c1[2] << 16), c1o = (uint32_t)c1[1] | ((uint32_t)c1[3] << 16);
-    __syncthreads();
-    if (dy0 >= dst.h) return;
-    // this wavefront's destination rows and the source rows they span (wave-uniform)
-    const int r_first = __builtin_amdgcn_readfirstlane(yo_first) - sy0, r_end = min(__builtin_amdgcn_readfirstlane(yo_last) + 2 - sy0, nrows);
-    uint8_t* dp = pyr + (size_t)f * frame_bytes + dst.off;
-    const uint8_t* wp = s_src + r_first * RS2_LW + base;
-    uint8_t* out = dp + (size_t)dy0 * dst.stride + dx;
-    const bool col_ok = dx < dst.stride;
-    // row schedule: destination row dy is emitted at source row yofs[dy] + 1 with the weight pair of yc1[dy];
-    // wave-uniform, fetched one destination row ahead of its use
-    int dy = dy0;
-    int e_at = r_first + 1;
-    uint32_t wy = (uint32_t)__builtin_amdgcn_readfirstlane((int)wy_first);
-    int e_next = dy + 1 < dy1 ? __builtin_amdgcn_readfirstlane(tab.yofs[dy + 1]) - sy0 + 1 : -1;
-    uint32_t wy_next = dy + 1 < dy1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tab.yc1[dy + 1]) : 0u;
-    uint32_t pe = 0, po = 0;                                // row results of the previous source row: (h0, h2), (h1, h3)
-    uint32_t n0 = ((const uint32_t*)wp)[0], n1 = ((const uint32_t*)wp)[1], n2 = ((const uint32_t*)wp)[2];
-    for (int r = r_first; r < r_end; r++) {
-        const uint32_t w0 = n0, w1 = n1, w2 = n2;
-        wp += RS2_LW;                                       // the next row's window is requested before this row is worked on
-        if (r + 1 < r_end) { n0 = ((const uint32_t*)wp)[0]; n1 = ((const uint32_t*)wp)[1]; n2 = ((const uint32_t*)wp)[2]; }
-        const uint32_t x0w = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)sh), x1w = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)sh);
-        const uint32_t a_e = __builtin_amdgcn_perm(x1w, x0w, sel_ae), a_o = __builtin_amdgcn_perm(x1w, x0w, sel_ao);
-        const uint32_t b_e = __builtin_amdgcn_perm(x1w, x0w, sel_be), b_o = __builtin_amdgcn_perm(x1w, x0w, sel_bo);
-        // h = (a << 8) + c1 * (b - a) = (256 - c1) * a + c1 * b <= 65280: exact in the low 16 bits of the packed multiply-add
-        const vo_u16x2 h_e = __builtin_bit_cast(vo_u16x2, c1e) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_e, a_e)) + __builtin_bit_cast(vo_u16x2, a_e << 8);
-        const vo_u16x2 h_o = __builtin_bit_cast(vo_u16x2, c1o) * __builtin_bit_cast(vo_u16x2, pk_sub16(b_o, a_o)) + __builtin_bit_cast(vo_u16x2, a_o << 8);
-        const uint32_t ce = __builtin_bit_cast(uint32_t, h_e), co = __builtin_bit_cast(uint32_t, h_o);
-        if (r == e_at) {                                    // scalar branch: r is the lower source row of destination row dy
-            const vo_u16x2 wv = __builtin_bit_cast(vo_u16x2, (256u - wy) | (wy << 16));
-            const uint32_t d0 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x05040100u)), wv, 32768u, false);
-            const uint32_t d2 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(ce, pe, 0x07060302u)), wv, 32768u, false);
-            const uint32_t d1 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x05040100u)), wv, 32768u, false);
-            const uint32_t d3 = __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, __builtin_amdgcn_perm(co, po, 0x07060302u)), wv, 32768u, false);
-            // (sum + 2^15) >> 16 is byte 2 of each dot product (at most 255: no saturation needed)
-            const uint32_t t01 = __builtin_amdgcn_perm(d1, d0, 0x0c0c0602u), t23 = __builtin_amdgcn_perm(d3, d2, 0x0c0c0602u);
-            if (col_ok) *(uint32_t*)out = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
-            out += dst.stride;
-            dy++;
-            e_at = e_next; wy = wy_next;
-            const int dn = min(dy + 1, dy1 - 1);
-            e_next = dy + 1 < dy1 ? __builtin_amdgcn_readfirstlane(tab.yofs[dn]) - sy0 + 1 : -1;
-            wy_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab.yc1[dn]);
-        }
-        pe = ce; po = co;
-    }
-}
-
-// f(integral_constant<int, I>) for I = 0, 1, ... while I < n (n <= N, wave-uniform): nested ifs, every index a compile-time
-// constant inside f (`#pragma unroll` gives up on a loop with a run-time trip count and an early exit)
 template <int I, int N, typename F>
 __device__ __forceinline__ void unroll_while(int n, F& f)
 {
@@ -433,19 +257,9 @@ __global__ __launch_bounds__(RS2_THREADS) void k_resize_direct(uint8_t* pyr, int
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F)
 {
     const LevelGeom& d = g.lv[level];
-    if (tab.strip == 2) {
+    if (tab.direct) {                                      // decided when the tables were built (vo_batch_configure)
         dim3 grid(((d.w + RS2_WW - 1) / RS2_WW) * ((d.h + RS2_TH - 1) / RS2_TH), 1, F);
         hipLaunchKernelGGL(k_resize_direct, grid, dim3(RS2_THREADS), 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
-        return;
-    }
-    if (tab.strip) {
-        dim3 grid(((d.w + RS2_WW - 1) / RS2_WW) * ((d.h + RS2_TH - 1) / RS2_TH), 1, F);
-        hipLaunchKernelGGL(k_resize_strip, grid, dim3(RS2_THREADS), 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
-        return;
-    }
-    if (tab.tiled) {
-        dim3 grid(((d.w + RS_TW - 1) / RS_TW) * ((d.h + RS_TH - 1) / RS_TH), 1, F);
-        hipLaunchKernelGGL(k_resize_tiled, grid, dim3(256), 0, s, pyr, g.frame_bytes, g.lv[level - 1], d, tab);
         return;
     }
     dim3 block(64, 4), grid((d.stride / 4 + 63) / 64, (d.h + 3) / 4, F);
@@ -1640,8 +1454,7 @@ __global__ __launch_bounds__(256) void k_blur_direct(const uint8_t* pyr, uint8_t
 
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F)
 {
-    const char* ev = getenv("VO_BLUR_DIRECT");             // read per launch (tests switch it inside one process)
-    bool direct = !(ev && ev[0] == '0');
+    bool direct = true;                                    // the LDS-tiled kernel only for pyramids with a level under 16 x 8 pixels
     int total = 0;
     for (int l = 0; l < g.nlevels; l++) {
         direct = direct && g.lv[l].w >= 16 && g.lv[l].h >= 8;

@@ -453,33 +453,16 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
         t.xofs = d_ofs + oi; t.xc1 = d_c + oi; oi += d.w;
         build_lin_tab(s.h, d.h, &hofs[oi], &hc[oi], &t.min_y, &t.max_y);
         t.yofs = d_ofs + oi; t.yc1 = d_c + oi; oi += d.h;
-        // does every RS_TW x RS_TH destination tile fit the tiled kernel's LDS window (RS_LW x RS_LH source bytes,
-        // 4 destination pixels within 8 source bytes)?
+        // k_resize_direct's assumptions (they hold for scale factors <= 1.27, ORB's 1.2 included): 4 destination pixels read
+        // within an 8-byte source window starting at the first one's tap; every source row is the lower row of at most one
+        // destination row; the 16 destination rows of a wavefront span at most 23 source rows.  Otherwise: the generic k_resize.
         {
             const int* xo = &hofs[oi - d.h - d.w]; const int* yo = &hofs[oi - d.h];
             bool ok = true;
             for (int x = 0; x + 3 < d.w && ok; x++) ok = xo[x + 3] - xo[x] <= 4;
-            for (int x0 = 0; x0 < d.w && ok; x0 += RS_TW) { const int xl = (x0 + RS_TW < d.w ? x0 + RS_TW : d.w) - 1; ok = xo[xl] + 2 - (xo[x0] & ~15) <= RS_LW - 12; }
-            for (int y0 = 0; y0 < d.h && ok; y0 += RS_TH) { const int yl = (y0 + RS_TH < d.h ? y0 + RS_TH : d.h) - 1; ok = yo[yl] + 2 - yo[y0] <= RS_LH; }
-            t.tiled = ok ? 1 : 0;
-            // ... and k_resize_strip's: 256 x 64 tiles, 4 destination pixels within an 8-byte window starting at the first one
-            bool ok2 = true;
-            for (int x = 0; x + 3 < d.w && ok2; x++) ok2 = xo[x + 3] - xo[x] <= 4;
-            for (int x0 = 0; x0 < d.w && ok2; x0 += RS2_WW) { const int xl = (x0 + RS2_WW < d.w ? x0 + RS2_WW : d.w) - 1; ok2 = xo[xl] + 2 - (xo[x0] & ~15) <= RS2_LW - 12; }
-            for (int y0 = 0; y0 < d.h && ok2; y0 += RS2_TH) { const int yl = (y0 + RS2_TH < d.h ? y0 + RS2_TH : d.h) - 1; ok2 = yo[yl] + 2 - yo[y0] <= RS2_LH; }
-            for (int y = 0; y + 1 < d.h && ok2; y++) ok2 = yo[y + 1] > yo[y];          // every source row is the lower row of at most one destination row
-            const int ntx = (d.w + RS2_WW - 1) / RS2_WW, nty = (d.h + RS2_TH - 1) / RS2_TH;
-            ok2 = ok2 && ntx <= RS2_MAX_TX && nty <= RS2_MAX_TY;
-            for (int tx = 0; tx < ntx && ok2; tx++) t.strip_sx0[tx] = (short)(xo[tx * RS2_WW] & ~15);
-            for (int ty = 0; ty < nty && ok2; ty++) {
-                const int y0 = ty * RS2_TH, yl = (y0 + RS2_TH < d.h ? y0 + RS2_TH : d.h) - 1;
-                t.strip_sy0[ty] = (short)yo[y0];
-                t.strip_rows[ty] = (short)(yo[yl] + 2 - yo[y0] < RS2_LH ? yo[yl] + 2 - yo[y0] : RS2_LH);
-            }
-            const char* ev = getenv("VO_RESIZE_STRIP");
-            t.strip = ok2 && !(ev && ev[0] == '0') ? 1 : 0;
-            if (t.strip && !(ev && ev[0] == '1')) t.strip = 2;           // default: k_resize_direct (no LDS staging); VO_RESIZE_STRIP=1: the staged strip kernel, 0: the tiled one
-            if (getenv("VO_DEBUG")) fprintf(stderr, "resize level %d: tiled %d strip %d\n", l, t.tiled, t.strip);
+            for (int y = 0; y + 1 < d.h && ok; y++) ok = yo[y + 1] > yo[y];
+            for (int y0 = 0; y0 < d.h && ok; y0 += RS2_WH) { const int yl = (y0 + RS2_WH < d.h ? y0 + RS2_WH : d.h) - 1; ok = yo[yl] + 2 - yo[y0] <= (RS2_WH * 127 + 99) / 100 + 3; }
+            t.direct = ok ? 1 : 0;
         }
     }
     HIPCHK(hipMemcpy(d_ofs, hofs.data(), int_bytes, hipMemcpyHostToDevice));

@@ -31,8 +31,8 @@ struct PyrGeom {
     LevelGeom lv[VO_MAX_LEVELS];
 };
 
-// k_resize_strip: a wavefront = RS2_WW x RS2_WH destination pixels (lane = 4 columns, swept down the rows), a workgroup =
-// four of them stacked; the LDS window holds the source rows / bytes the 256 x 64 tile can need
+// the direct pyramid kernel: a wavefront = RS2_WW x RS2_WH destination pixels (lane = 4 columns, swept down the rows), a
+// workgroup = four of them stacked
 #define RS2_WW 256
 #define RS2_WH 16
 #ifndef RS2_WAVES
@@ -40,29 +40,14 @@ struct PyrGeom {
 #endif
 #define RS2_THREADS (64 * RS2_WAVES)
 #define RS2_TH (RS2_WAVES * RS2_WH)
-#define RS2_LW 352
-#define RS2_LH ((RS2_TH * 127 + 99) / 100 + 3)
-#define RS2_MAX_TX 40
-#define RS2_MAX_TY 64
 
 struct ResizeTab {               // INTER_LINEAR_EXACT tables for one level (device pointers)
     const int* xofs; const uint16_t* xc1;
     const int* yofs; const uint16_t* yc1;
     int min_x, max_x, min_y, max_y;
-    int tiled;                   // 1: geometry fits k_resize_tiled's LDS tile (scale factor <= 4/3)
-    int strip;                   // 1: geometry fits k_resize_strip's LDS window (scale factor <= 1.27: ORB's 1.2)
-    // k_resize_strip: LDS window origin of every tile column / row and the number of source rows of every tile row, in the
-    // kernel argument segment so that no workgroup starts with a dependent table load
-    short strip_sx0[RS2_MAX_TX]; short strip_sy0[RS2_MAX_TY]; short strip_rows[RS2_MAX_TY];
+    int direct;                  // 1: the geometry fits k_resize_direct (scale factor <= 1.27: ORB's 1.2); 0: the generic k_resize
 };
 
-// k_resize_tiled: destination tile and the LDS window of source bytes / rows it may need at scale factors <= 4/3
-#define RS_TW 128
-#ifndef RS_TH
-#define RS_TH 32
-#endif
-#define RS_LW 192
-#define RS_LH ((RS_TH * 4 + 2) / 3 + 3)
 #ifndef FAST_TW
 #define FAST_TW 112
 #endif
