@@ -50,7 +50,11 @@ STAGE_KERNELS = {"fast_score_nms": [("k_fast<false>", 1)], "gaussian_blur": [("k
                  "select_fast": [("k_sel_threshold", 1), ("k_sel_rows<false>", 1), ("k_sel_rows<true>", 1)],
                  "harris": [("k_harris", 1)], "ic_angle": [("k_angle", 1)], "rbrief": [("k_brief", 1), ("k_brief_trig", 1), ("k_desc_expand", 1)],
                  "match_nn": [("k_nn_fp4<false>", 1)], "essential_ransac": [("k_ransac", 1)], "recover_pose": [("k_pose", 1)],
-                 "sift_descriptor": [("k_sb_descriptor", 1)], "sift_extrema": [("k_sb_extrema", 9)]}
+                 "cv2_keypoint_order": [("k_cv2_order", 1), ("k_sel_rows<false>", 1), ("k_sel_rows<true>", 1)],
+                 "sift_descriptor": [("k_sb_descriptor", 1)], "sift_extrema": [("k_sb_extrema<5>", 9)],
+                 "sift_scale_space": [("k_sb_sweep<11>", 10), ("k_sb_sweep<13>", 9), ("k_sb_sweep<17>", 9), ("k_sb_sweep<21>", 9), ("k_sb_sweep<27>", 9),
+                                      ("k_sb_base", 1), ("k_sb_half", 8)],
+                 "sift_refine_orient": [("k_sb_refine", 1), ("k_sb_orient", 1)]}
 STAGE_BOUND = {"gray": "hbm", "pyramid_resize": "hbm", "fast_score_nms": "hbm", "gaussian_blur": "hbm", "sift_scale_space": "hbm",
                "sift_extrema": "hbm", "match_nn": "mfma", "essential_ransac": "latency", "recover_pose": "latency", "triangulate": "latency",
                "sift_descriptor": "valu", "sift_refine_orient": "valu", "sift_sort_unique": "valu", "rbrief": "valu", "harris": "latency",
@@ -75,6 +79,9 @@ def pmc_sum(detector, stage, field, nframes=None):
     try:
         if t is None or (nframes is not None and t.get("_meta", {}).get("frames_per_launch") != nframes):
             return None
+        per_step = field.replace("_per_launch", "_per_step")
+        if all(per_step in t[k] for k, _ in STAGE_KERNELS[stage]):          # the sum over every launch of a step (octaves, levels)
+            return float(sum(t[k][per_step] for k, _ in STAGE_KERNELS[stage]))
         return float(sum(t[k][field] * n for k, n in STAGE_KERNELS[stage]))
     except KeyError:
         return None

@@ -8,13 +8,19 @@ read, so it is doubled.  Calibration on this code base: k_sel_scan<false> stream
 31-px border with aligned 16-byte loads (about 0.82 x the pyramid bytes); its raw FETCH_SIZE is 0.545 of that
 byte count, i.e. the factor 2 applies to our access pattern.
 
-usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> [frames_per_launch] [valu_dir]
-"""
+usage: collect_traffic.py <fetch_dir> <write_dir> <out.json> [frames_per_launch] [valu_dir] [bench steps incl. warm-up]
+
+Per kernel: the mean over its launches (`*_per_launch`) and, when the number of bench steps of the profiled run is given,
+the sum over all its launches divided by the steps (`*_per_step`: what a stage that runs once per pyramid octave moves
+per step)."""
 import collections
 import csv
 import glob
 import json
 import sys
+
+
+TOTALS = {}
 
 
 def load(d, counter):
@@ -23,6 +29,7 @@ def load(d, counter):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    TOTALS[counter] = {k: (sum(v), len(v)) for k, v in acc.items()}
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -30,6 +37,7 @@ def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     valu = load(sys.argv[5], "SQ_INSTS_VALU") if len(sys.argv) > 5 else {}
     salu = load(sys.argv[5], "SQ_INSTS_SALU") if len(sys.argv) > 5 else {}
+    steps = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     out = {}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
@@ -38,8 +46,15 @@ def main():
         if k in valu:
             out[k]["valu_wave_insts_per_launch"] = round(valu[k])
             out[k]["salu_wave_insts_per_launch"] = round(salu.get(k, 0.0))
+        if steps:
+            ft, fn = TOTALS["FETCH_SIZE"].get(k, (0.0, 0)); wt, wn = TOTALS["WRITE_SIZE"].get(k, (0.0, 0))
+            out[k]["launches_per_step"] = round(max(fn, wn) / steps, 3)
+            out[k]["hbm_bytes_per_step"] = round((2.0 * ft + wt) * 1024.0 / steps)
+            if k in valu:
+                out[k]["valu_wave_insts_per_step"] = round(TOTALS["SQ_INSTS_VALU"][k][0] / steps)
     out["_meta"] = {"frames_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 257,
-                    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile"}
+                    "bench_steps_incl_warmup": steps,
+                    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline --no-profile ... (tools/collect_profiles.sh)"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 

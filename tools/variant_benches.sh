@@ -10,7 +10,7 @@ d = json.load(open(sys.argv[1]))
 print(f"{sys.argv[2]:22s} {d['value']:9.1f} pairs/s  step {d['ms_per_step']:.3f} ms  ransac {d['stages']['essential_ransac']['ms_per_launch']:.3f} ms  iters mean {d['config']['ransac_iters']['mean']}")
 PY
 }
-run cv2_order --keypoint-order cv2
+run canonical_order --keypoint-order canonical
 run pair_stride6 --pair-stride 6
 run hard_pairs --distinct-frames 17 --matcher crosscheck-legacy
 run opencv300 --poly-solver opencv300
@@ -20,3 +20,5 @@ run kitti_shape --width 1241 --height 376
 run independent_pairs --workload independent
 run matcher_int8 --matcher-kernel mfma
 run matcher_popcount --matcher-kernel popcount
+run sift_1152x648 --detector sift --width 1152 --height 648
+run sift_independent --detector sift --workload independent --pairs-per-step 32

@@ -107,6 +107,9 @@ struct SiftTaps { int n; float k[SIFT_MAX_TAPS]; };
 
 // N > 0: tap count known at compile time (windows in registers); N == 0: any odd tap count <= SW_NMAX, taken from t.n
 #define SW_NMAX 63
+#ifndef SW_CTR_MAXN
+#define SW_CTR_MAXN 63                 // tap counts above this read the centre again from L2 instead (frees LDS: more workgroups per CU)
+#endif
 #ifndef SW_CTR_LDS
 #define SW_CTR_LDS 1                   // (measured: 7.87 vs 8.64 ms per 64 frames) 1: the source rows' centre columns wait in an LDS ring for the DoG; 0: they are read again (L2) when the row is written
 #endif
@@ -119,7 +122,8 @@ struct SweepDims {
     static constexpr int INP = INW + 4;                          // LDS pitch of s_in
     static constexpr int RING = (NN + SW_RS - 1 + 7) & ~7;       // row-filtered rows kept
     static constexpr int CRING = (R + SW_RS + 7) & ~7;           // source centre rows kept (for the DoG)
-    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + (SW_CTR_LDS ? CRING * SW_TW : 0);
+    static constexpr bool CTR = SW_CTR_LDS && NN <= SW_CTR_MAXN;
+    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + (CTR ? CRING * SW_TW : 0);
 };
 
 template <int N>
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[q] += t.k[i] * win[WO + i + q];
                 }
-                if (SW_CTR_LDS) *(float4*)(s_ctr + (seq % DM::CRING) * SW_TW + rx4) = make_float4(win[DM::R4], win[DM::R4 + 1], win[DM::R4 + 2], win[DM::R4 + 3]);
+                if (DM::CTR) *(float4*)(s_ctr + (seq % DM::CRING) * SW_TW + rx4) = make_float4(win[DM::R4], win[DM::R4 + 1], win[DM::R4 + 2], win[DM::R4 + 3]);
                 *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             } else {
 #pragma unroll
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[q] += t.k[i] * in[woff + i + q];
                 }
-                if (SW_CTR_LDS) *(float4*)(s_ctr + (seq % CRING) * SW_TW + rx4) = make_float4(in[R4], in[R4 + 1], in[R4 + 2], in[R4 + 3]);
+                if (DM::CTR) *(float4*)(s_ctr + (seq % CRING) * SW_TW + rx4) = make_float4(in[R4], in[R4 + 1], in[R4 + 2], in[R4 + 3]);
                 *(float4*)(s_ring + (seq % RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
                         const size_t o = (size_t)y * stride + x;
                         if (dstG) dstG[o] = acc[q];
                         if (dstD) {
-                            if (SW_CTR_LDS) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dstD[o] = acc[q] - s_ctr[ci * SW_TW + cc]; }
+                            if (DM::CTR) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dstD[o] = acc[q] - s_ctr[ci * SW_TW + cc]; }
                             else dstD[o] = acc[q] - src[o];     // this workgroup streamed the row through a moment ago: an L2 hit
                         }
                     }
@@ -261,7 +265,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 // 3-wide maximum / minimum comes from the two neighbouring lanes; the last three rows of (row maximum, row minimum, centre)
 // of every plane stay in registers, so the 3 x 3 x 3 extremes of the row above are three more max / min per plane.
 #define EX_COLS 62
-#define EX_SEG 32
+#ifndef EX_SEG
+#define EX_SEG 128                    // rows per wavefront sweep (32 / 64 / 128: 2.74 / 2.25 / 1.99 ms per 64 frames: fewer halo rows, longer streams)
+#endif
 #define EX_MAXP 10                     // DoG planes of an octave (nOctaveLayers + 2 <= 10)
 template <int NP>
 __global__ __launch_bounds__(256) void k_sb_extrema(const float* dog, size_t d_fs, size_t plane, int w, int h, int stride, int o,
@@ -844,7 +850,7 @@ static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG,
     while (seg > 64 && (long long)strips * ((h + seg - 1) / seg) * F < 2048) seg >>= 1;
     const int n = N > 0 ? N : t.n, r = n / 2, R4 = (r + 3) & ~3;
     const size_t lds = N > 0 ? (size_t)SweepDims<N>::LDS_FLOATS * 4
-                             : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + (SW_CTR_LDS ? ((r + SW_RS + 7) & ~7) : 0)) * SW_TW) * 4;
+                             : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + (SweepDims<0>::CTR ? ((r + SW_RS + 7) & ~7) : 0)) * SW_TW) * 4;
     hipLaunchKernelGGL(k_sb_sweep<N>, dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t);
 }
 
