@@ -14,13 +14,15 @@
 //                    it top to bottom eight rows at a time: rows stream HBM -> registers -> LDS one step ahead of their use,
 //                    row-filtered rows live in an LDS ring, every source plane is read once and every output written once
 //   k_sb_half        INTER_NEAREST half-size (first image of the next octave)
-//   k_sb_extrema     26-neighbour extrema of the DoG stack above the contrast pre-threshold, from an LDS tile of the five
-//                    DoG planes: a pixel is an extremum iff it equals the max (min) of the 3 x 3 x 3 block
+//   k_sb_extrema     26-neighbour extrema of the DoG stack above the contrast pre-threshold: a workgroup streams a
+//                    62-column strip of the three planes top to bottom (rows in registers, column maxima shared through
+//                    LDS); a pixel is an extremum iff it equals the max (min) of the 3 x 3 x 3 block
 //   k_sb_refine      lane per candidate: adjustLocalExtrema (<= 5 steps, Matx33f::solve closed form), contrast and edge tests
 //   k_sb_orient      wavefront per refined extremum: calcOrientationHist (cv::exp32f's table algorithm, cv::fastAtan2); the 36
 //                    bins are owned by 36 lanes that add their samples in window order (bit masks by LDS atomic OR)
-//   k_sb_rank / k_sb_emit   KeyPointsFilter::removeDuplicatedSorted on the device: rank of every record under
-//                    KeyPoint_LessThan (all-pairs count on 64-bit (x, y) keys, full comparator on ties), scatter, drop repeats
+//   k_sb_bucket / k_sb_rank / k_sb_emit   KeyPointsFilter::removeDuplicatedSorted on the device: records are binned by the
+//                    top bits of their 64-bit (x, y) key (4096 buckets per frame), ranked inside their bucket under
+//                    KeyPoint_LessThan (full comparator on key ties), scattered, repeats dropped
 //   k_sb_descriptor  wavefront per keypoint: calcSIFTDescriptor.  The window is first compacted to the samples that fall
 //                    inside the rotated 4 x 4 grid; 64 of them are evaluated in parallel (gradient, fastAtan2, exp32f,
 //                    trilinear split); the 128 + 16 histogram bins that matter live in REGISTERS of their owner lanes
