@@ -85,6 +85,14 @@ int vo_set_keypoint_order(vo_ctx* ctx, int kind);
  * test sets, 10x less RANSAC time).  Applies to vo_find_essential_ransac, vo_stage_five_point and vo_pairs_run. */
 int vo_set_poly_solver(vo_ctx* ctx, int kind);
 
+/* How vo_solve_pnp_ransac(_batch) computes the final pose from the consensus set (cv2.solvePnPRansac ends with
+ * solvePnP(inliers, SOLVEPNP_ITERATIVE, useExtrinsicGuess = false) — src/visual_slam.py:231-235): 1 (default) = as
+ * OpenCV 4.7 does: DLT start (homography start for a planar structure; the RANSAC model itself when only 5 non-planar
+ * inliers exist), then CvLevMarq on (rvec, tvec) for at most 20 iterations with the FLT_EPSILON step rule;
+ * 0 = fast mode: the same reprojection cost minimised from the best RANSAC model to tight convergence (agrees with
+ * mode 1 to ~1e-7 wherever both converge to the same minimum, ~25 % less kernel time). */
+int vo_set_pnp_refine(vo_ctx* ctx, int kind);
+
 /* self.matcher.match(d1, d2) for cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=...) —
  * src/image_pair.py:234-236, matcher built at src/visual_slam.py:18 / src/image_and_keypoints.py:9.
  * cross_check: 0 = nearest neighbour (crossCheck=False); 2 = crossCheck=True as OpenCV 4.x computes it: strict

@@ -388,6 +388,14 @@ def solve_pnp_ransac(obj, img, K, iterations=100, reproj_err=8.0, confidence=0.9
     return rc, rvec, tvec, mask[:n].copy(), ninl.value
 
 
+def set_pnp_refine(mode):
+    """"cv2" (default): solvePnPRansac's final pose as cv2 computes it (DLT / homography start, CvLevMarq);
+    "fast": the product's fast mode (the same cost minimised from the best RANSAC model)."""
+    f = lib().voo_set_pnp_refine
+    f.argtypes = [C.c_int]; f.restype = None
+    f({"cv2": 1, "fast": 0}[mode])
+
+
 def rodrigues(x):
     """cv2.Rodrigues: 3-vector -> 3x3 matrix, 3x3 matrix -> 3-vector."""
     x = np.ascontiguousarray(x, np.float64)

@@ -139,6 +139,7 @@ int voo_solve_pnp_ransac(const double* obj /*n x 3*/, const double* img /*n x 2*
                          int iterations, double reproj_err, double confidence, uint64_t seed,
                          double* rvec, double* tvec, uint8_t* mask, int32_t* n_inl);
 int voo_rodrigues(const double* in, int in_is_matrix, double* out);
+void voo_set_pnp_refine(int mode);   /* 1 (default): cv2's final solvePnP(ITERATIVE); 0: the product's fast mode */
 
 #ifdef __cplusplus
 }

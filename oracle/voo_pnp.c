@@ -12,13 +12,13 @@
  *     steps / absolute orientation, best of the three by reprojection error;
  *   - error = squared float32 distance between the image point and projectPoints' float32 output, inlier iff
  *     err <= 64;
- *   - final pose = reprojection-error minimum over the inliers (solvePnP SOLVEPNP_ITERATIVE), then Rodrigues.
+ *   - final pose = solvePnP(inliers, SOLVEPNP_ITERATIVE, no guess) as cv2 runs it: DLT (or, for a planar structure,
+ *     homography) initial pose, then CvLevMarq on (rvec, tvec) for at most 20 iterations — pn_refine_cv2 below;
+ *     voo_set_pnp_refine(0) selects the product's FAST mode instead (the same cost minimised from the best RANSAC
+ *     model with an so(3) increment, to tight convergence: pn_refine), which the tests hold against this one.
  * PARITY UNPINNED, and only to tolerance even in principle: opencv-python takes the 12x12 SVD of epnp.cpp from LAPACK
  * (any basis of its 2-dimensional null space is a valid answer for 5 points), so hypotheses agree with cv2's to
- * rounding-sensitive noise, not bit for bit.  [deviation] the final Levenberg-Marquardt runs from the best RANSAC
- * hypothesis with an so(3) increment and to tight convergence; cv2 starts from a DLT (or homography) initial
- * guess, uses the rvec parametrisation and stops after 20 iterations or a FLT_EPSILON step: same cost, same
- * minimum, agreement to the optimiser's tolerance. */
+ * rounding-sensitive noise, not bit for bit. */
 #include "voo.h"
 #include <float.h>
 #include <math.h>
@@ -364,8 +364,16 @@ static void pn_epnp(const double* pws, const double* us, int n, pn_cam K, double
 }
 
 /* cv::Rodrigues, matrix -> vector (calibration.cpp cvRodrigues2) */
-static void pn_rodrigues_to_vec(const double* R, double* r)
+static void pn_rodrigues_to_vec(const double* Rin, double* r)
 {
+    double At[9], W[3], Vt[9], R[9];                      /* SVD::compute(R, W, U, Vt); R = U * Vt */
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = Rin[i * 3 + j];
+    pn_jacobi_svd(At, 3, 3, W, Vt);
+    for (int i = 0; i < 3; i++) {                         /* JacobiSVD's normalisation of U */
+        const double s = W[i] > DBL_MIN ? 1 / W[i] : 0.;
+        for (int k = 0; k < 3; k++) At[i * 3 + k] *= s;
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = At[i] * Vt[j] + At[3 + i] * Vt[3 + j] + At[6 + i] * Vt[6 + j];
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
     double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
@@ -387,16 +395,17 @@ static void pn_rodrigues_to_vec(const double* R, double* r)
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
-/* cv::Rodrigues, vector -> matrix */
+/* cv::Rodrigues, vector -> matrix: R = cos(theta) I + (1 - cos(theta)) r r^T + sin(theta) [r]x, element by element */
 static void pn_rodrigues_to_mat(const double* r, double* R)
 {
+    static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    if (theta < DBL_EPSILON) { memset(R, 0, sizeof(double) * 9); R[0] = R[4] = R[8] = 1; return; }
-    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
-    double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
-    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
-    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
-    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+    if (theta < DBL_EPSILON) { memcpy(R, I, sizeof(I)); return; }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    const double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
 }
 
 int voo_rodrigues(const double* in, int in_is_matrix, double* out)
@@ -863,6 +872,554 @@ static int p3_solve(const float* obj, const float* img, pn_cam K, double R[4][3]
     return nb;
 }
 
+/* ---------------------------------------------------------------- cv2's final pose: solvePnP(inliers, SOLVEPNP_ITERATIVE)
+ * solvePnPRansac (calib3d solvepnp.cpp) ends with solvePnP(opoints_inliers, ipoints_inliers, K, dist, rvec, tvec,
+ * useExtrinsicGuess = false, SOLVEPNP_ITERATIVE) = cvFindExtrinsicCameraParams2 (calib3d calibration.cpp), restated here:
+ *   - the inliers are the FLOAT32 points of the RANSAC stage converted back to double;
+ *   - normalised image points (cvUndistortPoints with zero distortion: (u - cx) * (1 / fx));
+ *   - mean Mc and scatter MM of the object points, SVD(MM); W[2] / W[1] < 1e-3 -> planar structure:
+ *       R_transform = V^T (identity if its third row is almost the z axis; negated if det < 0), the points rotated into
+ *       the plane, cv::findHomography(Mxy, mn, 0) (float32 points; normalised DLT on the 9 x 9 L^T L by cv::eigen's
+ *       Jacobi, then LMSolver with 10 iterations on the 8 free entries), R from the normalised first two columns and
+ *       their cross product through a Rodrigues round trip, t = h3 * 2 / (|h1| + |h2|);
+ *     otherwise the DLT: 2N x 12 matrix L, SVD of L^T L, last right singular vector = [R | t] up to scale, R := U V^T
+ *       of its 3 x 3 part, t scaled by |R| / |RR|  (fewer than 6 inliers: cv2 raises "DLT algorithm needs at least 6
+ *       points", which solvePnPRansac answers for exactly 5 inliers with the RANSAC model itself: return 0);
+ *   - CvLevMarq (compat_ptsetreg.cpp): 6 parameters (rvec, tvec), at most 20 iterations, stop when the relative
+ *     parameter change is below FLT_EPSILON; lambda = 10^k, k from -3, +1 while the error grows, -1 per accepted step;
+ *     the damped normal equations solved with cv::solve(DECOMP_SVD); residuals and Jacobians from cvProjectPoints2
+ *     (d R / d rvec from cvRodrigues2's Jacobian).
+ * [rounding-order note] every sum over the points (mean, scatter, L^T L, J^T J, J^T e, |e|^2, the homography's sums)
+ * is taken in the 256-lane order of pn_lane_sums instead of OpenCV's row-sequential order: which order cv2 itself
+ * uses depends on its build (AVX2/FMA dispatch of mulTransposed and gemm, BLAS), so none is "the" reference order,
+ * and the SVDs it takes from LAPACK are not reproducible to the bit either.  Decisions (planarity, the 6-point
+ * rule, accept / reject of a step, the stopping rules) are OpenCV's. */
+typedef struct {
+    const float* obj; const float* img; pn_cam K;
+    double ifx, ify;
+    double Mc[3];
+    double Rp[9], Tp[3];                 /* planar case: rotation into the plane, translation */
+    double cm[2], cM[2], sm[2], sM[2];   /* homography normalisation */
+    double h[8];                         /* homography LM parameters */
+    double R[9], t[3], dRdr[27];         /* pose of the LM evaluation */
+    int want_j;
+} pn_rf;
+typedef void (*pn_terms_fn)(int i, const pn_rf* c, double* acc);
+
+/* nq sums over the masked points: partial sums over i = k, k + 256, ... per lane k, partials added in lane order */
+static void pn_lane_sums(int n, const uint8_t* mask, int nq, pn_terms_fn fn, const pn_rf* c, double* tot)
+{
+    double acc[80];
+    for (int q = 0; q < nq; q++) tot[q] = 0;
+    for (int k = 0; k < PN_LANES; k++) {
+        for (int q = 0; q < nq; q++) acc[q] = 0;
+        for (int i = k; i < n; i += PN_LANES) if (mask[i]) fn(i, c, acc);
+        for (int q = 0; q < nq; q++) tot[q] += acc[q];
+    }
+}
+
+/* JacobiSVD with its normalisation of U: At rows become the left singular vectors (rows with w <= DBL_MIN are zeroed:
+ * OpenCV fills them with an arbitrary orthogonal completion, which none of the callers below reads) */
+static void pn_svd_full(double* At, int m, int n, double* W, double* Vt)
+{
+    pn_jacobi_svd(At, m, n, W, Vt);
+    for (int i = 0; i < n; i++) {
+        const double s = W[i] > DBL_MIN ? 1 / W[i] : 0.;
+        for (int k = 0; k < m; k++) At[i * m + k] *= s;
+    }
+}
+
+/* SVD::backSubst (SVBkSbImpl_, one right-hand side): x = sum_i v_i (u_i . b) / w_i over w_i > 2 eps sum(w) */
+static void pn_backsubst(int m, int n, const double* W, const double* Ut, const double* Vt, const double* b, double* x)
+{
+    double thr = 0;
+    for (int i = 0; i < n; i++) { x[i] = 0; thr += W[i]; }
+    thr *= DBL_EPSILON * 2;
+    for (int i = 0; i < n; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= thr) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < m; j++) s += Ut[i * m + j] * b[j];
+        s *= wi;
+        for (int j = 0; j < n; j++) x[j] = x[j] + s * Vt[i * n + j];
+    }
+}
+
+/* cv::solve(A, b, x, DECOMP_SVD), A n x n (n <= 8) */
+static void pn_solve_svd(const double* A, int n, const double* b, double* x)
+{
+    double At[64], W[8], Vt[64];
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) At[j * n + i] = A[i * n + j];
+    pn_svd_full(At, n, n, W, Vt);
+    pn_backsubst(n, n, W, At, Vt, b, x);
+}
+
+/* cv::eigen of a symmetric matrix (lapack.cpp JacobiImpl_: largest off-diagonal pivot per step); W descending,
+ * V rows = eigenvectors.  n <= 9 */
+static void pn_eigen_sym(double* A, int n, double* W, double* V)
+{
+    const double eps = DBL_EPSILON;
+    int indR[9], indC[9], i, j, k, m;
+    double mv;
+    for (i = 0; i < n; i++) { for (j = 0; j < n; j++) V[i * n + j] = 0; V[i * n + i] = 1; }
+    for (k = 0; k < n; k++) {
+        W[k] = A[(n + 1) * k];
+        if (k < n - 1) {
+            for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; i++) { double val = fabs(A[n * k + i]); if (mv < val) mv = val, m = i; }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = fabs(A[k]), i = 1; i < k; i++) { double val = fabs(A[n * i + k]); if (mv < val) mv = val, m = i; }
+            indC[k] = m;
+        }
+    }
+    const int maxIters = n * n * 30;
+    if (n > 1) for (int iters = 0; iters < maxIters; iters++) {
+        for (k = 0, mv = fabs(A[indR[0]]), i = 1; i < n - 1; i++) { double val = fabs(A[n * i + indR[i]]); if (mv < val) mv = val, k = i; }
+        int l = indR[k];
+        for (i = 1; i < n; i++) { double val = fabs(A[n * indC[i] + i]); if (mv < val) mv = val, k = indC[i], l = i; }
+        double p = A[n * k + l];
+        if (fabs(p) <= eps) break;
+        double y = (W[l] - W[k]) * 0.5;
+        double t = fabs(y) + pn_hypot(p, y);
+        double s = pn_hypot(p, t);
+        double c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0) s = -s, t = -t;
+        A[n * k + l] = 0;
+        W[k] -= t;
+        W[l] += t;
+        double a0, b0;
+#define PN_ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
+        for (i = 0; i < k; i++) PN_ROT(A[n * i + k], A[n * i + l]);
+        for (i = k + 1; i < l; i++) PN_ROT(A[n * k + i], A[n * i + l]);
+        for (i = l + 1; i < n; i++) PN_ROT(A[n * k + i], A[n * l + i]);
+        for (i = 0; i < n; i++) PN_ROT(V[n * k + i], V[n * l + i]);
+#undef PN_ROT
+        for (j = 0; j < 2; j++) {
+            int idx = j == 0 ? k : l;
+            if (idx < n - 1) {
+                for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; i++) { double val = fabs(A[n * idx + i]); if (mv < val) mv = val, m = i; }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; i++) { double val = fabs(A[n * i + idx]); if (mv < val) mv = val, m = i; }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (k = 0; k < n - 1; k++) {
+        m = k;
+        for (i = k + 1; i < n; i++) if (W[m] < W[i]) m = i;
+        if (k != m) {
+            double tw = W[m]; W[m] = W[k]; W[k] = tw;
+            for (i = 0; i < n; i++) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; }
+        }
+    }
+}
+
+/* cv::solve(A, b, x, DECOMP_EIG): eigen-decomposition, then backSubst with u = v = the eigenvectors */
+static void pn_solve_eig(const double* A, int n, const double* b, double* x)
+{
+    double a[64], W[8], V[64];
+    memcpy(a, A, sizeof(double) * n * n);
+    pn_eigen_sym(a, n, W, V);
+    pn_backsubst(n, n, W, V, V, b, x);
+}
+
+/* max |diagonal| of cv::invert(A, DECOMP_EIG) = sum_k v_k v_k^T / w_k */
+static double pn_inv_eig_maxdiag(const double* A, int n)
+{
+    double a[64], W[8], V[64], inv[64], thr = 0;
+    memcpy(a, A, sizeof(double) * n * n);
+    pn_eigen_sym(a, n, W, V);
+    for (int i = 0; i < n * n; i++) inv[i] = 0;
+    for (int i = 0; i < n; i++) thr += W[i];
+    thr *= DBL_EPSILON * 2;
+    for (int k = 0; k < n; k++) {
+        double wi = W[k];
+        if (fabs(wi) <= thr) continue;
+        wi = 1 / wi;
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) inv[i * n + j] += V[k * n + i] * (V[k * n + j] * wi);
+    }
+    double maxval = DBL_EPSILON;
+    for (int i = 0; i < n; i++) { const double v = fabs(inv[i * n + i]); if (v > maxval) maxval = v; }
+    return maxval;
+}
+
+/* cvRodrigues2, vector -> matrix with the Jacobian J[i * 9 + k] = d R_k / d r_i (J may be NULL) */
+static void pn_rodrigues_jac(const double* rv, double* R, double* J)
+{
+    static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double theta = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (theta < DBL_EPSILON) {
+        memcpy(R, I, sizeof(I));
+        if (J) { memset(J, 0, sizeof(double) * 27); J[5] = J[15] = J[19] = -1; J[7] = J[11] = J[21] = 1; }
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    const double x = rv[0] * itheta, y = rv[1] * itheta, z = rv[2] * itheta;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    if (!J) return;
+    const double drrt[27] = {x + x, y, z, y, 0, 0, z, 0, 0,
+                             0, x, 0, x, y + y, z, 0, z, 0,
+                             0, 0, x, 0, 0, y, x, y, z + z};
+    static const double d_r_x[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0,
+                                     0, 0, 1, 0, 0, 0, -1, 0, 0,
+                                     0, -1, 0, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+        const double ri = i == 0 ? x : i == 1 ? y : z;
+        const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+        const double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+        for (int k = 0; k < 9; k++)
+            J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x[i * 9 + k];
+    }
+}
+
+static inline void pn_rf_point(int i, const pn_rf* c, double* M, double* m)
+{
+    M[0] = (double)c->obj[3 * i]; M[1] = (double)c->obj[3 * i + 1]; M[2] = (double)c->obj[3 * i + 2];
+    m[0] = (double)c->img[2 * i]; m[1] = (double)c->img[2 * i + 1];
+}
+static inline void pn_rf_normalised(const pn_rf* c, const double* m, double* mn)
+{
+    mn[0] = (m[0] - c->K.uc) * c->ifx; mn[1] = (m[1] - c->K.vc) * c->ify;
+}
+
+static void pn_t_sum(int i, const pn_rf* c, double* acc)                 /* cvAvg: 3 sums */
+{
+    double M[3], m[2];
+    pn_rf_point(i, c, M, m);
+    acc[0] += M[0]; acc[1] += M[1]; acc[2] += M[2];
+}
+static void pn_t_scatter(int i, const pn_rf* c, double* acc)             /* cvMulTransposed(M, MM, 1, Mc): upper triangle */
+{
+    double M[3], m[2];
+    pn_rf_point(i, c, M, m);
+    const double d0 = M[0] - c->Mc[0], d1 = M[1] - c->Mc[1], d2 = M[2] - c->Mc[2];
+    acc[0] += d0 * d0; acc[1] += d0 * d1; acc[2] += d0 * d2; acc[3] += d1 * d1; acc[4] += d1 * d2; acc[5] += d2 * d2;
+}
+static void pn_t_dlt(int i, const pn_rf* c, double* acc)                 /* L^T L of the DLT, 78 upper-triangle entries */
+{
+    double M[3], m[2], mn[2];
+    pn_rf_point(i, c, M, m);
+    pn_rf_normalised(c, m, mn);
+    const double x = -mn[0], y = -mn[1];
+    const double Lx[12] = {M[0], M[1], M[2], 1., 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
+    const double Ly[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1., y * M[0], y * M[1], y * M[2], y};
+    int q = 0;
+    for (int j = 0; j < 12; j++) for (int k = j; k < 12; k++) acc[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+}
+/* the float32 point pair cv::findHomography sees: object point rotated into the plane, normalised image point */
+static inline void pn_rf_planar(int i, const pn_rf* c, double* Mf, double* mf)
+{
+    double M[3], m[2], mn[2];
+    pn_rf_point(i, c, M, m);
+    pn_rf_normalised(c, m, mn);
+    Mf[0] = (double)(float)(c->Rp[0] * M[0] + c->Rp[1] * M[1] + c->Rp[2] * M[2] + c->Tp[0]);
+    Mf[1] = (double)(float)(c->Rp[3] * M[0] + c->Rp[4] * M[1] + c->Rp[5] * M[2] + c->Tp[1]);
+    mf[0] = (double)(float)mn[0]; mf[1] = (double)(float)mn[1];
+}
+static void pn_t_hcentre(int i, const pn_rf* c, double* acc)
+{
+    double M[2], m[2];
+    pn_rf_planar(i, c, M, m);
+    acc[0] += m[0]; acc[1] += m[1]; acc[2] += M[0]; acc[3] += M[1];
+}
+static void pn_t_hscale(int i, const pn_rf* c, double* acc)
+{
+    double M[2], m[2];
+    pn_rf_planar(i, c, M, m);
+    acc[0] += fabs(m[0] - c->cm[0]); acc[1] += fabs(m[1] - c->cm[1]); acc[2] += fabs(M[0] - c->cM[0]); acc[3] += fabs(M[1] - c->cM[1]);
+}
+static void pn_t_hltl(int i, const pn_rf* c, double* acc)                /* HomographyEstimatorCallback::runKernel's LtL, 45 entries */
+{
+    double M[2], m[2];
+    pn_rf_planar(i, c, M, m);
+    const double x = (m[0] - c->cm[0]) * c->sm[0], y = (m[1] - c->cm[1]) * c->sm[1];
+    const double X = (M[0] - c->cM[0]) * c->sM[0], Y = (M[1] - c->cM[1]) * c->sM[1];
+    const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+    const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+    int q = 0;
+    for (int j = 0; j < 9; j++) for (int k = j; k < 9; k++) acc[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+}
+/* HomographyRefineCallback::compute: acc = [|r|^2, J^T r (8), upper triangle of J^T J (36)] (norm(r, NORM_INF), a
+ * maximum and not a sum, is taken by pn_h_maxabs) */
+static void pn_t_hlm(int i, const pn_rf* c, double* acc)
+{
+    double M[2], m[2];
+    pn_rf_planar(i, c, M, m);
+    const double* h = c->h;
+    double ww = h[6] * M[0] + h[7] * M[1] + 1.;
+    ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+    const double xi = (h[0] * M[0] + h[1] * M[1] + h[2]) * ww, yi = (h[3] * M[0] + h[4] * M[1] + h[5]) * ww;
+    const double ex = xi - m[0], ey = yi - m[1];
+    acc[0] += ex * ex + ey * ey;
+    if (!c->want_j) return;
+    const double Jx[8] = {M[0] * ww, M[1] * ww, ww, 0, 0, 0, -M[0] * ww * xi, -M[1] * ww * xi};
+    const double Jy[8] = {0, 0, 0, M[0] * ww, M[1] * ww, ww, -M[0] * ww * yi, -M[1] * ww * yi};
+    int q = 9;
+    for (int r = 0; r < 8; r++) {
+        acc[1 + r] += Jx[r] * ex + Jy[r] * ey;
+        for (int s2 = r; s2 < 8; s2++) acc[q++] += Jx[r] * Jx[s2] + Jy[r] * Jy[s2];
+    }
+}
+static double pn_h_maxabs(int n, const uint8_t* mask, const pn_rf* c)     /* norm(r, NORM_INF) */
+{
+    double mx = 0;
+    for (int i = 0; i < n; i++) {
+        if (!mask[i]) continue;
+        double M[2], m[2];
+        pn_rf_planar(i, c, M, m);
+        const double* h = c->h;
+        double ww = h[6] * M[0] + h[7] * M[1] + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        const double ex = fabs((h[0] * M[0] + h[1] * M[1] + h[2]) * ww - m[0]), ey = fabs((h[3] * M[0] + h[4] * M[1] + h[5]) * ww - m[1]);
+        if (ex > mx) mx = ex;
+        if (ey > mx) mx = ey;
+    }
+    return mx;
+}
+
+/* cvProjectPoints2 with zero distortion: residual and the 2 x 6 Jacobian rows (d / d rvec, d / d tvec) of one point:
+ * acc = [|e|^2, J^T e (6), upper triangle of J^T J (21)] */
+static void pn_t_lm(int i, const pn_rf* c, double* acc)
+{
+    double M[3], m[2];
+    pn_rf_point(i, c, M, m);
+    const double* R = c->R; const double* t = c->t;
+    const double X = M[0], Y = M[1], Z = M[2];
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    const double eu = x * c->K.fu + c->K.uc - m[0], ev = y * c->K.fv + c->K.vc - m[1];
+    acc[0] += eu * eu + ev * ev;
+    if (!c->want_j) return;
+    const double* dRdr = c->dRdr;
+    double Ju[6], Jv[6];
+    for (int j = 0; j < 3; j++) {
+        const double dx0 = X * dRdr[9 * j] + Y * dRdr[9 * j + 1] + Z * dRdr[9 * j + 2];
+        const double dy0 = X * dRdr[9 * j + 3] + Y * dRdr[9 * j + 4] + Z * dRdr[9 * j + 5];
+        const double dz0 = X * dRdr[9 * j + 6] + Y * dRdr[9 * j + 7] + Z * dRdr[9 * j + 8];
+        Ju[j] = c->K.fu * (z * (dx0 - x * dz0));
+        Jv[j] = c->K.fv * (z * (dy0 - y * dz0));
+    }
+    Ju[3] = c->K.fu * z; Ju[4] = 0; Ju[5] = c->K.fu * (-x * z);
+    Jv[3] = 0; Jv[4] = c->K.fv * z; Jv[5] = c->K.fv * (-y * z);
+    int q = 7;
+    for (int r = 0; r < 6; r++) {
+        acc[1 + r] += Ju[r] * eu + Jv[r] * ev;
+        for (int s2 = r; s2 < 6; s2++) acc[q++] += Ju[r] * Ju[s2] + Jv[r] * Jv[s2];
+    }
+}
+
+static void pn_unpack_sym(const double* tri, int n, double* A)
+{
+    int q = 0;
+    for (int r = 0; r < n; r++) for (int s2 = r; s2 < n; s2++) { A[r * n + s2] = tri[q]; A[s2 * n + r] = tri[q]; q++; }
+}
+
+/* cv::findHomography(Mxy, mn, method 0) -> H (h[8] = 1); returns 0 when runKernel refuses (degenerate spread) */
+static int pn_find_homography(int n, const uint8_t* mask, int count, pn_rf* c, double* H)
+{
+    double s4[4], tri[45], LtL[81], W[9], V[81];
+    pn_lane_sums(n, mask, 4, pn_t_hcentre, c, s4);
+    c->cm[0] = s4[0] / count; c->cm[1] = s4[1] / count; c->cM[0] = s4[2] / count; c->cM[1] = s4[3] / count;
+    pn_lane_sums(n, mask, 4, pn_t_hscale, c, s4);
+    if (fabs(s4[0]) < DBL_EPSILON || fabs(s4[1]) < DBL_EPSILON || fabs(s4[2]) < DBL_EPSILON || fabs(s4[3]) < DBL_EPSILON) return 0;
+    c->sm[0] = count / s4[0]; c->sm[1] = count / s4[1]; c->sM[0] = count / s4[2]; c->sM[1] = count / s4[3];
+    const double invHnorm[9] = {1. / c->sm[0], 0, c->cm[0], 0, 1. / c->sm[1], c->cm[1], 0, 0, 1};
+    const double Hnorm2[9] = {c->sM[0], 0, -c->cM[0] * c->sM[0], 0, c->sM[1], -c->cM[1] * c->sM[1], 0, 0, 1};
+    pn_lane_sums(n, mask, 45, pn_t_hltl, c, tri);
+    pn_unpack_sym(tri, 9, LtL);
+    pn_eigen_sym(LtL, 9, W, V);
+    const double* H0 = V + 72;                                          /* eigenvector of the smallest eigenvalue */
+    double Ht[9], H1[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ht[i * 3 + j] = invHnorm[i * 3] * H0[j] + invHnorm[i * 3 + 1] * H0[3 + j] + invHnorm[i * 3 + 2] * H0[6 + j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) H1[i * 3 + j] = Ht[i * 3] * Hnorm2[j] + Ht[i * 3 + 1] * Hnorm2[3 + j] + Ht[i * 3 + 2] * Hnorm2[6 + j];
+    const double sc = 1. / H1[8];
+    for (int k = 0; k < 9; k++) H[k] = H1[k] * sc;
+    if (count <= 4) return 1;
+    /* LMSolver (levmarq.cpp), 10 iterations, FLT_EPSILON, on the first 8 entries */
+    double x[8], xd[8], acc[45], A[64], v[8], D[8], d[8], Ap[64], r_inf;
+    memcpy(x, H, sizeof(x));
+    memcpy(c->h, x, sizeof(x)); c->want_j = 1;
+    pn_lane_sums(n, mask, 45, pn_t_hlm, c, acc);
+    double S = acc[0];
+    memcpy(v, acc + 1, sizeof(v)); pn_unpack_sym(acc + 9, 8, A);
+    r_inf = pn_h_maxabs(n, mask, c);
+    for (int i = 0; i < 8; i++) D[i] = A[i * 8 + i];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+        memcpy(Ap, A, sizeof(A));
+        for (int i = 0; i < 8; i++) Ap[i * 8 + i] += lambda * D[i];
+        pn_solve_eig(Ap, 8, v, d);
+        for (int i = 0; i < 8; i++) xd[i] = x[i] - d[i];
+        memcpy(c->h, xd, sizeof(xd)); c->want_j = 0;
+        pn_lane_sums(n, mask, 1, pn_t_hlm, c, acc);
+        const double Sd = acc[0];
+        double dS = 0, td = 0;
+        for (int i = 0; i < 8; i++) {                                  /* temp_d = -A d + 2 v; dS = d . temp_d */
+            double s = 0;
+            for (int k = 0; k < 8; k++) s += A[i * 8 + k] * d[k];
+            dS += d[i] * (s * -1 + v[i] * 2);
+            td += d[i] * v[i];
+        }
+        const double Rr = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (Rr > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+        else if (Rr < Rlo) {
+            double nu = (Sd - S) / (fabs(td) > DBL_EPSILON ? td : 1) + 2;
+            nu = nu > 2. ? nu : 2.; nu = nu < 10. ? nu : 10.;
+            if (lambda == 0) { lambda = lc = 1. / pn_inv_eig_maxdiag(A, 8); nu *= 0.5; }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            memcpy(x, xd, sizeof(x));
+            memcpy(c->h, x, sizeof(x)); c->want_j = 1;
+            pn_lane_sums(n, mask, 45, pn_t_hlm, c, acc);
+            memcpy(v, acc + 1, sizeof(v)); pn_unpack_sym(acc + 9, 8, A);
+            r_inf = pn_h_maxabs(n, mask, c);
+        }
+        iter++;
+        double d_inf = 0;
+        for (int i = 0; i < 8; i++) if (fabs(d[i]) > d_inf) d_inf = fabs(d[i]);
+        if (!(iter < 10 && d_inf >= FLT_EPSILON && r_inf >= FLT_EPSILON)) break;
+    }
+    memcpy(H, x, sizeof(x));
+    return 1;
+}
+
+/* CvLevMarq::step */
+static void pn_lm_step(const double* JtJ, const double* JtErr, const double* prev, int lambdaLg10, double* param)
+{
+    const double LOG10 = log(10.);
+    const double lambda = exp(lambdaLg10 * LOG10);
+    double A[36], dx[6];
+    memcpy(A, JtJ, sizeof(A));
+    for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
+    pn_solve_svd(A, 6, JtErr, dx);
+    for (int i = 0; i < 6; i++) param[i] = prev[i] - dx[i];
+}
+
+static double pn_l2sqr6(const double* a, const double* b)                /* normL2Sqr over 6 doubles (4-unrolled) */
+{
+    double v[6];
+    for (int i = 0; i < 6; i++) v[i] = b ? a[i] - b[i] : a[i];
+    double s = 0;
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    s += v[4] * v[4];
+    s += v[5] * v[5];
+    return s;
+}
+
+/* returns 1 with (rvec, tvec); 0 = cv2's "DLT algorithm needs at least 6 points" (the caller keeps the RANSAC model) */
+static int pn_refine_cv2(const float* of, const float* imf, const uint8_t* mask, int n, pn_cam K, double* rvec, double* tvec)
+{
+    pn_rf c;
+    memset(&c, 0, sizeof(c));
+    c.obj = of; c.img = imf; c.K = K; c.ifx = 1. / K.fu; c.ify = 1. / K.fv;
+    int count = 0;
+    for (int i = 0; i < n; i++) count += mask[i] != 0;
+    double s3[3], tri[78], MM[9], W[3], V[9], param[6];
+    pn_lane_sums(n, mask, 3, pn_t_sum, &c, s3);
+    const double inv = 1. / count;
+    for (int k = 0; k < 3; k++) c.Mc[k] = s3[k] * inv;
+    pn_lane_sums(n, mask, 6, pn_t_scatter, &c, tri);
+    pn_unpack_sym(tri, 3, MM);
+    pn_jacobi_svd(MM, 3, 3, W, V);                                      /* MM symmetric: its transpose is itself */
+    if (W[2] / W[1] < 1e-3) {                                           /* planar structure */
+        double Rt[9];
+        memcpy(Rt, V, sizeof(Rt));
+        if (V[2] * V[2] + V[5] * V[5] < 1e-10) { memset(Rt, 0, sizeof(Rt)); Rt[0] = Rt[4] = Rt[8] = 1; }
+        const double det = Rt[0] * (Rt[4] * Rt[8] - Rt[5] * Rt[7]) - Rt[1] * (Rt[3] * Rt[8] - Rt[5] * Rt[6]) + Rt[2] * (Rt[3] * Rt[7] - Rt[4] * Rt[6]);
+        if (det < 0) for (int k = 0; k < 9; k++) Rt[k] = Rt[k] * -1;
+        for (int i = 0; i < 3; i++) c.Tp[i] = (Rt[i * 3] * c.Mc[0] + Rt[i * 3 + 1] * c.Mc[1] + Rt[i * 3 + 2] * c.Mc[2]) * -1;
+        memcpy(c.Rp, Rt, sizeof(Rt));
+        double h[9], R[9];
+        int finite = pn_find_homography(n, mask, count, &c, h);
+        for (int k = 0; k < 9 && finite; k++) finite = isfinite(h[k]);
+        if (finite) {
+            const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
+            const double s3n = 2. / (h1n + h2n > DBL_EPSILON ? h1n + h2n : DBL_EPSILON);
+            double t3[3], rv[3], Hm[9];
+            for (int k = 0; k < 3; k++) { h[3 * k] *= s1; h[3 * k + 1] *= s2; t3[k] = h[3 * k + 2] * s3n; }
+            h[2] = h[3] * h[7] - h[6] * h[4];                            /* h3 = h1 x h2 */
+            h[5] = h[6] * h[1] - h[0] * h[7];
+            h[8] = h[0] * h[4] - h[3] * h[1];
+            pn_rodrigues_to_vec(h, rv);
+            pn_rodrigues_jac(rv, Hm, NULL);
+            for (int i = 0; i < 3; i++) param[3 + i] = (Hm[i * 3] * c.Tp[0] + Hm[i * 3 + 1] * c.Tp[1] + Hm[i * 3 + 2] * c.Tp[2]) + t3[i];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = Hm[i * 3] * Rt[j] + Hm[i * 3 + 1] * Rt[3 + j] + Hm[i * 3 + 2] * Rt[6 + j];
+        } else {
+            memset(R, 0, sizeof(R)); R[0] = R[4] = R[8] = 1;
+            param[3] = param[4] = param[5] = 0;
+        }
+        pn_rodrigues_to_vec(R, param);
+    } else {                                                            /* DLT */
+        if (count < 6) return 0;
+        double LL[144], LW[12], LV[144], RR[9], Ut[9], Vt[9], R[9];
+        pn_lane_sums(n, mask, 78, pn_t_dlt, &c, tri);
+        pn_unpack_sym(tri, 12, LL);
+        pn_jacobi_svd(LL, 12, 12, LW, LV);
+        double RRt[12];
+        memcpy(RRt, LV + 11 * 12, sizeof(RRt));
+        const double det = RRt[0] * (RRt[5] * RRt[10] - RRt[6] * RRt[9]) - RRt[1] * (RRt[4] * RRt[10] - RRt[6] * RRt[8]) + RRt[2] * (RRt[4] * RRt[9] - RRt[5] * RRt[8]);
+        if (det < 0) for (int k = 0; k < 12; k++) RRt[k] = RRt[k] * -1;
+        double sc = 0;                                                  /* cvNorm of the 3 x 3 part: row by row */
+        for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += RRt[i * 4 + j] * RRt[i * 4 + j]; sc += s; }
+        sc = sqrt(sc);
+        for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) Ut[j * 3 + i] = RRt[i * 4 + j];   /* transpose for the one-sided Jacobi */
+        pn_svd_full(Ut, 3, 3, W, Vt);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = Ut[i] * Vt[j] + Ut[3 + i] * Vt[3 + j] + Ut[6 + i] * Vt[6 + j];
+        double nr = 0;
+        nr += R[0] * R[0] + R[1] * R[1] + R[2] * R[2] + R[3] * R[3];
+        nr += R[4] * R[4] + R[5] * R[5] + R[6] * R[6] + R[7] * R[7];
+        nr += R[8] * R[8];
+        const double scale = sqrt(nr) / sc;
+        for (int k = 0; k < 3; k++) param[3 + k] = RRt[k * 4 + 3] * scale;
+        (void)RR;
+        pn_rodrigues_to_vec(R, param);
+    }
+    /* CvLevMarq solver(6, 2 count, {max_iter 20, FLT_EPSILON}, completeSymm) driven as cvFindExtrinsicCameraParams2 drives it */
+    int lambdaLg10 = -3, iters = 0;
+    double prev[6], JtJ[36], JtErr[6], tot[28], errNorm, prevErrNorm = DBL_MAX;
+    pn_rodrigues_jac(param, c.R, c.dRdr); memcpy(c.t, param + 3, sizeof(c.t)); c.want_j = 1;
+    pn_lane_sums(n, mask, 28, pn_t_lm, &c, tot);
+    for (;;) {
+        memcpy(JtErr, tot + 1, sizeof(JtErr)); pn_unpack_sym(tot + 7, 6, JtJ);
+        memcpy(prev, param, sizeof(prev));
+        pn_lm_step(JtJ, JtErr, prev, lambdaLg10, param);
+        if (iters == 0) prevErrNorm = sqrt(tot[0]);
+        for (;;) {
+            double e2;
+            pn_rodrigues_jac(param, c.R, NULL); memcpy(c.t, param + 3, sizeof(c.t)); c.want_j = 0;
+            pn_lane_sums(n, mask, 1, pn_t_lm, &c, &e2);
+            errNorm = sqrt(e2);
+            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) { pn_lm_step(JtJ, JtErr, prev, lambdaLg10, param); continue; }
+            break;
+        }
+        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+        if (++iters >= 20 || sqrt(pn_l2sqr6(param, prev)) / (sqrt(pn_l2sqr6(prev, NULL)) + DBL_EPSILON) < FLT_EPSILON) break;
+        prevErrNorm = errNorm;
+        pn_rodrigues_jac(param, c.R, c.dRdr); memcpy(c.t, param + 3, sizeof(c.t)); c.want_j = 1;
+        pn_lane_sums(n, mask, 28, pn_t_lm, &c, tot);
+    }
+    memcpy(rvec, param, sizeof(double) * 3); memcpy(tvec, param + 3, sizeof(double) * 3);
+    return 1;
+}
+
+static int g_pnp_refine = 1;          /* 1 = cv2's final solvePnP (default), 0 = the fast mode's minimiser */
+void voo_set_pnp_refine(int mode) { g_pnp_refine = mode != 0; }
+
 /* returns 0 and (rvec, tvec, inlier mask) like cv2.solvePnPRansac's retval True; -3: fewer than 4 points,
  * -4: no model (for exactly 4 points: P3P found no solution) */
 int voo_solve_pnp_ransac(const double* obj, const double* img, int n, const double* Kd, int iterations, double reproj_err,
@@ -922,11 +1479,22 @@ int voo_solve_pnp_ransac(const double* obj, const double* img, int n, const doub
             niters = pn_update_num_iters(confidence, (double)(n - good) / n, 5, niters);
         }
     }
-    free(cur); free(of);
-    if (max_good <= 0) { memset(mask, 0, (size_t)n); return -4; }
-    pn_refine(obj, img, mask, n, K, Rb, tb);               /* solvePnP(SOLVEPNP_ITERATIVE) on the inliers, in double */
-    pn_rodrigues_to_vec(Rb, rvec);
-    memcpy(tvec, tb, sizeof(tb));
+    free(cur);
+    if (max_good <= 0) { free(of); memset(mask, 0, (size_t)n); return -4; }
+    if (g_pnp_refine) {                                    /* solvePnP(SOLVEPNP_ITERATIVE) on the inliers, as cv2 runs it */
+        if (!pn_refine_cv2(of, imf, mask, n, K, rvec, tvec)) {           /* 5 non-planar inliers: the RANSAC model is the answer */
+            pn_rodrigues_to_vec(Rb, rvec);
+            memcpy(tvec, tb, sizeof(tb));
+        }
+    } else {                                               /* fast mode: the same cost minimised from the RANSAC model */
+        double* od = (double*)malloc(sizeof(double) * 5 * (size_t)n);   /* the inliers are the float32 points, as in cv2 */
+        for (int i = 0; i < 5 * n; i++) od[i] = (double)of[i];
+        pn_refine(od, od + 3 * (size_t)n, mask, n, K, Rb, tb);
+        free(od);
+        pn_rodrigues_to_vec(Rb, rvec);
+        memcpy(tvec, tb, sizeof(tb));
+    }
+    free(of);
     *n_inl = max_good;
     return 0;
 }

@@ -1,6 +1,7 @@
 """GPU parity of the localisation row: cv2.solvePnPRansac + cv2.Rodrigues
 (src/visual_slam.py:231-243) against the CPU oracle — identical inlier sets, poses to 1e-9 (the two differ only
-through libm's acos / cos / sin)."""
+through libm's acos / cos / sin).  Default mode on both sides: the final pose as cv2 computes it (solvePnP(ITERATIVE) on
+the consensus set: DLT or homography start + CvLevMarq); the fast mode is held against the oracle's and against it."""
 import numpy as np
 import pytest
 
@@ -126,3 +127,63 @@ def test_four_points_take_the_p3p_branch(oracle, ctx):
         if it % 2 == 0:                                      # noise-free: the true pose is among P3P's candidates and wins
             exact += np.abs(geometry.Rodrigues(rvec)[0] - R).max() < 1e-4 and np.abs(tvec.ravel() - t).max() < 1e-3
     assert exact >= 27                                        # float32 image points; a rare ambiguous configuration may pick a twin
+
+
+def planar_problem(seed, n, outl, noise=0.5):
+    X, uv, R, t, bad = problem(seed, n, 0.0, noise=0.0)
+    rng = np.random.default_rng(1000 + seed)
+    X[:, 2] = 0.3 * X[:, 0] - 0.2 * X[:, 1] + 1.0                      # all map points in one plane: cv2 starts from a homography
+    Xc = X @ R.T + t
+    uv = ((Xc / Xc[:, 2:]) @ K.T)[:, :2] + rng.normal(0, noise, (n, 2))
+    bad = rng.random(n) < outl
+    uv[bad] += rng.uniform(-100, 100, (int(bad.sum()), 2))
+    return X, uv, R, t, bad
+
+
+@pytest.fixture()
+def refine_modes(oracle, ctx):
+    def set_mode(m):
+        oracle.set_pnp_refine(m); ctx.set_pnp_refine(m)
+    yield set_mode
+    set_mode("cv2")
+
+
+@pytest.mark.parametrize("seed,n,outl", [(41, 300, 0.3), (42, 40, 0.1), (43, 9, 0.0), (44, 6, 0.0), (45, 1200, 0.5)])
+def test_planar_structure_takes_the_homography_start(oracle, ctx, seed, n, outl):
+    """cvFindExtrinsicCameraParams2's planar branch (W[2] / W[1] < 1e-3): findHomography (normalised DLT + LMSolver) start."""
+    from visual_odometry_amd import geometry
+    X, uv, R, t, bad = planar_problem(seed, n, outl)
+    rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(X, uv, K)
+    ok, rvec, tvec, inl = geometry.solvePnPRansac(X, uv, K, np.zeros(4))
+    assert ok and rc == 0
+    assert np.array_equal(inl.ravel(), np.nonzero(mask)[0])
+    assert np.abs(rvec.ravel() - rv).max() < 1e-8 and np.abs(tvec.ravel() - tv).max() < 1e-8
+    assert np.abs(geometry.Rodrigues(rvec)[0] - R).max() < 0.03 and np.abs(tvec.ravel() - t).max() < 0.15
+
+
+def test_fast_mode_equals_its_oracle_and_agrees_with_cv2_mode(oracle, ctx, refine_modes):
+    """vo_set_pnp_refine(0): same inlier sets; the pose is the same minimum reached from the RANSAC model (1e-9 against the
+    oracle's fast mode, 1e-6 against cv2's mode — which stops at a FLT_EPSILON step — wherever cv2's mode refines at all:
+    with exactly 5 non-planar inliers cv2 returns the RANSAC model itself, "DLT algorithm needs at least 6 points")."""
+    from visual_odometry_amd import geometry
+    five = 0
+    for seed in range(100, 170):
+        n = [8, 20, 100, 400][seed % 4]; outl = [0, 0.2, 0.5][seed % 3]
+        X, uv, *_ = problem(seed, n, outl)
+        refine_modes("cv2")
+        ok1, r1, t1, i1 = geometry.solvePnPRansac(X, uv, K, np.zeros(4))
+        rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(X, uv, K)
+        refine_modes("fast")
+        ok0, r0, t0, i0 = geometry.solvePnPRansac(X, uv, K, np.zeros(4))
+        rc0, rv0, tv0, mask0, _ = oracle.solve_pnp_ransac(X, uv, K)
+        assert ok0 == ok1 == (rc == 0) == (rc0 == 0)
+        if not ok0:
+            continue
+        assert np.array_equal(i0, i1) and np.array_equal(mask, mask0)
+        assert np.abs(r0.ravel() - rv0).max() < 1e-9 and np.abs(t0.ravel() - tv0).max() < 1e-9
+        assert np.abs(r1.ravel() - rv).max() < 1e-9 and np.abs(t1.ravel() - tv).max() < 1e-9
+        if ninl == 5:
+            five += 1                                                   # cv2 mode: the un-refined RANSAC model
+            continue
+        assert np.abs(r0 - r1).max() < 1e-6 and np.abs(t0 - t1).max() < 1e-6
+    assert five >= 1

@@ -338,6 +338,54 @@ def test_pnp_ransac_recovers_the_pose_and_the_lm_minimum(oracle, seed, n, outl):
     assert np.array_equal(rv, rv2) and np.array_equal(tv, tv2) and np.array_equal(mask, mask2)
 
 
+def test_pnp_final_pose_follows_cv2s_solvepnp_iterative(oracle):
+    """solvePnPRansac's last step, solvePnP(inliers, SOLVEPNP_ITERATIVE) = cvFindExtrinsicCameraParams2 (oracle/voo_pnp.c
+    pn_refine_cv2): the result is a stationary point of the pixel reprojection cost over the (float32) inliers; it equals
+    the fast mode's minimum to 1e-6; a planar map takes the homography start and still lands on the generating pose; and with
+    exactly 5 non-planar inliers cv2 keeps the RANSAC model ("DLT algorithm needs at least 6 points")."""
+    def cost_grad(X, uv, K, rv, tv, mask):
+        Xf = X.astype(np.float32).astype(np.float64)[mask > 0]; uf = uv.astype(np.float32).astype(np.float64)[mask > 0]
+        def cost(p):
+            Rm = oracle.rodrigues(p[:3]); Xc = Xf @ Rm.T + p[3:]
+            pr = np.stack([K[0, 0] * Xc[:, 0] / Xc[:, 2] + K[0, 2], K[1, 1] * Xc[:, 1] / Xc[:, 2] + K[1, 2]], 1)
+            return ((pr - uf) ** 2).sum()
+        p = np.concatenate([rv, tv]); g = np.zeros(6)
+        for k in range(6):
+            d = np.zeros(6); d[k] = 1e-6
+            g[k] = (cost(p + d) - cost(p - d)) / 2e-6
+        return cost(p), g
+    try:
+        five = 0
+        for seed in range(100, 170):
+            n = [8, 20, 100, 400][seed % 4]; outl = [0, 0.2, 0.5][seed % 3]
+            K, X, uv, R, t, bad = _pnp_problem(seed, n, outl)
+            oracle.set_pnp_refine("cv2"); rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(X, uv, K)
+            oracle.set_pnp_refine("fast"); rc0, rv0, tv0, mask0, _ = oracle.solve_pnp_ransac(X, uv, K)
+            assert rc == rc0
+            if rc:
+                continue
+            assert np.array_equal(mask, mask0)
+            if ninl == 5:
+                five += 1
+                continue
+            assert np.abs(rv - rv0).max() < 1e-6 and np.abs(tv - tv0).max() < 1e-6
+            c0, g = cost_grad(X, uv, K, rv, tv, mask)
+            assert np.abs(g).max() < 1e-3 * max(c0, 1.0)                # stationary (the cost is a sum of squared pixels)
+        assert five >= 1
+        oracle.set_pnp_refine("cv2")
+        for seed in range(5):                                           # planar structure: homography start
+            K, X, uv, R, t, bad = _pnp_problem(200 + seed, 150, 0.2)
+            X[:, 2] = 0.25 * X[:, 0] + 0.1 * X[:, 1] + 0.5
+            Xc = X @ R.T + t
+            uv2 = ((Xc / Xc[:, 2:]) @ K.T)[:, :2] + np.random.default_rng(seed).normal(0, 0.3, uv.shape)
+            uv2[bad] = uv[bad]
+            rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(X, uv2, K)
+            assert rc == 0 and ninl >= 100
+            assert np.abs(oracle.rodrigues(rv) - R).max() < 0.01 and np.abs(tv - t).max() < 0.05
+    finally:
+        oracle.set_pnp_refine("cv2")
+
+
 def test_pnp_error_codes_and_rodrigues(oracle):
     from scipy.spatial.transform import Rotation
     K, X, uv, *_ = _pnp_problem(3, 4, 0.0)

@@ -74,6 +74,7 @@ _SIGS = {
     "vo_sync": (C.c_int, [_P]),
     "vo_set_matcher_kernel": (C.c_int, [_P, C.c_int]),
     "vo_set_poly_solver": (C.c_int, [_P, C.c_int]),
+    "vo_set_pnp_refine": (C.c_int, [_P, C.c_int]),
     "vo_set_keypoint_order": (C.c_int, [_P, C.c_int]),
     "vo_stage_retain_best": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vo_detect_after": (C.c_int, [_P, _P]),
@@ -213,6 +214,11 @@ class Context:
         """'fast' (default): Durand-Kerner sweeps stop at the rounding-noise floor; 'opencv300': cv::solvePoly's fixed
         300 sweeps (the faithful, 10x slower form of the five-point solver's root finder)."""
         self.check(self.lib.vo_set_poly_solver(self.handle, {"fast": 0, "opencv300": 1}[kind]))
+
+    def set_pnp_refine(self, kind):
+        """'cv2' (default): solvePnPRansac's final pose as OpenCV computes it (DLT / homography start + CvLevMarq, <= 20
+        iterations); 'fast': the same cost minimised from the best RANSAC model."""
+        self.check(self.lib.vo_set_pnp_refine(self.handle, {"fast": 0, "cv2": 1}[kind]))
 
     def last_error(self) -> str:
         msg = self.lib.vo_last_error(self.handle)

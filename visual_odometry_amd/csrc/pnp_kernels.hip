@@ -430,8 +430,16 @@ __device__ static void dp_epnp(const double* pws, const double* us, int n, dp_ca
 }
 
 /* cv::Rodrigues, matrix -> vector (calibration.cpp cvRodrigues2) */
-__device__ static void dp_rodrigues_to_vec(const double* R, double* r)
+__device__ static void dp_rodrigues_to_vec(const double* Rin, double* r)
 {
+    double At[9], W[3], Vt[9], R[9];                      /* SVD::compute(R, W, U, Vt); R = U * Vt */
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) At[j * 3 + i] = Rin[i * 3 + j];
+    dp_jacobi_svd(At, 3, 3, W, Vt);
+    for (int i = 0; i < 3; i++) {                         /* JacobiSVD's normalisation of U */
+        const double s = W[i] > DBL_MIN ? 1 / W[i] : 0.;
+        for (int k = 0; k < 3; k++) At[i * 3 + k] *= s;
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = At[i] * Vt[j] + At[3 + i] * Vt[3 + j] + At[6 + i] * Vt[6 + j];
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
     double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
@@ -453,18 +461,18 @@ __device__ static void dp_rodrigues_to_vec(const double* R, double* r)
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
-/* cv::Rodrigues, vector -> matrix */
+/* cv::Rodrigues, vector -> matrix: R = cos(theta) I + (1 - cos(theta)) r r^T + sin(theta) [r]x, element by element */
 __device__ static void dp_rodrigues_to_mat(const double* r, double* R)
 {
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    if (theta < DBL_EPSILON) { memset(R, 0, sizeof(double) * 9); R[0] = R[4] = R[8] = 1; return; }
-    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
-    double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
-    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
-    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
-    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+    if (theta < DBL_EPSILON) { for (int k = 0; k < 9; k++) R[k] = I[k]; return; }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    const double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
 }
-
 
 __device__ static inline uint32_t dp_rng_next(uint64_t* state)
 {
@@ -579,12 +587,225 @@ __device__ static int dp_count_inliers(const double* obj, const double* img, int
     return good;
 }
 
+// ------------------------------------------------------------------ cv2's final pose: solvePnP(inliers, SOLVEPNP_ITERATIVE)
+// cvFindExtrinsicCameraParams2 (calib3d calibration.cpp) as solvePnPRansac calls it on the consensus set — the stages,
+// decisions and stopping rules of oracle/voo_pnp.c pn_refine_cv2 (which cites the OpenCV lines):
+//   mean / scatter of the object points -> planar (W[2] / W[1] < 1e-3: homography start) or DLT start (>= 6 inliers, else
+//   the RANSAC model is returned as cv2 does) -> CvLevMarq on (rvec, tvec), <= 20 iterations, FLT_EPSILON step rule.
+// Every sum over the points is taken by all 256 threads (interleaved partial sums added in thread order: the oracle's
+// order); the small dense algebra between the sums runs on thread 0 out of an LDS scratch area.  The symmetric
+// eigen-problems of the homography branch (cv::eigen, solve / invert with DECOMP_EIG) are taken through the one-sided
+// Jacobi SVD here — the same decomposition for a symmetric positive semi-definite matrix, to rounding.
+struct PnpLambdaTab { double v[33]; };
+struct DpRf {
+    dp_cam K;
+    double ifx, ify;
+    double Mc[3];
+    double Rp[9], Tp[3];
+    double cm[2], cM[2], sm[2], sM[2];
+    double h[8];
+    double R[9], t[3], dRdr[27];
+};
+enum { RF_SUM, RF_SCATTER, RF_DLT_A, RF_DLT_B, RF_HCENTRE, RF_HSCALE, RF_HLTL, RF_HLM, RF_LM };
+#define RF_RED 46                        /* widest set of sums taken in one pass (homography LM: 45 + the maximum) */
+
+__device__ static void dp_svd_full(double* At, int m, int n, double* W, double* Vt)
+{
+    dp_jacobi_svd(At, m, n, W, Vt);
+    for (int i = 0; i < n; i++) {
+        const double s = W[i] > DBL_MIN ? 1 / W[i] : 0.;
+        for (int k = 0; k < m; k++) At[i * m + k] *= s;
+    }
+}
+
+__device__ static void dp_backsubst(int m, int n, const double* W, const double* Ut, const double* Vt, const double* b, double* x)
+{
+    double thr = 0;
+    for (int i = 0; i < n; i++) { x[i] = 0; thr += W[i]; }
+    thr *= DBL_EPSILON * 2;
+    for (int i = 0; i < n; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= thr) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < m; j++) s += Ut[i * m + j] * b[j];
+        s *= wi;
+        for (int j = 0; j < n; j++) x[j] = x[j] + s * Vt[i * n + j];
+    }
+}
+
+/* cv::solve(A, b, x, DECOMP_SVD), A n x n; tmp: 2 n n + n doubles */
+__device__ static void dp_solve_svd(const double* A, int n, const double* b, double* x, double* tmp)
+{
+    double *At = tmp, *Vt = tmp + n * n, *W = tmp + 2 * n * n;
+    for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) At[j * n + i] = A[i * n + j];
+    dp_svd_full(At, n, n, W, Vt);
+    dp_backsubst(n, n, W, At, Vt, b, x);
+}
+
+/* cvRodrigues2, vector -> matrix with the Jacobian J[i * 9 + k] = d R_k / d r_i (J may be null) */
+__device__ static void dp_rodrigues_jac(const double* rv, double* R, double* J)
+{
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double theta = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (theta < DBL_EPSILON) {
+        for (int k = 0; k < 9; k++) R[k] = I[k];
+        if (J) { for (int k = 0; k < 27; k++) J[k] = 0; J[5] = J[15] = J[19] = -1; J[7] = J[11] = J[21] = 1; }
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    const double x = rv[0] * itheta, y = rv[1] * itheta, z = rv[2] * itheta;
+    const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    if (!J) return;
+    const double drrt[27] = {x + x, y, z, y, 0, 0, z, 0, 0,
+                             0, x, 0, x, y + y, z, 0, z, 0,
+                             0, 0, x, 0, 0, y, x, y, z + z};
+    const double d_r_x[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0,
+                              0, 0, 1, 0, 0, 0, -1, 0, 0,
+                              0, -1, 0, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+        const double ri = i == 0 ? x : i == 1 ? y : z;
+        const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+        const double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+        for (int k = 0; k < 9; k++)
+            J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x[i * 9 + k];
+    }
+}
+
+// the float32 points of the RANSAC stage, back in double (opoints.convertTo(opoints_inliers, CV_64F))
+__device__ static inline void dp_rf_point(const double* obj, const double* img, int i, double* M, double* m)
+{
+    M[0] = (double)(float)obj[3 * i]; M[1] = (double)(float)obj[3 * i + 1]; M[2] = (double)(float)obj[3 * i + 2];
+    m[0] = (double)(float)img[2 * i]; m[1] = (double)(float)img[2 * i + 1];
+}
+__device__ static inline void dp_rf_planar(const DpRf& c, const double* obj, const double* img, int i, double* Mf, double* mf)
+{
+    double M[3], m[2];
+    dp_rf_point(obj, img, i, M, m);
+    const double mn0 = (m[0] - c.K.uc) * c.ifx, mn1 = (m[1] - c.K.vc) * c.ify;
+    Mf[0] = (double)(float)(c.Rp[0] * M[0] + c.Rp[1] * M[1] + c.Rp[2] * M[2] + c.Tp[0]);
+    Mf[1] = (double)(float)(c.Rp[3] * M[0] + c.Rp[4] * M[1] + c.Rp[5] * M[2] + c.Tp[1]);
+    mf[0] = (double)(float)mn0; mf[1] = (double)(float)mn1;
+}
+
+// one point's terms of the sums of stage KIND (WANT_J: with the Jacobian products)
+template <int KIND, bool WANT_J>
+__device__ static inline void dp_rf_terms(const DpRf& c, const double* obj, const double* img, int i, double* acc)
+{
+    if (KIND == RF_SUM) {
+        double M[3], m[2];
+        dp_rf_point(obj, img, i, M, m);
+        acc[0] += M[0]; acc[1] += M[1]; acc[2] += M[2];
+    } else if (KIND == RF_SCATTER) {
+        double M[3], m[2];
+        dp_rf_point(obj, img, i, M, m);
+        const double d0 = M[0] - c.Mc[0], d1 = M[1] - c.Mc[1], d2 = M[2] - c.Mc[2];
+        acc[0] += d0 * d0; acc[1] += d0 * d1; acc[2] += d0 * d2; acc[3] += d1 * d1; acc[4] += d1 * d2; acc[5] += d2 * d2;
+    } else if (KIND == RF_DLT_A || KIND == RF_DLT_B) {                 // the 78 entries in two passes of 39
+        double M[3], m[2];
+        dp_rf_point(obj, img, i, M, m);
+        const double x = -((m[0] - c.K.uc) * c.ifx), y = -((m[1] - c.K.vc) * c.ify);
+        const double Lx[12] = {M[0], M[1], M[2], 1., 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
+        const double Ly[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1., y * M[0], y * M[1], y * M[2], y};
+        int q = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++)
+#pragma unroll
+            for (int k = j; k < 12; k++) {
+                if (KIND == RF_DLT_A ? q < 39 : q >= 39) acc[KIND == RF_DLT_A ? q : q - 39] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+                q++;
+            }
+    } else if (KIND == RF_HCENTRE) {
+        double M[2], m[2];
+        dp_rf_planar(c, obj, img, i, M, m);
+        acc[0] += m[0]; acc[1] += m[1]; acc[2] += M[0]; acc[3] += M[1];
+    } else if (KIND == RF_HSCALE) {
+        double M[2], m[2];
+        dp_rf_planar(c, obj, img, i, M, m);
+        acc[0] += fabs(m[0] - c.cm[0]); acc[1] += fabs(m[1] - c.cm[1]); acc[2] += fabs(M[0] - c.cM[0]); acc[3] += fabs(M[1] - c.cM[1]);
+    } else if (KIND == RF_HLTL) {
+        double M[2], m[2];
+        dp_rf_planar(c, obj, img, i, M, m);
+        const double x = (m[0] - c.cm[0]) * c.sm[0], y = (m[1] - c.cm[1]) * c.sm[1];
+        const double X = (M[0] - c.cM[0]) * c.sM[0], Y = (M[1] - c.cM[1]) * c.sM[1];
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        int q = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++) acc[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    } else if (KIND == RF_HLM) {                                       // acc = [|r|^2, J^T r (8), J^T J (36), max |r|]
+        double M[2], m[2];
+        dp_rf_planar(c, obj, img, i, M, m);
+        const double* h = c.h;
+        double ww = h[6] * M[0] + h[7] * M[1] + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        const double xi = (h[0] * M[0] + h[1] * M[1] + h[2]) * ww, yi = (h[3] * M[0] + h[4] * M[1] + h[5]) * ww;
+        const double ex = xi - m[0], ey = yi - m[1];
+        acc[0] += ex * ex + ey * ey;
+        if (WANT_J) {
+            const double Jx[8] = {M[0] * ww, M[1] * ww, ww, 0, 0, 0, -M[0] * ww * xi, -M[1] * ww * xi};
+            const double Jy[8] = {0, 0, 0, M[0] * ww, M[1] * ww, ww, -M[0] * ww * yi, -M[1] * ww * yi};
+            int q = 9;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                acc[1 + r] += Jx[r] * ex + Jy[r] * ey;
+#pragma unroll
+                for (int s2 = r; s2 < 8; s2++) acc[q++] += Jx[r] * Jx[s2] + Jy[r] * Jy[s2];
+            }
+            acc[45] = fmax(acc[45], fmax(fabs(ex), fabs(ey)));
+        }
+    } else {                                                           // RF_LM: acc = [|e|^2, J^T e (6), J^T J (21)]
+        double M[3], m[2];
+        dp_rf_point(obj, img, i, M, m);
+        const double* R = c.R; const double* t = c.t;
+        const double X = M[0], Y = M[1], Z = M[2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+        double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+        double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        const double eu = x * c.K.fu + c.K.uc - m[0], ev = y * c.K.fv + c.K.vc - m[1];
+        acc[0] += eu * eu + ev * ev;
+        if (WANT_J) {
+            const double* dRdr = c.dRdr;
+            double Ju[6], Jv[6];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double dx0 = X * dRdr[9 * j] + Y * dRdr[9 * j + 1] + Z * dRdr[9 * j + 2];
+                const double dy0 = X * dRdr[9 * j + 3] + Y * dRdr[9 * j + 4] + Z * dRdr[9 * j + 5];
+                const double dz0 = X * dRdr[9 * j + 6] + Y * dRdr[9 * j + 7] + Z * dRdr[9 * j + 8];
+                Ju[j] = c.K.fu * (z * (dx0 - x * dz0));
+                Jv[j] = c.K.fv * (z * (dy0 - y * dz0));
+            }
+            Ju[3] = c.K.fu * z; Ju[4] = 0; Ju[5] = c.K.fu * (-x * z);
+            Jv[3] = 0; Jv[4] = c.K.fv * z; Jv[5] = c.K.fv * (-y * z);
+            int q = 7;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                acc[1 + r] += Ju[r] * eu + Jv[r] * ev;
+#pragma unroll
+                for (int s2 = r; s2 < 6; s2++) acc[q++] += Ju[r] * Ju[s2] + Jv[r] * Jv[s2];
+            }
+        }
+    }
+}
+
 #define PNP_STREAM 448
 struct PnpShared {
     double Rt[64][12];                  // hypotheses of the round
     union {
         double red[DP_LANES][28];       // per-thread partial sums of the normal equations (refinement)
         double ws[DP_WS_ELEMS * DP_WS_LANES];   // EPnP's 12 x 12 eigen-problem, one slice per lane (hypothesis rounds)
+        struct {                            // cv2's final solvePnP (dp_refine_cv2)
+            double red2[DP_LANES][RF_RED];  // per-thread partial sums
+            double scr[640];                // thread 0's matrices
+            double tot[80];                 // reduced sums
+            DpRf c;                         // what the point terms read
+        } rf;
     };
     double cand[12];                    // candidate (R, t) of the Levenberg-Marquardt step
     double tot[28];                     // reduced normal equations
@@ -892,6 +1113,307 @@ __device__ static int dq_solve(const double* obj, const double* img, dp_cam K, d
     return nb;
 }
 
+// NQ sums of stage KIND over the masked points -> sh.rf.tot[off .. off + NQ): per-thread partial sums over i = tid, tid + 256, ...,
+// added in thread order by thread q (one sum each).  Called by all 256 threads; ends with a barrier.
+template <int KIND, bool WANT_J, int NQ>
+__device__ static void dp_rf_sums(PnpShared& sh, const double* obj, const double* img, const uint8_t* mask, int n, int tid, int off = 0)
+{
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = 0;
+    for (int i = tid; i < n; i += DP_LANES)
+        if (mask[i]) dp_rf_terms<KIND, WANT_J>(sh.rf.c, obj, img, i, acc);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) sh.rf.red2[tid][q] = acc[q];
+    __syncthreads();
+    if (tid < NQ) {
+        double a = 0;
+        if (KIND == RF_HLM && WANT_J && tid == 45) { for (int k = 0; k < DP_LANES; k++) a = fmax(a, sh.rf.red2[k][45]); }
+        else for (int k = 0; k < DP_LANES; k++) a += sh.rf.red2[k][tid];
+        sh.rf.tot[off + tid] = a;
+    }
+    __syncthreads();
+}
+
+__device__ static void dp_unpack_sym(const double* tri, int n, double* A)
+{
+    int q = 0;
+    for (int r = 0; r < n; r++) for (int s2 = r; s2 < n; s2++) { A[r * n + s2] = tri[q]; A[s2 * n + r] = tri[q]; q++; }
+}
+
+__device__ static double dp_l2sqr6(const double* a, const double* b)
+{
+    double v[6];
+    for (int i = 0; i < 6; i++) v[i] = b ? a[i] - b[i] : a[i];
+    double s = 0;
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    s += v[4] * v[4];
+    s += v[5] * v[5];
+    return s;
+}
+
+// all 256 threads; thread 0 writes (rvec, tvec)
+__device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const double* img, const uint8_t* mask, int n, int count, dp_cam K,
+                                     const double* bestRt, const double* lam_tab /* 10^k, k = -16 .. 16 */, int tid, double* rvec_out, double* tvec_out)
+{
+    DpRf& c = sh.rf.c;
+    double* tot = sh.rf.tot;
+    double* scr = sh.rf.scr;
+    double* param = scr + 620;                               // the six pose parameters (rvec, tvec)
+    __syncthreads();                                         // the union's previous users (hypothesis rounds) are done
+    if (tid == 0) { c.K = K; c.ifx = 1. / K.fu; c.ify = 1. / K.fv; }
+    __syncthreads();
+    dp_rf_sums<RF_SUM, false, 3>(sh, obj, img, mask, n, tid);
+    if (tid == 0) { const double inv = 1. / count; for (int k = 0; k < 3; k++) c.Mc[k] = tot[k] * inv; }
+    __syncthreads();
+    dp_rf_sums<RF_SCATTER, false, 6>(sh, obj, img, mask, n, tid);
+    if (tid == 0) {
+        double *MM = scr, *W = scr + 9, *V = scr + 12;
+        dp_unpack_sym(tot, 3, MM);
+        dp_jacobi_svd(MM, 3, 3, W, V);
+        int mode = 0;
+        if (W[2] / W[1] < 1e-3) {
+            mode = 1;
+            double Rt[9];
+            for (int k = 0; k < 9; k++) Rt[k] = V[k];
+            if (V[2] * V[2] + V[5] * V[5] < 1e-10) { for (int k = 0; k < 9; k++) Rt[k] = 0; Rt[0] = Rt[4] = Rt[8] = 1; }
+            const double det = Rt[0] * (Rt[4] * Rt[8] - Rt[5] * Rt[7]) - Rt[1] * (Rt[3] * Rt[8] - Rt[5] * Rt[6]) + Rt[2] * (Rt[3] * Rt[7] - Rt[4] * Rt[6]);
+            if (det < 0) for (int k = 0; k < 9; k++) Rt[k] = Rt[k] * -1;
+            for (int i = 0; i < 3; i++) c.Tp[i] = (Rt[i * 3] * c.Mc[0] + Rt[i * 3 + 1] * c.Mc[1] + Rt[i * 3 + 2] * c.Mc[2]) * -1;
+            for (int k = 0; k < 9; k++) c.Rp[k] = Rt[k];
+        } else if (count < 6) mode = 2;
+        sh.ctrl = mode;
+    }
+    __syncthreads();
+    const int mode = sh.ctrl;
+    __syncthreads();
+    if (mode == 2) {                                         // cv2: "DLT algorithm needs at least 6 points" -> the RANSAC model
+        if (tid == 0) {
+            double r[3];
+            dp_rodrigues_to_vec(bestRt, r);
+            for (int k = 0; k < 3; k++) { rvec_out[k] = r[k]; tvec_out[k] = bestRt[9 + k]; }
+        }
+        return;
+    }
+    if (mode == 1) {                                         // planar structure: homography start
+        double *H = scr + 510;
+        dp_rf_sums<RF_HCENTRE, false, 4>(sh, obj, img, mask, n, tid);
+        if (tid == 0) { c.cm[0] = tot[0] / count; c.cm[1] = tot[1] / count; c.cM[0] = tot[2] / count; c.cM[1] = tot[3] / count; }
+        __syncthreads();
+        dp_rf_sums<RF_HSCALE, false, 4>(sh, obj, img, mask, n, tid);
+        if (tid == 0) {
+            const int ok = !(fabs(tot[0]) < DBL_EPSILON || fabs(tot[1]) < DBL_EPSILON || fabs(tot[2]) < DBL_EPSILON || fabs(tot[3]) < DBL_EPSILON);
+            if (ok) { c.sm[0] = count / tot[0]; c.sm[1] = count / tot[1]; c.sM[0] = count / tot[2]; c.sM[1] = count / tot[3]; }
+            sh.ctrl = ok;
+        }
+        __syncthreads();
+        const int have_h = sh.ctrl;
+        __syncthreads();
+        if (have_h) {
+            dp_rf_sums<RF_HLTL, false, 45>(sh, obj, img, mask, n, tid);
+            if (tid == 0) {
+                double *LtL = scr, *W = scr + 81, *V = scr + 96;
+                dp_unpack_sym(tot, 9, LtL);
+                dp_jacobi_svd(LtL, 9, 9, W, V);              // symmetric: eigenvectors = right singular vectors
+                const double* H0 = V + 72;
+                const double invHnorm[9] = {1. / c.sm[0], 0, c.cm[0], 0, 1. / c.sm[1], c.cm[1], 0, 0, 1};
+                const double Hnorm2[9] = {c.sM[0], 0, -c.cM[0] * c.sM[0], 0, c.sM[1], -c.cM[1] * c.sM[1], 0, 0, 1};
+                double Ht[9], H1[9];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ht[i * 3 + j] = invHnorm[i * 3] * H0[j] + invHnorm[i * 3 + 1] * H0[3 + j] + invHnorm[i * 3 + 2] * H0[6 + j];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) H1[i * 3 + j] = Ht[i * 3] * Hnorm2[j] + Ht[i * 3 + 1] * Hnorm2[3 + j] + Ht[i * 3 + 2] * Hnorm2[6 + j];
+                const double sc = 1. / H1[8];
+                for (int k = 0; k < 9; k++) H[k] = H1[k] * sc;
+                for (int k = 0; k < 8; k++) c.h[k] = H[k];
+            }
+            __syncthreads();
+            if (count > 4) {                                 // LMSolver (levmarq.cpp): 10 iterations, FLT_EPSILON
+                double *A = scr + 200, *Ap = scr + 264, *tmp = scr + 328, *v = scr + 470, *D = scr + 478, *d = scr + 486, *x = scr + 494, *xd = scr + 502;
+                double S = 0, lambda = 1, lc = 0.75, r_inf = 0;
+                int iter = 0;
+                dp_rf_sums<RF_HLM, true, 46>(sh, obj, img, mask, n, tid);
+                if (tid == 0) {
+                    S = tot[0]; r_inf = tot[45];
+                    for (int k = 0; k < 8; k++) { v[k] = tot[1 + k]; x[k] = H[k]; }
+                    dp_unpack_sym(tot + 9, 8, A);
+                    for (int i = 0; i < 8; i++) D[i] = A[i * 8 + i];
+                }
+                for (;;) {
+                    if (tid == 0) {
+                        for (int k = 0; k < 64; k++) Ap[k] = A[k];
+                        for (int i = 0; i < 8; i++) Ap[i * 8 + i] += lambda * D[i];
+                        dp_solve_svd(Ap, 8, v, d, tmp);
+                        for (int i = 0; i < 8; i++) { xd[i] = x[i] - d[i]; c.h[i] = xd[i]; }
+                    }
+                    __syncthreads();
+                    dp_rf_sums<RF_HLM, false, 1>(sh, obj, img, mask, n, tid);
+                    if (tid == 0) {
+                        const double Sd = tot[0];
+                        double dS = 0, td = 0;
+                        for (int i = 0; i < 8; i++) {
+                            double s = 0;
+                            for (int k = 0; k < 8; k++) s += A[i * 8 + k] * d[k];
+                            dS += d[i] * (s * -1 + v[i] * 2);
+                            td += d[i] * v[i];
+                        }
+                        const double Rr = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+                        if (Rr > 0.75) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+                        else if (Rr < 0.25) {
+                            double nu = (Sd - S) / (fabs(td) > DBL_EPSILON ? td : 1) + 2;
+                            nu = nu > 2. ? nu : 2.; nu = nu < 10. ? nu : 10.;
+                            if (lambda == 0) {               // max |diagonal| of the inverse of A
+                                double *At = tmp, *Vt = tmp + 64, *W = tmp + 128;
+                                for (int j = 0; j < 8; j++) for (int i = 0; i < 8; i++) At[j * 8 + i] = A[i * 8 + j];
+                                dp_svd_full(At, 8, 8, W, Vt);
+                                double thr = 0, maxval = DBL_EPSILON;
+                                for (int i = 0; i < 8; i++) thr += W[i];
+                                thr *= DBL_EPSILON * 2;
+                                for (int i = 0; i < 8; i++) {
+                                    double s = 0;
+                                    for (int k = 0; k < 8; k++) { if (fabs(W[k]) <= thr) continue; s += Vt[k * 8 + i] * (At[k * 8 + i] * (1 / W[k])); }
+                                    maxval = fmax(maxval, fabs(s));
+                                }
+                                lambda = lc = 1. / maxval;
+                                nu *= 0.5;
+                            }
+                            lambda *= nu;
+                        }
+                        const int better = Sd < S;
+                        if (better) { S = Sd; for (int k = 0; k < 8; k++) { x[k] = xd[k]; c.h[k] = x[k]; } }
+                        sh.ctrl = better;
+                    }
+                    __syncthreads();
+                    const int better = sh.ctrl;
+                    __syncthreads();
+                    if (better) {
+                        dp_rf_sums<RF_HLM, true, 46>(sh, obj, img, mask, n, tid);
+                        if (tid == 0) { r_inf = tot[45]; for (int k = 0; k < 8; k++) v[k] = tot[1 + k]; dp_unpack_sym(tot + 9, 8, A); }
+                    }
+                    if (tid == 0) {
+                        iter++;
+                        double d_inf = 0;
+                        for (int i = 0; i < 8; i++) d_inf = fmax(d_inf, fabs(d[i]));
+                        sh.ctrl = iter < 10 && d_inf >= FLT_EPSILON && r_inf >= FLT_EPSILON;
+                    }
+                    __syncthreads();
+                    const int proceed = sh.ctrl;
+                    __syncthreads();
+                    if (!proceed) break;
+                }
+                if (tid == 0) for (int k = 0; k < 8; k++) H[k] = x[k];
+            }
+        }
+        if (tid == 0) {
+            double h[9], R[9];
+            int finite = have_h;
+            for (int k = 0; k < 9; k++) { h[k] = H[k]; finite = finite && isfinite(h[k]); }
+            if (finite) {
+                const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+                const double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
+                const double s3n = 2. / (h1n + h2n > DBL_EPSILON ? h1n + h2n : DBL_EPSILON);
+                double t3[3], rv[3], Hm[9];
+                for (int k = 0; k < 3; k++) { h[3 * k] *= s1; h[3 * k + 1] *= s2; t3[k] = h[3 * k + 2] * s3n; }
+                h[2] = h[3] * h[7] - h[6] * h[4];
+                h[5] = h[6] * h[1] - h[0] * h[7];
+                h[8] = h[0] * h[4] - h[3] * h[1];
+                dp_rodrigues_to_vec(h, rv);
+                dp_rodrigues_jac(rv, Hm, nullptr);
+                for (int i = 0; i < 3; i++) param[3 + i] = (Hm[i * 3] * c.Tp[0] + Hm[i * 3 + 1] * c.Tp[1] + Hm[i * 3 + 2] * c.Tp[2]) + t3[i];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = Hm[i * 3] * c.Rp[j] + Hm[i * 3 + 1] * c.Rp[3 + j] + Hm[i * 3 + 2] * c.Rp[6 + j];
+            } else {
+                for (int k = 0; k < 9; k++) R[k] = 0;
+                R[0] = R[4] = R[8] = 1;
+                param[3] = param[4] = param[5] = 0;
+            }
+            double rv[3];
+            dp_rodrigues_to_vec(R, rv);
+            for (int k = 0; k < 3; k++) param[k] = rv[k];
+        }
+    } else {                                                 // DLT
+        dp_rf_sums<RF_DLT_A, false, 39>(sh, obj, img, mask, n, tid, 0);
+        dp_rf_sums<RF_DLT_B, false, 39>(sh, obj, img, mask, n, tid, 39);
+        if (tid == 0) {
+            double *LL = scr, *LW = scr + 144, *LV = scr + 160;
+            dp_unpack_sym(tot, 12, LL);
+            dp_jacobi_svd(LL, 12, 12, LW, LV);
+            double RRt[12], Ut[9], Vt[9], W[3], R[9];
+            for (int k = 0; k < 12; k++) RRt[k] = LV[11 * 12 + k];
+            const double det = RRt[0] * (RRt[5] * RRt[10] - RRt[6] * RRt[9]) - RRt[1] * (RRt[4] * RRt[10] - RRt[6] * RRt[8]) + RRt[2] * (RRt[4] * RRt[9] - RRt[5] * RRt[8]);
+            if (det < 0) for (int k = 0; k < 12; k++) RRt[k] = RRt[k] * -1;
+            double sc = 0;
+            for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += RRt[i * 4 + j] * RRt[i * 4 + j]; sc += s; }
+            sc = sqrt(sc);
+            for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) Ut[j * 3 + i] = RRt[i * 4 + j];
+            dp_svd_full(Ut, 3, 3, W, Vt);
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = Ut[i] * Vt[j] + Ut[3 + i] * Vt[3 + j] + Ut[6 + i] * Vt[6 + j];
+            double nr = 0;
+            nr += R[0] * R[0] + R[1] * R[1] + R[2] * R[2] + R[3] * R[3];
+            nr += R[4] * R[4] + R[5] * R[5] + R[6] * R[6] + R[7] * R[7];
+            nr += R[8] * R[8];
+            const double scale = sqrt(nr) / sc;
+            for (int k = 0; k < 3; k++) param[3 + k] = RRt[k * 4 + 3] * scale;
+            double rv[3];
+            dp_rodrigues_to_vec(R, rv);
+            for (int k = 0; k < 3; k++) param[k] = rv[k];
+        }
+    }
+    // CvLevMarq as cvFindExtrinsicCameraParams2 drives it
+    double *JtJ = scr, *Aw = scr + 36, *tmp = scr + 72, *JtErr = scr + 150, *prev = scr + 156, *dx = scr + 168;
+    int lambdaLg10 = -3, iters = 0;
+    double errNorm = 0, prevErrNorm = DBL_MAX;
+    auto set_pose = [&](bool with_j) {                       // thread 0: the evaluation point of the next sums
+        double R[9], J[27];
+        dp_rodrigues_jac(param, R, with_j ? J : nullptr);
+        for (int k = 0; k < 9; k++) c.R[k] = R[k];
+        if (with_j) for (int k = 0; k < 27; k++) c.dRdr[k] = J[k];
+        for (int k = 0; k < 3; k++) c.t[k] = param[3 + k];
+    };
+    auto step = [&]() {                                      // CvLevMarq::step
+        const double lambda = lam_tab[lambdaLg10 + 16];
+        for (int k = 0; k < 36; k++) Aw[k] = JtJ[k];
+        for (int i = 0; i < 6; i++) Aw[i * 6 + i] *= 1. + lambda;
+        dp_solve_svd(Aw, 6, JtErr, dx, tmp);
+        for (int i = 0; i < 6; i++) param[i] = prev[i] - dx[i];
+    };
+    if (tid == 0) set_pose(true);
+    __syncthreads();
+    dp_rf_sums<RF_LM, true, 28>(sh, obj, img, mask, n, tid);
+    for (;;) {
+        if (tid == 0) {
+            for (int k = 0; k < 6; k++) { JtErr[k] = tot[1 + k]; prev[k] = param[k]; }
+            dp_unpack_sym(tot + 7, 6, JtJ);
+            step();
+            if (iters == 0) prevErrNorm = sqrt(tot[0]);
+            set_pose(false);
+        }
+        __syncthreads();
+        for (;;) {
+            dp_rf_sums<RF_LM, false, 1>(sh, obj, img, mask, n, tid);
+            if (tid == 0) {
+                errNorm = sqrt(tot[0]);
+                int again = 0;
+                if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) { step(); set_pose(false); again = 1; }
+                sh.ctrl = again;
+            }
+            __syncthreads();
+            const int again = sh.ctrl;
+            __syncthreads();
+            if (!again) break;
+        }
+        if (tid == 0) {
+            lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+            const int stop = ++iters >= 20 || sqrt(dp_l2sqr6(param, prev)) / (sqrt(dp_l2sqr6(prev, nullptr)) + DBL_EPSILON) < FLT_EPSILON;
+            if (!stop) { prevErrNorm = errNorm; set_pose(true); }
+            sh.ctrl = stop;
+        }
+        __syncthreads();
+        const int stop = sh.ctrl;
+        __syncthreads();
+        if (stop) break;
+        dp_rf_sums<RF_LM, true, 28>(sh, obj, img, mask, n, tid);
+    }
+    if (tid == 0) for (int k = 0; k < 3; k++) { rvec_out[k] = param[k]; tvec_out[k] = param[3 + k]; }
+}
+
 // sum of the 256 partials in thread order (the oracle's order), one of the 28 sums per thread: called by every thread
 // after the barrier that follows the writes of sh.red; ends with a barrier, after which sh.tot is valid
 __device__ static void dp_reduce(PnpShared& sh, int tid)
@@ -906,7 +1428,7 @@ __device__ static void dp_reduce(PnpShared& sh, int tid)
 
 __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const double* img_all, const int* offsets, const double* Kd,
                                                     int iterations, double reproj_err, double confidence, uint64_t seed,
-                                                    const uint32_t* rng_tab, int rng_n,
+                                                    const uint32_t* rng_tab, int rng_n, int refine_cv2, PnpLambdaTab lam,
                                                     double* rvec_out, double* tvec_out, uint8_t* mask_all, int* ninl_out, int* status_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn_pnp[];   // 160 KB: more than the static limit
@@ -1051,7 +1573,12 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
     if (tid == 0) { status_out[pb] = VO_OK; ninl_out[pb] = max_good; } return;
 #endif
 
-    // solvePnP(SOLVEPNP_ITERATIVE) on the inliers: Levenberg-Marquardt on the pixel reprojection error
+    if (refine_cv2) {                                       // solvePnP(SOLVEPNP_ITERATIVE) on the inliers as cv2 runs it
+        dp_refine_cv2(sh, obj, img, mask, n, max_good, K, bestRt, lam.v, tid, rvec_out + 3 * pb, tvec_out + 3 * pb);
+        if (tid == 0) { status_out[pb] = VO_OK; ninl_out[pb] = max_good; }
+        return;
+    }
+    // fast mode: the same cost (pixel reprojection error over the inliers) minimised from the best RANSAC model
     double R[9], t[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = bestRt[k];
@@ -1062,7 +1589,11 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
 #pragma unroll
         for (int q = 0; q < 28; q++) acc[q] = 0;
         for (int i = tid; i < n; i += DP_LANES)
-            if (mask[i]) dp_point_terms(obj + 3 * i, img + 2 * i, Rc, tc, K, want_j, acc);
+            if (mask[i]) {                                  // the inliers are the float32 points of the RANSAC stage, as in cv2
+                const double Xw[3] = {(double)(float)obj[3 * i], (double)(float)obj[3 * i + 1], (double)(float)obj[3 * i + 2]};
+                const double uv[2] = {(double)(float)img[2 * i], (double)(float)img[2 * i + 1]};
+                dp_point_terms(Xw, uv, Rc, tc, K, want_j, acc);
+            }
         __syncthreads();                                    // the previous reduction has been read
 #pragma unroll
         for (int q = 0; q < 28; q++) sh.red[tid][q] = acc[q];
@@ -1143,14 +1674,17 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* obj_all, const
 
 void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, const int* offsets, int B, const double* Kd,
                        int iterations, double reproj_err, double confidence, uint64_t seed, const uint32_t* rng_tab, int rng_n,
-                       double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status)
+                       int refine_cv2, double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status)
 {
     if (B <= 0) return;
+    PnpLambdaTab lam;                                        // CvLevMarq::step: lambda = exp(lambdaLg10 * log(10.)), from the host's libm
+    const double LOG10 = log(10.);
+    for (int k = -16; k <= 16; k++) lam.v[k + 16] = exp(k * LOG10);
     static_assert(sizeof(PnpShared) <= 160 * 1024, "one workgroup's LDS");
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_pnp_ransac, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PnpShared)); attr = true; }
     hipLaunchKernelGGL(k_pnp_ransac, dim3(B), dim3(256), sizeof(PnpShared), s, obj, img, offsets, Kd, iterations, reproj_err, confidence, seed,
-                       rng_tab, rng_n, rvec, tvec, mask, ninl, status);
+                       rng_tab, rng_n, refine_cv2, lam, rvec, tvec, mask, ninl, status);
 }
 
 // cv2.Rodrigues for the Python shim (a 3-vector or a 3x3 matrix in, the other out): one thread

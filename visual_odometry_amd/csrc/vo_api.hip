@@ -89,6 +89,7 @@ struct vo_ctx {
     int kp_order = 1;                     // 1 (default): cv2's retainBest order — keypoint / match indices as cv2 numbers them; 0: canonical (octave, y, x)
     Cv2Buf cv2{};
     bool cv2_ready = false;
+    int pnp_refine = 1;                   // solvePnPRansac's final pose: 1 = cv2's solvePnP(ITERATIVE) (default), 0 = fast minimiser
     int dk_early = 1;                     // five-point polynomial roots: 1 = noise-floor exit (default), 0 = fixed 300 sweeps
 };
 
@@ -410,6 +411,14 @@ extern "C" int vo_set_poly_solver(vo_ctx* ctx, int kind)
     if (!ctx) return VO_ERR_INVALID;
     if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "poly solver must be 0 (noise-floor exit) or 1 (OpenCV's fixed 300 sweeps)");
     ctx->dk_early = kind == 0;
+    return VO_OK;
+}
+
+extern "C" int vo_set_pnp_refine(vo_ctx* ctx, int kind)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (kind != 0 && kind != 1) FAIL(VO_ERR_INVALID, "pnp refine must be 1 (cv2's solvePnP(ITERATIVE) on the inliers) or 0 (fast minimiser from the RANSAC model)");
+    ctx->pnp_refine = kind;
     return VO_OK;
 }
 
@@ -1486,7 +1495,7 @@ extern "C" int vo_solve_pnp_ransac_batch(vo_ctx* ctx, const double* obj, const d
     HIPCHK(hipMemcpyAsync(doff, off.data(), (size_t)(B + 1) * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));                                 // `off` is a stack vector
     { StageTimer t(ctx, ST_MISC); launch_pnp_ransac(s, dobj, dimg, doff, B, dK, iterations, reproj_err, confidence, seed, ctx->rng_tab, RNG_TAB_N,
-                                                   drv, dtv, dmask, dninl, dst); }
+                                                   ctx->pnp_refine, drv, dtv, dmask, dninl, dst); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(rvec, drv, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(tvec, dtv, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToHost, s));

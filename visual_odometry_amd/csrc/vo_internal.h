@@ -202,7 +202,7 @@ void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, con
 
 void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, const int* offsets, int B, const double* Kd,
                        int iterations, double reproj_err, double confidence, uint64_t seed, const uint32_t* rng_tab, int rng_n,
-                       double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status);
+                       int refine_cv2, double* rvec, double* tvec, uint8_t* mask, int* ninl, int* status);
 void launch_rodrigues(hipStream_t s, const double* in, int in_is_matrix, double* out);
 void launch_blur(hipStream_t s, const uint8_t* pyr, uint8_t* blur, const PyrGeom& g, int F);
 void launch_brief(hipStream_t s, const uint8_t* blur, const PyrGeom& g, FrameFeat ff, int F, uint8_t* desc_x, int cap_x, int fp4);
