@@ -1152,6 +1152,95 @@ __device__ static double dp_l2sqr6(const double* a, const double* b)
     return s;
 }
 
+// ---- wave-cooperative dense algebra for the serial sections (wave 0 only; the other waves wait at the next barrier)
+#define DP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+template <int CTRL>
+__device__ static inline double dp_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row (butterfly: every lane of the row ends with the same bits), lane 0's to the whole wave
+__device__ static inline double dp_row0_sum(double v)
+{
+    v += dp_dpp<0xB1>(v);                                    // quad_perm [1,0,3,2]
+    v += dp_dpp<0x4E>(v);                                    // quad_perm [2,3,0,1]
+    v += dp_dpp<0x141>(v);                                   // row_half_mirror
+    v += dp_dpp<0x140>(v);                                   // row_mirror
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// JacobiSVDImpl_ (lapack.cpp) by one wavefront: lane k < m owns column k of At (n rows of length m), lane m + k column k of Vt;
+// same pair order, rotation formulas, convergence test and final ordering as dp_jacobi_svd — the dot products over a row are
+// butterfly sums over the lanes instead of left-to-right sums.  m <= 16, m + n <= 64.  At, W, Vt in LDS.
+__device__ static void dp_svd_wave(double* At, int m, int n, double* W, double* Vt, int lane, bool normalise_u)
+{
+    const bool isA = lane < m, isV = lane >= m && lane < m + n, act = isA || isV;
+    double* col = isA ? At + lane : Vt + (isV ? lane - m : 0);
+    const int st = isA ? m : n;
+    DP_WAVE_SYNC();
+    for (int i = 0; i < n; i++) {
+        const double v = isA ? col[i * m] : 0.;
+        W[i] = dp_row0_sum(v * v);
+        if (isV) col[i * n] = lane - m == i ? 1. : 0.;
+    }
+    const double eps = DBL_EPSILON * 10;
+    const int max_iter = m > 30 ? m : 30;
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                const double xi = act ? col[i * st] : 0., xj = act ? col[j * st] : 0.;
+                double a = W[i], b = W[j];
+                double p = dp_row0_sum(isA ? xi * xj : 0.);
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = dp_hypot(p, beta), c, s;
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                const double t0 = c * xi + s * xj, t1 = -s * xi + c * xj;
+                if (act) { col[i * st] = t0; col[j * st] = t1; }
+                W[i] = dp_row0_sum(isA ? t0 * t0 : 0.);
+                W[j] = dp_row0_sum(isA ? t1 * t1 : 0.);
+                changed = true;
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        const double v = isA ? col[i * m] : 0.;
+        W[i] = sqrt(dp_row0_sum(v * v));
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            const double wi = W[i], wj = W[j];
+            W[i] = wj; W[j] = wi;
+            if (act) { const double t = col[i * st]; col[i * st] = col[j * st]; col[j * st] = t; }
+        }
+    }
+    if (normalise_u && isA)
+        for (int i = 0; i < n; i++) col[i * m] *= W[i] > DBL_MIN ? 1 / W[i] : 0.;
+    DP_WAVE_SYNC();
+}
+
+/* cv::solve(A, b, x, DECOMP_SVD) by one wavefront, A n x n (n <= 12); tmp: 2 n n + n doubles of LDS; x valid for lane 0 */
+__device__ static void dp_solve_svd_wave(const double* A, int n, const double* b, double* x, double* tmp, int lane)
+{
+    double *At = tmp, *Vt = tmp + n * n, *W = tmp + 2 * n * n;
+    if (lane == 0) for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) At[j * n + i] = A[i * n + j];
+    dp_svd_wave(At, n, n, W, Vt, lane, true);
+    if (lane == 0) dp_backsubst(n, n, W, At, Vt, b, x);
+}
+
 // all 256 threads; thread 0 writes (rvec, tvec)
 __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const double* img, const uint8_t* mask, int n, int count, dp_cam K,
                                      const double* bestRt, const double* lam_tab /* 10^k, k = -16 .. 16 */, int tid, double* rvec_out, double* tvec_out)
@@ -1160,6 +1249,8 @@ __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const dou
     double* tot = sh.rf.tot;
     double* scr = sh.rf.scr;
     double* param = scr + 620;                               // the six pose parameters (rvec, tvec)
+    const int lane = tid & 63;
+    const bool wave0 = tid < 64;
     __syncthreads();                                         // the union's previous users (hypothesis rounds) are done
     if (tid == 0) { c.K = K; c.ifx = 1. / K.fu; c.ify = 1. / K.fv; }
     __syncthreads();
@@ -1211,19 +1302,21 @@ __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const dou
         __syncthreads();
         if (have_h) {
             dp_rf_sums<RF_HLTL, false, 45>(sh, obj, img, mask, n, tid);
-            if (tid == 0) {
+            if (wave0) {
                 double *LtL = scr, *W = scr + 81, *V = scr + 96;
-                dp_unpack_sym(tot, 9, LtL);
-                dp_jacobi_svd(LtL, 9, 9, W, V);              // symmetric: eigenvectors = right singular vectors
-                const double* H0 = V + 72;
-                const double invHnorm[9] = {1. / c.sm[0], 0, c.cm[0], 0, 1. / c.sm[1], c.cm[1], 0, 0, 1};
-                const double Hnorm2[9] = {c.sM[0], 0, -c.cM[0] * c.sM[0], 0, c.sM[1], -c.cM[1] * c.sM[1], 0, 0, 1};
-                double Ht[9], H1[9];
-                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ht[i * 3 + j] = invHnorm[i * 3] * H0[j] + invHnorm[i * 3 + 1] * H0[3 + j] + invHnorm[i * 3 + 2] * H0[6 + j];
-                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) H1[i * 3 + j] = Ht[i * 3] * Hnorm2[j] + Ht[i * 3 + 1] * Hnorm2[3 + j] + Ht[i * 3 + 2] * Hnorm2[6 + j];
-                const double sc = 1. / H1[8];
-                for (int k = 0; k < 9; k++) H[k] = H1[k] * sc;
-                for (int k = 0; k < 8; k++) c.h[k] = H[k];
+                if (lane == 0) dp_unpack_sym(tot, 9, LtL);
+                dp_svd_wave(LtL, 9, 9, W, V, lane, false);   // symmetric: eigenvectors = right singular vectors
+                if (lane == 0) {
+                    const double* H0 = V + 72;
+                    const double invHnorm[9] = {1. / c.sm[0], 0, c.cm[0], 0, 1. / c.sm[1], c.cm[1], 0, 0, 1};
+                    const double Hnorm2[9] = {c.sM[0], 0, -c.cM[0] * c.sM[0], 0, c.sM[1], -c.cM[1] * c.sM[1], 0, 0, 1};
+                    double Ht[9], H1[9];
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ht[i * 3 + j] = invHnorm[i * 3] * H0[j] + invHnorm[i * 3 + 1] * H0[3 + j] + invHnorm[i * 3 + 2] * H0[6 + j];
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) H1[i * 3 + j] = Ht[i * 3] * Hnorm2[j] + Ht[i * 3 + 1] * Hnorm2[3 + j] + Ht[i * 3 + 2] * Hnorm2[6 + j];
+                    const double sc = 1. / H1[8];
+                    for (int k = 0; k < 9; k++) H[k] = H1[k] * sc;
+                    for (int k = 0; k < 8; k++) c.h[k] = H[k];
+                }
             }
             __syncthreads();
             if (count > 4) {                                 // LMSolver (levmarq.cpp): 10 iterations, FLT_EPSILON
@@ -1238,32 +1331,42 @@ __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const dou
                     for (int i = 0; i < 8; i++) D[i] = A[i * 8 + i];
                 }
                 for (;;) {
-                    if (tid == 0) {
-                        for (int k = 0; k < 64; k++) Ap[k] = A[k];
-                        for (int i = 0; i < 8; i++) Ap[i * 8 + i] += lambda * D[i];
-                        dp_solve_svd(Ap, 8, v, d, tmp);
-                        for (int i = 0; i < 8; i++) { xd[i] = x[i] - d[i]; c.h[i] = xd[i]; }
+                    if (wave0) {
+                        if (lane == 0) {
+                            for (int k = 0; k < 64; k++) Ap[k] = A[k];
+                            for (int i = 0; i < 8; i++) Ap[i * 8 + i] += lambda * D[i];
+                        }
+                        dp_solve_svd_wave(Ap, 8, v, d, tmp, lane);
+                        if (lane == 0) for (int i = 0; i < 8; i++) { xd[i] = x[i] - d[i]; c.h[i] = xd[i]; }
                     }
                     __syncthreads();
                     dp_rf_sums<RF_HLM, false, 1>(sh, obj, img, mask, n, tid);
-                    if (tid == 0) {
-                        const double Sd = tot[0];
-                        double dS = 0, td = 0;
-                        for (int i = 0; i < 8; i++) {
-                            double s = 0;
-                            for (int k = 0; k < 8; k++) s += A[i * 8 + k] * d[k];
-                            dS += d[i] * (s * -1 + v[i] * 2);
-                            td += d[i] * v[i];
+                    if (wave0) {
+                        int need_inv = 0, better = 0;
+                        double Sd = 0, nu = 0;
+                        if (lane == 0) {
+                            Sd = tot[0];
+                            double dS = 0, td = 0;
+                            for (int i = 0; i < 8; i++) {
+                                double s = 0;
+                                for (int k = 0; k < 8; k++) s += A[i * 8 + k] * d[k];
+                                dS += d[i] * (s * -1 + v[i] * 2);
+                                td += d[i] * v[i];
+                            }
+                            const double Rr = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+                            if (Rr > 0.75) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+                            else if (Rr < 0.25) {
+                                nu = (Sd - S) / (fabs(td) > DBL_EPSILON ? td : 1) + 2;
+                                nu = nu > 2. ? nu : 2.; nu = nu < 10. ? nu : 10.;
+                                if (lambda == 0) need_inv = 1; else lambda *= nu;
+                            }
                         }
-                        const double Rr = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
-                        if (Rr > 0.75) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
-                        else if (Rr < 0.25) {
-                            double nu = (Sd - S) / (fabs(td) > DBL_EPSILON ? td : 1) + 2;
-                            nu = nu > 2. ? nu : 2.; nu = nu < 10. ? nu : 10.;
-                            if (lambda == 0) {               // max |diagonal| of the inverse of A
-                                double *At = tmp, *Vt = tmp + 64, *W = tmp + 128;
-                                for (int j = 0; j < 8; j++) for (int i = 0; i < 8; i++) At[j * 8 + i] = A[i * 8 + j];
-                                dp_svd_full(At, 8, 8, W, Vt);
+                        need_inv = __builtin_amdgcn_readfirstlane(need_inv);
+                        if (need_inv) {                      // lambda = lc = 1 / max |diagonal of the inverse of A|
+                            double *At = tmp, *Vt = tmp + 64, *W = tmp + 128;
+                            if (lane == 0) for (int j = 0; j < 8; j++) for (int i = 0; i < 8; i++) At[j * 8 + i] = A[i * 8 + j];
+                            dp_svd_wave(At, 8, 8, W, Vt, lane, true);
+                            if (lane == 0) {
                                 double thr = 0, maxval = DBL_EPSILON;
                                 for (int i = 0; i < 8; i++) thr += W[i];
                                 thr *= DBL_EPSILON * 2;
@@ -1274,12 +1377,14 @@ __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const dou
                                 }
                                 lambda = lc = 1. / maxval;
                                 nu *= 0.5;
+                                lambda *= nu;
                             }
-                            lambda *= nu;
                         }
-                        const int better = Sd < S;
-                        if (better) { S = Sd; for (int k = 0; k < 8; k++) { x[k] = xd[k]; c.h[k] = x[k]; } }
-                        sh.ctrl = better;
+                        if (lane == 0) {
+                            better = Sd < S;
+                            if (better) { S = Sd; for (int k = 0; k < 8; k++) { x[k] = xd[k]; c.h[k] = x[k]; } }
+                            sh.ctrl = better;
+                        }
                     }
                     __syncthreads();
                     const int better = sh.ctrl;
@@ -1305,7 +1410,7 @@ __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const dou
         if (tid == 0) {
             double h[9], R[9];
             int finite = have_h;
-            for (int k = 0; k < 9; k++) { h[k] = H[k]; finite = finite && isfinite(h[k]); }
+            for (int k = 0; k < 9; k++) { h[k] = have_h ? H[k] : 0.; finite = finite && isfinite(h[k]); }
             if (finite) {
                 const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
                 const double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
@@ -1331,32 +1436,37 @@ __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const dou
     } else {                                                 // DLT
         dp_rf_sums<RF_DLT_A, false, 39>(sh, obj, img, mask, n, tid, 0);
         dp_rf_sums<RF_DLT_B, false, 39>(sh, obj, img, mask, n, tid, 39);
-        if (tid == 0) {
+        if (wave0) {
             double *LL = scr, *LW = scr + 144, *LV = scr + 160;
-            dp_unpack_sym(tot, 12, LL);
-            dp_jacobi_svd(LL, 12, 12, LW, LV);
-            double RRt[12], Ut[9], Vt[9], W[3], R[9];
-            for (int k = 0; k < 12; k++) RRt[k] = LV[11 * 12 + k];
-            const double det = RRt[0] * (RRt[5] * RRt[10] - RRt[6] * RRt[9]) - RRt[1] * (RRt[4] * RRt[10] - RRt[6] * RRt[8]) + RRt[2] * (RRt[4] * RRt[9] - RRt[5] * RRt[8]);
-            if (det < 0) for (int k = 0; k < 12; k++) RRt[k] = RRt[k] * -1;
-            double sc = 0;
-            for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += RRt[i * 4 + j] * RRt[i * 4 + j]; sc += s; }
-            sc = sqrt(sc);
-            for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) Ut[j * 3 + i] = RRt[i * 4 + j];
-            dp_svd_full(Ut, 3, 3, W, Vt);
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = Ut[i] * Vt[j] + Ut[3 + i] * Vt[3 + j] + Ut[6 + i] * Vt[6 + j];
-            double nr = 0;
-            nr += R[0] * R[0] + R[1] * R[1] + R[2] * R[2] + R[3] * R[3];
-            nr += R[4] * R[4] + R[5] * R[5] + R[6] * R[6] + R[7] * R[7];
-            nr += R[8] * R[8];
-            const double scale = sqrt(nr) / sc;
-            for (int k = 0; k < 3; k++) param[3 + k] = RRt[k * 4 + 3] * scale;
-            double rv[3];
-            dp_rodrigues_to_vec(R, rv);
-            for (int k = 0; k < 3; k++) param[k] = rv[k];
+            if (lane == 0) dp_unpack_sym(tot, 12, LL);
+            dp_svd_wave(LL, 12, 12, LW, LV, lane, false);
+            if (lane == 0) {
+                double RRt[12], Ut[9], Vt[9], W[3], R[9];
+                for (int k = 0; k < 12; k++) RRt[k] = LV[11 * 12 + k];
+                const double det = RRt[0] * (RRt[5] * RRt[10] - RRt[6] * RRt[9]) - RRt[1] * (RRt[4] * RRt[10] - RRt[6] * RRt[8]) + RRt[2] * (RRt[4] * RRt[9] - RRt[5] * RRt[8]);
+                if (det < 0) for (int k = 0; k < 12; k++) RRt[k] = RRt[k] * -1;
+                double sc = 0;
+                for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += RRt[i * 4 + j] * RRt[i * 4 + j]; sc += s; }
+                sc = sqrt(sc);
+                for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) Ut[j * 3 + i] = RRt[i * 4 + j];
+                dp_svd_full(Ut, 3, 3, W, Vt);
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = Ut[i] * Vt[j] + Ut[3 + i] * Vt[3 + j] + Ut[6 + i] * Vt[6 + j];
+                double nr = 0;
+                nr += R[0] * R[0] + R[1] * R[1] + R[2] * R[2] + R[3] * R[3];
+                nr += R[4] * R[4] + R[5] * R[5] + R[6] * R[6] + R[7] * R[7];
+                nr += R[8] * R[8];
+                const double scale = sqrt(nr) / sc;
+                for (int k = 0; k < 3; k++) param[3 + k] = RRt[k * 4 + 3] * scale;
+                double rv[3];
+                dp_rodrigues_to_vec(R, rv);
+                for (int k = 0; k < 3; k++) param[k] = rv[k];
+            }
         }
     }
-    // CvLevMarq as cvFindExtrinsicCameraParams2 drives it
+    // CvLevMarq as cvFindExtrinsicCameraParams2 drives it (the control state lives in thread 0)
+#if defined(VO_PNP_STOP) && VO_PNP_STOP == 3
+    return;
+#endif
     double *JtJ = scr, *Aw = scr + 36, *tmp = scr + 72, *JtErr = scr + 150, *prev = scr + 156, *dx = scr + 168;
     int lambdaLg10 = -3, iters = 0;
     double errNorm = 0, prevErrNorm = DBL_MAX;
@@ -1367,32 +1477,43 @@ __device__ static void dp_refine_cv2(PnpShared& sh, const double* obj, const dou
         if (with_j) for (int k = 0; k < 27; k++) c.dRdr[k] = J[k];
         for (int k = 0; k < 3; k++) c.t[k] = param[3 + k];
     };
-    auto step = [&]() {                                      // CvLevMarq::step
-        const double lambda = lam_tab[lambdaLg10 + 16];
-        for (int k = 0; k < 36; k++) Aw[k] = JtJ[k];
-        for (int i = 0; i < 6; i++) Aw[i * 6 + i] *= 1. + lambda;
-        dp_solve_svd(Aw, 6, JtErr, dx, tmp);
-        for (int i = 0; i < 6; i++) param[i] = prev[i] - dx[i];
+    auto step = [&]() {                                      // CvLevMarq::step, by wave 0
+        if (lane == 0) {
+            const double lambda = lam_tab[lambdaLg10 + 16];
+            for (int k = 0; k < 36; k++) Aw[k] = JtJ[k];
+            for (int i = 0; i < 6; i++) Aw[i * 6 + i] *= 1. + lambda;
+        }
+        dp_solve_svd_wave(Aw, 6, JtErr, dx, tmp, lane);
+        if (lane == 0) for (int i = 0; i < 6; i++) param[i] = prev[i] - dx[i];
     };
+    __syncthreads();
     if (tid == 0) set_pose(true);
     __syncthreads();
     dp_rf_sums<RF_LM, true, 28>(sh, obj, img, mask, n, tid);
     for (;;) {
-        if (tid == 0) {
-            for (int k = 0; k < 6; k++) { JtErr[k] = tot[1 + k]; prev[k] = param[k]; }
-            dp_unpack_sym(tot + 7, 6, JtJ);
+        if (wave0) {
+            if (lane == 0) {
+                for (int k = 0; k < 6; k++) { JtErr[k] = tot[1 + k]; prev[k] = param[k]; }
+                dp_unpack_sym(tot + 7, 6, JtJ);
+            }
             step();
-            if (iters == 0) prevErrNorm = sqrt(tot[0]);
-            set_pose(false);
+            if (lane == 0) {
+                if (iters == 0) prevErrNorm = sqrt(tot[0]);
+                set_pose(false);
+            }
         }
         __syncthreads();
         for (;;) {
             dp_rf_sums<RF_LM, false, 1>(sh, obj, img, mask, n, tid);
-            if (tid == 0) {
-                errNorm = sqrt(tot[0]);
+            if (wave0) {
                 int again = 0;
-                if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) { step(); set_pose(false); again = 1; }
-                sh.ctrl = again;
+                if (lane == 0) {
+                    errNorm = sqrt(tot[0]);
+                    if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) again = 1;
+                }
+                again = __builtin_amdgcn_readfirstlane(again);
+                if (again) { step(); if (lane == 0) set_pose(false); }
+                if (lane == 0) sh.ctrl = again;
             }
             __syncthreads();
             const int again = sh.ctrl;
