@@ -39,9 +39,10 @@ __device__ __forceinline__ float sift_atan2_deg(float y, float x)            // 
     const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
     const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
-    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    const bool xge = ax >= ay;                                   // the two branches of cv::fastAtan2 differ only in which operand divides
+    const float c = (xge ? ay : ax) / ((xge ? ax : ay) + (float)DBL_EPSILON), c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (!xge) a = 90.f - a;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
@@ -597,17 +598,19 @@ __global__ __launch_bounds__(256) void k_sb_emit(const SiftKp* sorted, int kp_ca
 //      by bisection on the very same float expressions, a wave scan turns the interval lengths into the row-major numbering of the
 //      valid samples — no scan over the window, no queue;
 //  (1) the valid samples are evaluated 64 at a time, one per lane (gradient, fastAtan2, exp32f weight, trilinear split -> 8
-//      values), SD_SUB such batches per routing round; every sample sets its bit in the masks of the owner lanes it feeds;
-//  (2) the 64 lanes OWN the histogram: lane = inner cell (a, b) x q, q = orientation bins {2q, 2q+1} (+ bin 8 for q = 3), kept
-//      in registers; an owner walks the set bits of its masks, lowest (= earliest sample) first, and adds (branch-free: a
-//      contribution that does not concern an accumulator adds +0.0, which changes nothing in a sum of non-negative terms).
-// Same additions, same order as the scalar loop; no read-modify-write chain through memory.
+//      values for 8 ACCUMULATORS: bins o0 and o0 + 1 of the 2 x 2 cells of the footprint; 144 accumulators = 16 inner cells x
+//      bins 0..8, bin 8 being the wrap bin that calcSIFTDescriptor folds into bin 0 at the end); every sample sets its lane's
+//      bit in the 64-bit masks of the accumulators it feeds (LDS atomic OR);
+//  (2) the accumulators are OWNED by lanes (accumulator & 63: the nine bins of a cell sit in nine lanes): an owner counts the
+//      bits of its masks, a wave scan of the counts gives every accumulator a contiguous queue in LDS;
+//  (3) every sample writes its values to the queues: position = queue base + number of lower lanes that feed the same
+//      accumulator (popcount of the mask below its own bit) — i.e. the queue holds the accumulator's addends IN SAMPLE ORDER;
+//  (4) the owners add their queues front to back: one LDS read and one float add per addend, nothing else.
+// Same additions, same order as the scalar loop; no read-modify-write chain through memory, no per-addend decoding.
 #define SD_D 4
 #define SD_N 8
-#ifndef SD_SUB
-#define SD_SUB 1                       // 64-sample batches per routing round (1 / 2 / 4: 7.6 / 8.0 / 10.7 ms per 64 frames: LDS per wave, i.e. occupancy, outweighs the better balance of longer rounds)
-#endif
-#define SD_NS (64 * SD_SUB)
+#define SD_ACC 144                     // accumulators: inner cell (0..15) * 9 + bin (0..8)
+#define SD_QCAP (64 * 8 + 8)           // addends of a round (+ padding for the owners' four-wide reads)
 #define SD_ROWS 128                    // window rows per chunk (two per lane)
 
 struct SdRot { float cos_t, sin_t; };
@@ -632,17 +635,19 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
     __shared__ float s_tab[64];
     __shared__ int s_rstart[SD_ROWS + 1];                       // row-major number of a row's first valid sample (chunk-relative rows)
     __shared__ int s_rjlo[SD_ROWS];                             // its column
-    __shared__ float s_v[8][SD_NS];                             // s_v[(dr * 2 + dc) * 2 + dori][sample of the round]
-    __shared__ unsigned int s_code[SD_NS];                      // A * 4 + B * 2 | o0 << 8  (A = r0 + 1, B = c0 + 1 in 0..4)
-    __shared__ unsigned long long s_own[SD_SUB][64];
+    __shared__ unsigned long long s_mask[SD_ACC];               // lanes (samples of the round) that feed an accumulator
+    __shared__ int s_base[SD_ACC];                              // start of its queue
+    __shared__ float s_q[SD_QCAP];                              // the addends of the round, accumulator by accumulator, in sample order
+    __shared__ float s_acc[SD_ACC];
     __shared__ __attribute__((aligned(16))) float s_fin[128];
     __shared__ float s_x[64];
     const int lane = threadIdx.x, f = blockIdx.y;
     const int nkp = min(counts[4 * f + 3], kp_cap);
     s_tab[lane] = E.tab[lane];
-    // owner role of this lane
-    const int own_a = 1 + (lane >> 4), own_b = 1 + ((lane >> 2) & 3), own_q = lane & 3;
-    const int own_code = own_a * 4 + own_b * 2;
+    // owner role of this lane: accumulators lane, lane + 64 and (lane < 16) lane + 128
+    const bool own3 = lane < SD_ACC - 128;
+    for (int k = lane; k < SD_ACC; k += 64) s_mask[k] = 0ull;
+    if (lane < 8) s_q[64 * 8 + lane] = 0.f;
     const int d = SD_D, n = SD_N;
     for (int id = blockIdx.x; id < nkp; id += gridDim.x) {
         const SiftKp kp = kps[(size_t)f * kp_cap + id];         // already in input-image coordinates (firstOctave = -1 applied)
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
         cos_t /= hist_width; sin_t /= hist_width;
         const SdRot R = {cos_t, sin_t};
         const int side = 2 * radius + 1;
-        float e0 = 0.f, e1 = 0.f, e2 = 0.f;                     // bins 2q, 2q+1 (and 8 for q = 3) of cell (own_a, own_b)
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f;                     // accumulators lane, lane + 64, lane + 128
         for (int i0 = 0; i0 < side; i0 += SD_ROWS) {            // (one chunk unless the window has more than 128 rows)
             const int nrows = min(SD_ROWS, side - i0);
             __syncthreads();
@@ -701,89 +706,102 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
             s_rjlo[lane] = jl[0]; s_rjlo[64 + lane] = jl[1];
             if (lane == 0) s_rstart[SD_ROWS] = T;
             __syncthreads();
-            // ---- (1) + (2): rounds of SD_NS samples
-            int row[SD_SUB];
+            // ---- (1) .. (4): rounds of 64 samples
+            int rw = 0;
+            for (int s0 = 0; s0 < T; s0 += 64) {
+                const int sidx = s0 + lane;
+                float val[8];
+                int acc[4];                                      // accumulator of (dr, dc)'s bin o0 (or -1: not an inner cell); its bin o0 + 1 follows it
 #pragma unroll
-            for (int u = 0; u < SD_SUB; u++) row[u] = 0;
-            for (int s0 = 0; s0 < T; s0 += SD_NS) {
+                for (int k = 0; k < 4; k++) acc[k] = -1;
+                if (sidx < T) {
+                    while (sidx >= s_rstart[rw + 1]) rw++;              // (rows without valid samples are skipped: their start equals the next one's)
+                    const int i = i0 + rw - radius, j = s_rjlo[rw] + (sidx - s_rstart[rw]);
+                    float c_rot, r_rot, rbin, cbin;
+                    sd_bins(R, i, j, c_rot, r_rot, rbin, cbin);
+                    const int idx = (py + i) * st + px + j;
+                    const float dx = img[idx + 1] - img[idx - 1], dy = img[idx - st] - img[idx + st];
+                    const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
+                    const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
+                    float obin = (Ori - ori) * bins_per_rad;
+                    const float mag = Mag * Wq;
+                    const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+                    int o0 = (int)floorf(obin);
+                    rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
+                    if (o0 < 0) o0 += n;
+                    if (o0 >= n) o0 -= n;
+                    const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                    const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                    val[1] = v_rc00 * obin; val[0] = v_rc00 - val[1];   // v_rco001, v_rco000
+                    val[3] = v_rc01 * obin; val[2] = v_rc01 - val[3];   // v_rco011, v_rco010
+                    val[5] = v_rc10 * obin; val[4] = v_rc10 - val[5];   // v_rco101, v_rco100
+                    val[7] = v_rc11 * obin; val[6] = v_rc11 - val[7];   // v_rco111, v_rco110
+                    const unsigned long long bit = 1ull << lane;
 #pragma unroll
-                for (int u = 0; u < SD_SUB; u++) s_own[u][lane] = 0ull;
-                __syncthreads();
+                    for (int dr = 0; dr < 2; dr++)
 #pragma unroll
-                for (int u = 0; u < SD_SUB; u++) {
-                    const int sidx = s0 + 64 * u + lane, slot = 64 * u + lane;
-                    if (sidx < T) {
-                        int rw = row[u];
-                        while (sidx >= s_rstart[rw + 1]) rw++;          // (rows without valid samples are skipped: their start equals the next one's)
-                        row[u] = rw;
-                        const int i = i0 + rw - radius, j = s_rjlo[rw] + (sidx - s_rstart[rw]);
-                        float c_rot, r_rot, rbin, cbin;
-                        sd_bins(R, i, j, c_rot, r_rot, rbin, cbin);
-                        const int idx = (py + i) * st + px + j;
-                        const float dx = img[idx + 1] - img[idx - 1], dy = img[idx - st] - img[idx + st];
-                        const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
-                        const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
-                        float obin = (Ori - ori) * bins_per_rad;
-                        const float mag = Mag * Wq;
-                        const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-                        int o0 = (int)floorf(obin);
-                        rbin -= (float)r0; cbin -= (float)c0; obin -= (float)o0;
-                        if (o0 < 0) o0 += n;
-                        if (o0 >= n) o0 -= n;
-                        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                        const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-                        const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-                        s_v[0][slot] = v_rco000; s_v[1][slot] = v_rco001; s_v[2][slot] = v_rco010; s_v[3][slot] = v_rco011;
-                        s_v[4][slot] = v_rco100; s_v[5][slot] = v_rco101; s_v[6][slot] = v_rco110; s_v[7][slot] = v_rco111;
-                        const int A = r0 + 1, B = c0 + 1;       // cells (A, B), (A, B+1), (A+1, B), (A+1, B+1) of the 6 x 6 grid
-                        s_code[slot] = (unsigned)(A * 4 + B * 2) | ((unsigned)o0 << 8);
-                        // owners fed: orientation group(s) of o0 — even o0 = 2q: q (both of its bins); odd o0 = 2q+1: q (bin 2q+1) and
-                        // q+1 (bin 2q+2), except o0 = 7 whose upper bin 8 also belongs to q = 3
-                        const int qa = o0 >> 1, qb = (o0 & 1) && o0 < 7 ? qa + 1 : -1;
-                        const unsigned long long bit = 1ull << lane;
-#pragma unroll
-                        for (int dr = 0; dr < 2; dr++)
-#pragma unroll
-                            for (int dc = 0; dc < 2; dc++) {
-                                const int a = A + dr, b = B + dc;
-                                if (a >= 1 && a <= 4 && b >= 1 && b <= 4) {
-                                    const int ow = ((a - 1) << 4) | ((b - 1) << 2);
-                                    atomicOr(&s_own[u][ow | qa], bit);
-                                    if (qb >= 0) atomicOr(&s_own[u][ow | qb], bit);
-                                }
+                        for (int dc = 0; dc < 2; dc++) {
+                            const int a = r0 + dr, b = c0 + dc;         // inner cells: 0..3 (the histogram's rows / columns 1..4)
+                            if (a >= 0 && a < SD_D && b >= 0 && b < SD_D) {
+                                const int ac = (a * SD_D + b) * 9 + o0;
+                                acc[dr * 2 + dc] = ac;
+                                atomicOr(&s_mask[ac], bit);
+                                atomicOr(&s_mask[ac + 1], bit);
                             }
-                    }
+                        }
                 }
                 __syncthreads();
+                // (2) counts, queue starts
+                const unsigned long long m0 = s_mask[lane], m1 = s_mask[lane + 64], m2 = own3 ? s_mask[lane + 128] : 0ull;
+                const int c0n = __popcll(m0), c1n = __popcll(m1), c2n = __popcll(m2);
+                int inc = c0n + c1n + c2n;
 #pragma unroll
-                for (int u = 0; u < SD_SUB; u++) {
-                    const unsigned long long m64 = s_own[u][lane];
+                for (int dd = 1; dd < 64; dd <<= 1) { const int t0 = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t0; }
+                const int b0 = inc - (c0n + c1n + c2n), b1 = b0 + c0n, b2 = b1 + c1n;
+                s_base[lane] = b0; s_base[lane + 64] = b1;
+                if (own3) s_base[lane + 128] = b2;
+                __syncthreads();
+                // (3) every sample files its addends
+                const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-                    for (int hh = 0; hh < 2; hh++) {
-                        unsigned int m = hh ? (unsigned int)(m64 >> 32) : (unsigned int)m64;
-                        while (m) {
-                            const int t = 64 * u + 32 * hh + __ffs((int)m) - 1;
-                            m &= m - 1;
-                            const unsigned int code = s_code[t];
-                            const int sel = own_code - (int)(code & 255u);      // ((own_a - A) * 2 + (own_b - B)) * 2
-                            const int rel = (int)(code >> 8) - 2 * own_q;       // -1, 0 or 1
-                            const float v0 = s_v[0][sel * SD_NS + t], v1 = s_v[1][sel * SD_NS + t];
-                            e0 += rel == 0 ? v0 : rel < 0 ? v1 : 0.f;
-                            e1 += rel == 0 ? v1 : rel > 0 ? v0 : 0.f;
-                            e2 += rel > 0 ? v1 : 0.f;                           // (only read for q = 3: o0 = 7 -> bin 8)
-                        }
+                for (int k = 0; k < 4; k++)
+                    if (acc[k] >= 0) {
+                        const unsigned long long ma = s_mask[acc[k]], mb = s_mask[acc[k] + 1];
+                        s_q[s_base[acc[k]] + __popcll(ma & below)] = val[2 * k];
+                        s_q[s_base[acc[k] + 1] + __popcll(mb & below)] = val[2 * k + 1];
                     }
+                __syncthreads();
+                // (4) the owners add their queues, front to back (four reads in flight; the padding / the next queue's entries
+                // read past the end are discarded by the selects)
+                s_mask[lane] = 0ull; s_mask[lane + 64] = 0ull;
+                if (own3) s_mask[lane + 128] = 0ull;
+                for (int k = 0; k < c0n; k += 4) {
+                    const float q0 = s_q[b0 + k], q1 = s_q[b0 + k + 1], q2 = s_q[b0 + k + 2], q3 = s_q[b0 + k + 3];
+                    e0 += q0; e0 += k + 1 < c0n ? q1 : 0.f; e0 += k + 2 < c0n ? q2 : 0.f; e0 += k + 3 < c0n ? q3 : 0.f;
+                }
+                for (int k = 0; k < c1n; k += 4) {
+                    const float q0 = s_q[b1 + k], q1 = s_q[b1 + k + 1], q2 = s_q[b1 + k + 2], q3 = s_q[b1 + k + 3];
+                    e1 += q0; e1 += k + 1 < c1n ? q1 : 0.f; e1 += k + 2 < c1n ? q2 : 0.f; e1 += k + 3 < c1n ? q3 : 0.f;
+                }
+                for (int k = 0; k < c2n; k += 4) {
+                    const float q0 = s_q[b2 + k], q1 = s_q[b2 + k + 1], q2 = s_q[b2 + k + 2], q3 = s_q[b2 + k + 3];
+                    e2 += q0; e2 += k + 1 < c2n ? q1 : 0.f; e2 += k + 2 < c2n ? q2 : 0.f; e2 += k + 3 < c2n ? q3 : 0.f;
                 }
                 __syncthreads();
             }
         }
         // finalisation: hist[.][0] += hist[.][8] (hist[.][9] is never written), then the strictly sequential norm / clip / norm chain
         // of calcSIFTDescriptor on one lane; element order (cell row, cell column, bin)
-        s_x[lane] = e2;                                          // bin 8 of (cell, q = 3) -> added to bin 0 by the lane with q = 0
+        s_acc[lane] = e0; s_acc[lane + 64] = e1;
+        if (own3) s_acc[lane + 128] = e2;
         __syncthreads();
-        if (own_q == 0) e0 += s_x[lane + 3];
-        s_fin[(lane >> 2) * 8 + own_q * 2] = e0; s_fin[(lane >> 2) * 8 + own_q * 2 + 1] = e1;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {                            // element (cell, bin): bin 0 takes the wrap bin 8
+            const int el = lane + 64 * u, ci = el >> 3, o = el & 7;
+            float v = s_acc[ci * 9 + o];
+            if (o == 0) v += s_acc[ci * 9 + 8];
+            s_fin[el] = v;
+        }
         __syncthreads();
         if (lane == 0) {
             float nrm2 = 0;
