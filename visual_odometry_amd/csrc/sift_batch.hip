@@ -620,6 +620,18 @@ __device__ __forceinline__ void sd_bins(const SdRot& R, int i, int j, float& c_r
     rbin = r_rot + (float)(SD_D / 2) - 0.5f; cbin = c_rot + (float)(SD_D / 2) - 0.5f;
 }
 
+// inclusive prefix sum over the 64 lanes: Kogge-Stone inside the 16-lane DPP rows, then the row totals (row_bcast)
+__device__ __forceinline__ int sd_wave_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 // first j in [jl, jh] with pred(j), pred monotone false -> true over the range; jh + 1 if there is none
 template <typename P>
 __device__ __forceinline__ int sd_first_true(int jl, int jh, P pred)
@@ -629,6 +641,9 @@ __device__ __forceinline__ int sd_first_true(int jl, int jh, P pred)
     return lo;
 }
 
+// the workgroup IS one wavefront: LDS operations of a wave execute in program order, so ordering them for the compiler is all a
+// barrier has to do here (no s_barrier, and no wait for the global loads in flight)
+#define SD_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* gauss, const SiftKp* kps, int kp_cap, const int* counts, SiftExpTab E,
                                                       uint8_t* desc, uint8_t* desc_x, int cap_x, int* norms, int* flags, int first_slot)
 {
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
         float e0 = 0.f, e1 = 0.f, e2 = 0.f;                     // accumulators lane, lane + 64, lane + 128
         for (int i0 = 0; i0 < side; i0 += SD_ROWS) {            // (one chunk unless the window has more than 128 rows)
             const int nrows = min(SD_ROWS, side - i0);
-            __syncthreads();
+            SD_SYNC();
             // ---- (0) the valid interval of every row of the chunk
             int len[2], jl[2];
 #pragma unroll
@@ -698,29 +713,40 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
                 } else jhi = jlo - 1;
                 len[u] = max(0, jhi - jlo + 1); jl[u] = jlo;
             }
-            int inc0 = len[0], inc1 = len[1];
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) { const int t0 = __shfl_up(inc0, dd, 64), t1 = __shfl_up(inc1, dd, 64); if (lane >= dd) { inc0 += t0; inc1 += t1; } }
+            const int inc0 = sd_wave_scan(len[0]), inc1 = sd_wave_scan(len[1]);
             const int tot0 = __shfl(inc0, 63, 64), T = tot0 + __shfl(inc1, 63, 64);
             s_rstart[lane] = inc0 - len[0]; s_rstart[64 + lane] = tot0 + inc1 - len[1];
             s_rjlo[lane] = jl[0]; s_rjlo[64 + lane] = jl[1];
             if (lane == 0) s_rstart[SD_ROWS] = T;
-            __syncthreads();
+            SD_SYNC();
             // ---- (1) .. (4): rounds of 64 samples
             int rw = 0;
+            // the four pixels of a sample's gradient are loaded one round ahead (the loads stay in flight across the routing phases)
+            int ci = 0, cj = 0, ni = 0, nj = 0;
+            float pr = 0.f, pl = 0.f, pu = 0.f, pd = 0.f, npr = 0.f, npl = 0.f, npu = 0.f, npd = 0.f;
+            if (lane < T) {
+                while (lane >= s_rstart[rw + 1]) rw++;                  // (rows without valid samples are skipped: their start equals the next one's)
+                ci = i0 + rw - radius; cj = s_rjlo[rw] + (lane - s_rstart[rw]);
+                const int idx = (py + ci) * st + px + cj;
+                pr = img[idx + 1]; pl = img[idx - 1]; pu = img[idx - st]; pd = img[idx + st];
+            }
             for (int s0 = 0; s0 < T; s0 += 64) {
                 const int sidx = s0 + lane;
+                if (sidx + 64 < T) {
+                    while (sidx + 64 >= s_rstart[rw + 1]) rw++;
+                    ni = i0 + rw - radius; nj = s_rjlo[rw] + (sidx + 64 - s_rstart[rw]);
+                    const int idx = (py + ni) * st + px + nj;
+                    npr = img[idx + 1]; npl = img[idx - 1]; npu = img[idx - st]; npd = img[idx + st];
+                }
                 float val[8];
                 int acc[4];                                      // accumulator of (dr, dc)'s bin o0 (or -1: not an inner cell); its bin o0 + 1 follows it
 #pragma unroll
                 for (int k = 0; k < 4; k++) acc[k] = -1;
                 if (sidx < T) {
-                    while (sidx >= s_rstart[rw + 1]) rw++;              // (rows without valid samples are skipped: their start equals the next one's)
-                    const int i = i0 + rw - radius, j = s_rjlo[rw] + (sidx - s_rstart[rw]);
+                    const int i = ci, j = cj;
                     float c_rot, r_rot, rbin, cbin;
                     sd_bins(R, i, j, c_rot, r_rot, rbin, cbin);
-                    const int idx = (py + i) * st + px + j;
-                    const float dx = img[idx + 1] - img[idx - 1], dy = img[idx - st] - img[idx + st];
+                    const float dx = pr - pl, dy = pu - pd;
                     const float Wq = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
                     const float Ori = sift_atan2_deg(dy, dx), Mag = sqrtf(dx * dx + dy * dy);
                     float obin = (Ori - ori) * bins_per_rad;
@@ -750,17 +776,15 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
                             }
                         }
                 }
-                __syncthreads();
+                SD_SYNC();
                 // (2) counts, queue starts
                 const unsigned long long m0 = s_mask[lane], m1 = s_mask[lane + 64], m2 = own3 ? s_mask[lane + 128] : 0ull;
                 const int c0n = __popcll(m0), c1n = __popcll(m1), c2n = __popcll(m2);
-                int inc = c0n + c1n + c2n;
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) { const int t0 = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t0; }
+                const int inc = sd_wave_scan(c0n + c1n + c2n);
                 const int b0 = inc - (c0n + c1n + c2n), b1 = b0 + c0n, b2 = b1 + c1n;
                 s_base[lane] = b0; s_base[lane + 64] = b1;
                 if (own3) s_base[lane + 128] = b2;
-                __syncthreads();
+                SD_SYNC();
                 // (3) every sample files its addends
                 const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -770,7 +794,7 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
                         s_q[s_base[acc[k]] + __popcll(ma & below)] = val[2 * k];
                         s_q[s_base[acc[k] + 1] + __popcll(mb & below)] = val[2 * k + 1];
                     }
-                __syncthreads();
+                SD_SYNC();
                 // (4) the owners add their queues, front to back (four reads in flight; the padding / the next queue's entries
                 // read past the end are discarded by the selects)
                 s_mask[lane] = 0ull; s_mask[lane + 64] = 0ull;
@@ -787,14 +811,15 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
                     const float q0 = s_q[b2 + k], q1 = s_q[b2 + k + 1], q2 = s_q[b2 + k + 2], q3 = s_q[b2 + k + 3];
                     e2 += q0; e2 += k + 1 < c2n ? q1 : 0.f; e2 += k + 2 < c2n ? q2 : 0.f; e2 += k + 3 < c2n ? q3 : 0.f;
                 }
-                __syncthreads();
+                ci = ni; cj = nj; pr = npr; pl = npl; pu = npu; pd = npd;
+                SD_SYNC();
             }
         }
         // finalisation: hist[.][0] += hist[.][8] (hist[.][9] is never written), then the strictly sequential norm / clip / norm chain
         // of calcSIFTDescriptor on one lane; element order (cell row, cell column, bin)
         s_acc[lane] = e0; s_acc[lane + 64] = e1;
         if (own3) s_acc[lane + 128] = e2;
-        __syncthreads();
+        SD_SYNC();
 #pragma unroll
         for (int u = 0; u < 2; u++) {                            // element (cell, bin): bin 0 takes the wrap bin 8
             const int el = lane + 64 * u, ci = el >> 3, o = el & 7;
@@ -802,7 +827,7 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
             if (o == 0) v += s_acc[ci * 9 + 8];
             s_fin[el] = v;
         }
-        __syncthreads();
+        SD_SYNC();
         if (lane == 0) {
             float nrm2 = 0;
             for (int k = 0; k < 128; k++) { const float v = s_fin[k]; nrm2 += v * v; }
@@ -811,7 +836,7 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
             for (int k = 0; k < 128; k++) { float v = s_fin[k]; v = v < thr ? v : thr; s_fin[k] = v; nrm2 += v * v; }
             s_x[0] = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
         }
-        __syncthreads();
+        SD_SYNC();
         {
             const float sc = s_x[0];
             const int u0 = min(max(__float2int_rn(s_fin[2 * lane] * sc), 0), 255), u1 = min(max(__float2int_rn(s_fin[2 * lane + 1] * sc), 0), 255);
@@ -832,7 +857,7 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
                 if (lane == 0) norms[slot * cap_x + id] = sq;
             }
         }
-        __syncthreads();
+        SD_SYNC();
     }
 }
 
