@@ -172,7 +172,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     issue(0);
     // thread roles
     const int rrow = tid >> 5, rx4 = (tid & 31) * 4;       // row pass: 4 consecutive columns of one of the 8 rows
-    const int cc = tid & (SW_TW - 1), crg = wave >> 1;     // column pass: 4 consecutive rows (scalar: 4 crg ..) of one column
+    const int cc = 2 * lane;                               // column pass: two adjacent columns of two consecutive rows (scalar: 2 wave ..)
     const int woff = R4 - r;                               // window start inside the aligned span
     const int x = x0 + cc;
     for (int k = 0; k < nsteps; k++) {
@@ -214,44 +214,50 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
             }
         }
         __syncthreads();
-        // ---- column pass: output rows m = 8 k - 2 r + 4 crg + q (relative to Y0) have their whole window in the ring now.
-        //      m0 and every ring row index are scalars (crg is a wavefront's property)
+        // ---- column pass: output rows m = 8 k - 2 r + 2 wave + q (relative to Y0) have their whole window in the ring now.  A
+        //      thread owns TWO ADJACENT COLUMNS of two rows: the ring is read eight bytes at a time and the arithmetic runs on
+        //      float pairs (v_pk_add / v_pk_mul_f32: the same IEEE operations per component, half the instructions).  m0 and every
+        //      ring row index are scalars (a wavefront's property)
         {
-            const int m0 = k * SW_RS - 2 * r + 4 * crg;
-            if (m0 + 3 >= 0 && Y0 + m0 < Y1 && x < w) {
-                float acc[4];
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const int m0 = k * SW_RS - 2 * r + 2 * wave;
+            if (m0 + 1 >= 0 && Y0 + m0 < Y1 && x < w) {
+                v2f acc[2];
                 const int rb0 = (m0 + 4 * RING) % RING;
                 if (N > 0) {
-                    float win[N + 3];
+                    v2f win[N + 1];
 #pragma unroll
-                    for (int i = 0; i < N + 3; i++) { int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; win[i] = s_ring[ri * SW_TW + cc]; }
+                    for (int i = 0; i < N + 1; i++) { int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; win[i] = *(const v2f*)(s_ring + ri * SW_TW + cc); }
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[q] = t.k[DM::R] * win[DM::R + q];
+                    for (int q = 0; q < 2; q++) acc[q] = t.k[DM::R] * win[DM::R + q];
 #pragma unroll
                     for (int i = 1; i <= DM::R; i++) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) acc[q] += t.k[DM::R + i] * (win[DM::R + q + i] + win[DM::R + q - i]);
+                        for (int q = 0; q < 2; q++) acc[q] += t.k[DM::R + i] * (win[DM::R + q + i] + win[DM::R + q - i]);
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[q] = t.k[r] * s_ring[((rb0 + r + q) % RING) * SW_TW + cc];
+                    for (int q = 0; q < 2; q++) acc[q] = t.k[r] * *(const v2f*)(s_ring + ((rb0 + r + q) % RING) * SW_TW + cc);
                     for (int i = 1; i <= r; i++) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            acc[q] += t.k[r + i] * (s_ring[((rb0 + r + q + i) % RING) * SW_TW + cc] + s_ring[((rb0 + r + q - i) % RING) * SW_TW + cc]);
+                        for (int q = 0; q < 2; q++)
+                            acc[q] += t.k[r + i] * (*(const v2f*)(s_ring + ((rb0 + r + q + i) % RING) * SW_TW + cc) + *(const v2f*)(s_ring + ((rb0 + r + q - i) % RING) * SW_TW + cc));
                     }
                 }
                 const int cb0 = (m0 + r + 4 * CRING) % CRING;
+                const bool two = x + 1 < w;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < 2; q++) {
                     const int m = m0 + q, y = Y0 + m;
                     if (m >= 0 && y < Y1) {
                         const size_t o = (size_t)y * stride + x;
-                        if (dstG) dstG[o] = acc[q];
+                        v2f dg;
                         if (dstD) {
-                            if (DM::CTR) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dstD[o] = acc[q] - s_ctr[ci * SW_TW + cc]; }
-                            else dstD[o] = acc[q] - src[o];     // this workgroup streamed the row through a moment ago: an L2 hit
+                            if (DM::CTR) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dg = acc[q] - *(const v2f*)(s_ctr + ci * SW_TW + cc); }
+                            else { dg.x = acc[q].x - src[o]; dg.y = two ? acc[q].y - src[o + 1] : 0.f; }     // this workgroup streamed the row through a moment ago: an L2 hit
                         }
+                        if (two) { if (dstG) *(v2f*)(dstG + o) = acc[q]; if (dstD) *(v2f*)(dstD + o) = dg; }
+                        else { if (dstG) dstG[o] = acc[q].x; if (dstD) dstD[o] = dg.x; }
                     }
                 }
             }
