@@ -68,28 +68,47 @@ __device__ __forceinline__ float sift_expf(float x, const float* tab)       // c
 __device__ __forceinline__ int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; }
 
 // ------------------------------------------------------------------ base image
+// A thread makes FOUR consecutive destination pixels (one 16-byte store) from the 4 x 2 source pixels they touch; the weights
+// and the border rule are cv::resize's (INTER_LINEAR, float coefficients: 0.25 / 0.75, or 0 / 1 where the source index is
+// clamped — a clamped tap has weight 0, so which finite neighbour stands in for it does not matter).
 __global__ __launch_bounds__(256) void k_sb_base(const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh,
                                                  float* dst, int dstride, size_t dframe)
 {
-    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y, dw = 2 * sw;
-    if (dx >= dw) return;
+    const int t = blockIdx.x * 256 + threadIdx.x, dx0 = 4 * t, dy = blockIdx.y, dw = 2 * sw;
+    if (dx0 >= dw) return;
     src += (size_t)blockIdx.z * frame_stride;
-    float fx = (float)((dx + 0.5) * 0.5 - 0.5), fy = (float)((dy + 0.5) * 0.5 - 0.5);
-    int sx = (int)floorf(fx), sy = (int)floorf(fy);
-    fx -= (float)sx; fy -= (float)sy;
-    if (sx < 0) { fx = 0; sx = 0; }
-    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * 0.5 - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
     if (sy < 0) { fy = 0; sy = 0; }
     if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
-    const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
+    const int sy1 = min(sy + 1, sh - 1);
     auto px = [&](int y, int x) -> float {
         const uint8_t* p = src + (size_t)y * row_stride + (size_t)x * channels;
         const int v = channels == 1 ? p[0] : (p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15;
         return (float)v;
     };
-    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
-    const float r0 = px(sy, sx) * a0 + px(sy, sx1) * a1, r1 = px(sy1, sx) * a0 + px(sy1, sx1) * a1;
-    dst[(size_t)blockIdx.z * dframe + (size_t)dy * dstride + dx] = r0 * b0 + r1 * b1;
+    float v0[4], v1[4];                                       // source columns 2 t - 1 .. 2 t + 2 (clamped) of the two rows
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int c = min(max(2 * t - 1 + i, 0), sw - 1); v0[i] = px(sy, c); v1[i] = px(sy1, c); }
+    const float b0 = 1.f - fy, b1 = fy;
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int dx = dx0 + j;
+        float fx = (float)((dx + 0.5) * 0.5 - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const int n0 = (j + 1) >> 1;                          // first tap among the four cached columns: 0, 1, 1, 2
+        const float a0 = 1.f - fx, a1 = fx;
+        const float r0 = v0[n0] * a0 + v0[n0 + 1] * a1, r1 = v1[n0] * a0 + v1[n0 + 1] * a1;
+        out[j] = r0 * b0 + r1 * b1;
+    }
+    float* o = dst + (size_t)blockIdx.z * dframe + (size_t)dy * dstride + dx0;
+    if (dx0 + 3 < dw) *(float4*)o = make_float4(out[0], out[1], out[2], out[3]);
+    else for (int j = 0; j < 4 && dx0 + j < dw; j++) o[j] = out[j];
 }
 
 __global__ __launch_bounds__(256) void k_sb_half(const float* src, size_t sframe, int sw, int sh, int sstride,
@@ -112,6 +131,9 @@ struct SiftTaps { int n; float k[SIFT_MAX_TAPS]; };
 #define SW_NMAX 63
 #ifndef SW_CTR_MAXN
 #define SW_CTR_MAXN 63                 // tap counts above this read the centre again from L2 instead (frees LDS: more workgroups per CU)
+#endif
+#ifndef SW_VGPR_TAPS
+#define SW_VGPR_TAPS 21
 #endif
 #ifndef SW_CTR_LDS
 #define SW_CTR_LDS 1                   // (measured: 7.87 vs 8.64 ms per 64 frames) 1: the source rows' centre columns wait in an LDS ring for the DoG; 0: they are read again (L2) when the row is written
@@ -136,6 +158,17 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     typedef SweepDims<N> DM;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int n = N > 0 ? N : t.n, r = n / 2;
+    // the taps: wave-uniform, but more than ~17 of them beside the loop's other scalars overflow the 102 SGPRs of a wave and get
+    // spilled to VGPR lanes (v_readlane in the loop); from 21 taps on they are kept in vector registers outright
+    constexpr bool VT = N >= SW_VGPR_TAPS;
+    float tk[N > 0 ? N : 1];
+    if (N > 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            if (VT) asm volatile("v_mov_b32 %0, %1" : "=v"(tk[i]) : "s"(t.k[i]));
+            else tk[i] = t.k[i];
+        }
+    }
     const int R4 = N > 0 ? DM::R4 : ((r + 3) & ~3);
     const int INW = SW_TW + 2 * R4, INP = INW + 4;
     const int RING = N > 0 ? DM::RING : ((n + SW_RS - 1 + 7) & ~7);
@@ -194,11 +227,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
                 for (int i = 0; i < (2 * DM::R4 + 4) / 4; i++) { const float4 v = *(const float4*)(in + 4 * i); win[4 * i] = v.x; win[4 * i + 1] = v.y; win[4 * i + 2] = v.z; win[4 * i + 3] = v.w; }
                 constexpr int WO = DM::R4 - DM::R;
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] = t.k[0] * win[WO + q];
+                for (int q = 0; q < 4; q++) acc[q] = tk[0] * win[WO + q];
 #pragma unroll
                 for (int i = 1; i < N; i++) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[q] += t.k[i] * win[WO + i + q];
+                    for (int q = 0; q < 4; q++) acc[q] += tk[i] * win[WO + i + q];
                 }
                 if (DM::CTR) *(float4*)(s_ctr + (seq % DM::CRING) * SW_TW + rx4) = make_float4(win[DM::R4], win[DM::R4 + 1], win[DM::R4 + 2], win[DM::R4 + 3]);
                 *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -229,11 +262,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int i = 0; i < N + 1; i++) { int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; win[i] = *(const v2f*)(s_ring + ri * SW_TW + cc); }
 #pragma unroll
-                    for (int q = 0; q < 2; q++) acc[q] = t.k[DM::R] * win[DM::R + q];
+                    for (int q = 0; q < 2; q++) acc[q] = tk[DM::R] * win[DM::R + q];
 #pragma unroll
                     for (int i = 1; i <= DM::R; i++) {
 #pragma unroll
-                        for (int q = 0; q < 2; q++) acc[q] += t.k[DM::R + i] * (win[DM::R + q + i] + win[DM::R + q - i]);
+                        for (int q = 0; q < 2; q++) acc[q] += tk[DM::R + i] * (win[DM::R + q + i] + win[DM::R + q - i]);
                     }
                 } else {
 #pragma unroll
@@ -884,7 +917,7 @@ __global__ __launch_bounds__(256) void k_sb_unpack(const SiftKp* kps, int kp_cap
 // ------------------------------------------------------------------ launchers
 void launch_sb_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh, float* dst, int dstride, size_t dframe, int F)
 {
-    hipLaunchKernelGGL(k_sb_base, dim3((2 * sw + 255) / 256, 2 * sh, F), dim3(256), 0, s, src, channels, row_stride, frame_stride, sw, sh, dst, dstride, dframe);
+    hipLaunchKernelGGL(k_sb_base, dim3((2 * sw + 1023) / 1024, 2 * sh, F), dim3(256), 0, s, src, channels, row_stride, frame_stride, sw, sh, dst, dstride, dframe);
 }
 
 void launch_sb_half(hipStream_t s, const float* src, size_t sframe, int sw, int sh, int sstride, float* dst, size_t dframe, int dw, int dh, int dstride, int F)
