@@ -108,11 +108,14 @@ static bool build_tables(const uint8_t* counts /*16*/, const uint8_t* vals, int 
 // Frames of one camera / encoder carry identical DQT and DHT segments: when `prev` (the header bytes and tables of the
 // file parsed before) starts with the same bytes up to the scan header, its tables are copied instead of rebuilt.
 int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why, const uint8_t* prev_hdr, size_t prev_hdr_len,
-               const JpegImage* prev_img, const JpegTables* prev_T)
+               const JpegImage* prev_img, const JpegTables* prev_T, bool* same_tables)
 {
+    if (same_tables) *same_tables = false;
     if (prev_hdr && prev_hdr_len > 4 && prev_hdr_len <= n && !memcmp(d, prev_hdr, prev_hdr_len)) {
         static const char* dummy2; if (!why) why = &dummy2;
-        *img = *prev_img; memcpy(T, prev_T, sizeof(*T));
+        *img = *prev_img;
+        if (same_tables) *same_tables = true;                 // the caller lets this file share the previous file's tables
+        else memcpy(T, prev_T, sizeof(*T));
         if (n - prev_hdr_len > 0x7fffffffull) { *why = "image too large"; return VO_ERR_UNSUPPORTED; }
         img->raw_len = (uint32_t)(n - prev_hdr_len);
         return VO_OK;

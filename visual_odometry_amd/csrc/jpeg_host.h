@@ -15,6 +15,7 @@ struct JpegImage {               // one file of a batch: geometry from the heade
     uint32_t rst_off, rst_cap, nrst;             // restart positions (clean-stream byte offsets)
     uint32_t sync_rounds;                        // diagnostic: propagation rounds k_jpeg_huffman needed
     uint32_t coef_blk;                           // first 8x8 block in the coefficient buffer
+    uint32_t tab_idx;                            // its JpegTables in the batch's table array (files with identical headers share one)
     uint32_t out_stride;
     uint64_t plane_off[3], out_off;
     int32_t W, H, nc, mx, my, ri, ycc, bpm, total_blocks, mode /*0: 4:4:4 or grey, 1: h2v1, 2: h2v2*/, orientation;
@@ -35,4 +36,4 @@ struct JpegTables {
 };
 int jpeg_info(const uint8_t* d, size_t n, int* h, int* w, int* ncomp, int* sampling, int* orientation);
 int jpeg_parse(const uint8_t* d, size_t n, JpegImage* img, JpegTables* T, const char** why, const uint8_t* prev_hdr = nullptr,
-               size_t prev_hdr_len = 0, const JpegImage* prev_img = nullptr, const JpegTables* prev_T = nullptr);
+               size_t prev_hdr_len = 0, const JpegImage* prev_img = nullptr, const JpegTables* prev_T = nullptr, bool* same_tables = nullptr);

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     __shared__ int s_dc[JPG_NT][4];                        // per-thread DC sums of three components + "saw a restart"
     __shared__ int s_valid_mcus;
     const JpegImage& im = imgs[blockIdx.x];
-    const JpegTables& G = tabs[blockIdx.x];
+    const JpegTables& G = tabs[im.tab_idx];
     const int tid = threadIdx.x;
     for (int i = tid; i < 8 * (1 << JPG_LOOK) / 2; i += JPG_NT) ((uint32_t*)&T.lut[0][0])[i] = ((const uint32_t*)&G.lut[0][0])[i];
     for (int i = tid; i < 8 * JPG_LONG * 64 / 2; i += JPG_NT) ((uint32_t*)&T.sub[0][0][0])[i] = ((const uint32_t*)&G.sub[0][0][0])[i];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImage* imgs, const 
     const int mcu = j / im.bpm, jj = j - mcu * im.bpm;
     const int c = im.blk_comp[jj];
     const int px = ((mcu % im.mx) * im.ch[c] + im.blk_bx[jj]) * 8, py = ((mcu / im.mx) * im.cv[c] + im.blk_by[jj]) * 8;
-    const uint16_t* q = tabs[blockIdx.y].q[im.tq[c]];
+    const uint16_t* q = tabs[im.tab_idx].q[im.tq[c]];
     const uint4* src = (const uint4*)(coef_all + ((size_t)im.coef_blk + j) * 64);
     int32_t ws[64];
 #pragma unroll

@@ -1692,10 +1692,18 @@ static int ingest_from_device(vo_ctx* ctx, const uint8_t* src, int n, int sh, in
 {
     const int dw = ctx->w, dh = ctx->h;
     const size_t dper = (size_t)dw * dh * channels;
+    hipStream_t s = ctx->stream;
+    if (sw == dw && sh == dh && (!resized_out || (row_stride == dw * channels && frame_stride == (int64_t)dper))) {
+        // cv::resize to the source's own size is a copy: gray straight from the source frames
+        { StageTimer t(ctx, ST_GRAY); launch_gray(s, src, channels, row_stride, frame_stride, ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes, ctx->g, n); }
+        if (resized_out) HIPCHK(hipMemcpyAsync(resized_out, src, dper * n, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        return VO_OK;
+    }
     int rc = ensure_bytes(ctx, &ctx->ingest_out, &ctx->ingest_out_bytes, dper * n); if (rc) return rc;
     const int* xofs; const void* xa; const int* yofs; const void* yb;
     rc = ingest_tables(ctx, sw, sh, dw, dh, &xofs, &xa, &yofs, &yb); if (rc) return rc;
-    hipStream_t s = ctx->stream;
     const LevelGeom& lv = ctx->g.lv[0];
     uint8_t* lvl0 = ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes + lv.off;
     {
@@ -2070,18 +2078,23 @@ extern "C" int vo_jpeg_info(const uint8_t* data, size_t nbytes, int32_t* h, int3
 static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int f0, int n, int out_h, int out_w)
 {
     std::vector<JpegImage> imgs((size_t)n);
-    std::vector<JpegTables> tabs((size_t)n);
+    std::vector<JpegTables> tabs;                          // one per DISTINCT header (the frames of one camera share theirs)
+    tabs.reserve(4);
+    JpegTables scratch;
     const size_t base = (size_t)offsets[f0], bytes = (size_t)(offsets[f0 + n] - offsets[f0]);
     size_t clean = 0, rst = 0, blocks = 0, planes = 0;
     int max_blocks = 0;
     for (int k = 0; k < n; k++) {
         const char* why = "";
         const size_t o = (size_t)offsets[f0 + k], len = (size_t)(offsets[f0 + k + 1] - offsets[f0 + k]);
-        const int rc = k == 0 ? jpeg_parse(blob + o, len, &imgs[k], &tabs[k], &why)
-                              : jpeg_parse(blob + o, len, &imgs[k], &tabs[k], &why, blob + (size_t)offsets[f0 + k - 1], imgs[k - 1].hdr_len,
-                                           &imgs[k - 1], &tabs[k - 1]);
+        bool same = false;
+        const int rc = k == 0 ? jpeg_parse(blob + o, len, &imgs[k], &scratch, &why)
+                              : jpeg_parse(blob + o, len, &imgs[k], &scratch, &why, blob + (size_t)offsets[f0 + k - 1], imgs[k - 1].hdr_len,
+                                           &imgs[k - 1], nullptr, &same);
         if (rc) FAIL(rc, "JPEG %d: %s", f0 + k, why);
         JpegImage& im = imgs[k];
+        if (!same) tabs.push_back(scratch);
+        im.tab_idx = (uint32_t)tabs.size() - 1;
         if (im.H != out_h || im.W != out_w) FAIL(VO_ERR_INVALID, "JPEG %d is %d x %d, the batch expects %d x %d", f0 + k, im.W, im.H, out_w, out_h);
         im.raw_off = (uint32_t)(o - base + im.hdr_len);
         im.clean_off = (uint32_t)clean; clean += ((size_t)im.raw_len + JPG_PAD + 15) & ~(size_t)15;
@@ -2101,11 +2114,11 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     if ((rc = ensure_bytes(ctx, &ctx->jpg_planes, &ctx->jpg_planes_n, planes + 256))) return rc;
     if ((rc = ensure_bytes(ctx, &ctx->jpg_out, &ctx->jpg_out_n, (size_t)n * out_h * out_w * 3 + 16))) return rc;
     if ((rc = ensure_bytes(ctx, &ctx->jpg_img, &ctx->jpg_img_n, (size_t)n * sizeof(JpegImage)))) return rc;
-    if ((rc = ensure_bytes(ctx, &ctx->jpg_tab, &ctx->jpg_tab_n, (size_t)n * sizeof(JpegTables)))) return rc;
+    if ((rc = ensure_bytes(ctx, &ctx->jpg_tab, &ctx->jpg_tab_n, tabs.size() * sizeof(JpegTables)))) return rc;
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemcpyAsync(ctx->jpg_blob, blob + base, bytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->jpg_img, imgs.data(), (size_t)n * sizeof(JpegImage), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(ctx->jpg_tab, tabs.data(), (size_t)n * sizeof(JpegTables), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->jpg_tab, tabs.data(), tabs.size() * sizeof(JpegTables), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(ctx->jpg_coef, 0, blocks * 128, s));
     {
         StageTimer t(ctx, ST_MISC);
