@@ -6,10 +6,11 @@
 // (epnp.cpp: control points, barycentric coordinates, null space of M^T M by one-sided Jacobi, three beta
 // approximations + Gauss-Newton, absolute orientation) with thread-private work arrays, the hypotheses are scored
 // one per wavefront (float32 reprojection error, ballot + popcount) and consumed in OpenCV's order; the final pose
-// is the reprojection-error minimum over the inliers: Levenberg-Marquardt whose normal equations are accumulated by
-// all 256 threads (interleaved partial sums, added in thread order — the order the CPU oracle uses, so the two agree
-// to the last bit up to libm's acos / cos / sin).  The arithmetic below is kept operation for operation equal to the
-// oracle's restatement.
+// is cv2's own solvePnP(inliers, SOLVEPNP_ITERATIVE) (dp_refine_cv2: DLT or homography start, CvLevMarq; sums over the points by
+// all 256 threads in the oracle's order, the small SVDs by one wavefront), or, with vo_set_pnp_refine(ctx, 0), the same
+// reprojection cost minimised from the best RANSAC model (interleaved partial sums, added in thread order — the order the CPU
+// oracle uses, so the two agree to the last bit up to libm's acos / cos / sin).  The arithmetic below is kept operation for
+// operation equal to the oracle's restatement.
 #include "vo_internal.h"
 #include <float.h>
 
