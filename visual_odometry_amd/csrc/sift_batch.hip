@@ -65,6 +65,21 @@ __device__ __forceinline__ float sift_expf(float x, const float* tab)       // c
     return __int_as_float(t << 23) * tab[xi & 63] * ((((x0 + A1) * x0 + A2) * x0 + A3) * x0 + A4);
 }
 
+// the workgroup IS one wavefront: LDS operations of a wave execute in program order, so ordering them for the compiler is all a
+// barrier has to do here (no s_barrier, and no wait for the global loads in flight)
+#define SD_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// inclusive prefix sum over the 64 lanes: Kogge-Stone inside the 16-lane DPP rows, then the row totals (row_bcast)
+__device__ __forceinline__ int sd_wave_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
 __device__ __forceinline__ int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; }
 
 // ------------------------------------------------------------------ base image
@@ -441,11 +456,16 @@ __global__ __launch_bounds__(64) void k_sb_orient(SiftGeom P, const float* gauss
     __shared__ float s_tab[64];
     __shared__ float s_val[64];
     __shared__ unsigned long long s_mask[SO_BINS];
+    __shared__ int s_base[SO_BINS];
+    __shared__ float s_q[64 + 4];                               // the addends of a round, bin by bin, in sample order (+ padding for four-wide reads)
     __shared__ float s_th[SO_BINS + 4];
     const int lane = threadIdx.x, f = blockIdx.y;
     const int nsurv = min(counts[4 * f + 1], surv_cap);
     s_tab[lane] = E.tab[lane];
     const int n = SO_BINS;
+    if (lane < n) s_mask[lane] = 0ull;
+    if (lane < 4) s_q[64 + lane] = 0.f;
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int id = blockIdx.x; id < nsurv; id += gridDim.x) {
         const SiftSurv sv = surv[(size_t)f * surv_cap + id];
         const int o = sv.o, w = P.w[o], h = P.h[o], st = P.stride[o], r = sv.r, c = sv.c;
@@ -454,44 +474,69 @@ __global__ __launch_bounds__(64) void k_sb_orient(SiftGeom P, const float* gauss
         const float osigma = 1.5f * scl_octv, expf_scale = -1.f / (2.f * osigma * osigma);
         const float* g = gauss + (size_t)f * P.gframe + P.goff[o] + (size_t)sv.layer * P.plane[o];
         const int side = 2 * radius + 1, total = side * side;
+        // window position of this lane's sample: (row, column) of sample `lane`, advanced by 64 samples per round
+        const int step_i = 64 / side, step_j = 64 - step_i * side;
+        int wi = lane / side, wj = lane - wi * side;
         float acc = 0.f;                                         // temphist[lane] for lane < 36
-        __syncthreads();
+        // the four pixels of a sample's gradient are loaded one round ahead
+        auto inside = [&](int y, int x) { return !(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1); };
+        float pr = 0.f, pl = 0.f, pu = 0.f, pd = 0.f;
+        if (lane < total && inside(r + wi - radius, c + wj - radius)) {
+            const size_t at = (size_t)(r + wi - radius) * st + (c + wj - radius);
+            pr = g[at + 1]; pl = g[at - 1]; pu = g[at - st]; pd = g[at + st];
+        }
+        SD_SYNC();
         for (int q0 = 0; q0 < total; q0 += 64) {
-            if (lane < n) s_mask[lane] = 0ull;
-            __syncthreads();
-            const int q = q0 + lane;
-            if (q < total) {
-                const int ii = q / side - radius, jj = q % side - radius, y = r + ii, x = c + jj;
-                if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
-                    const float dx = g[(size_t)y * st + x + 1] - g[(size_t)y * st + x - 1], dy = g[(size_t)(y - 1) * st + x] - g[(size_t)(y + 1) * st + x];
-                    const float wgt = sift_expf((float)(ii * ii + jj * jj) * expf_scale, s_tab);
-                    const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
-                    int bin = __float2int_rn((n / 360.f) * ori);
-                    if (bin >= n) bin -= n;
-                    if (bin < 0) bin += n;
-                    s_val[lane] = wgt * mag;
-                    atomicOr(&s_mask[bin], 1ull << lane);
-                }
+            const int q = q0 + lane, ii = wi - radius, jj = wj - radius;
+            wi += step_i; wj += step_j;
+            if (wj >= side) { wj -= side; wi++; }
+            float npr = 0.f, npl = 0.f, npu = 0.f, npd = 0.f;
+            if (q + 64 < total && inside(r + wi - radius, c + wj - radius)) {
+                const size_t at = (size_t)(r + wi - radius) * st + (c + wj - radius);
+                npr = g[at + 1]; npl = g[at - 1]; npu = g[at - st]; npd = g[at + st];
             }
-            __syncthreads();
-            if (lane < n) {
-                unsigned long long m = s_mask[lane];
-                while (m) { const int t = __ffsll((long long)m) - 1; m &= m - 1; acc += s_val[t]; }
+            int bin = -1;
+            float val = 0.f;
+            if (q < total && inside(r + ii, c + jj)) {
+                const float dx = pr - pl, dy = pu - pd;
+                const float wgt = sift_expf((float)(ii * ii + jj * jj) * expf_scale, s_tab);
+                const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                bin = __float2int_rn((n / 360.f) * ori);
+                if (bin >= n) bin -= n;
+                if (bin < 0) bin += n;
+                val = wgt * mag;
+                atomicOr(&s_mask[bin], 1ull << lane);
             }
-            __syncthreads();
+            SD_SYNC();
+            // the owners (lane = bin) count their addends; a scan gives every bin its queue; every sample files its value at
+            // queue start + number of earlier samples of the same bin; the owners add front to back
+            const unsigned long long mine = lane < n ? s_mask[lane] : 0ull;
+            const int cnt = __popcll(mine);
+            const int start = sd_wave_scan(cnt) - cnt;
+            if (lane < n) { s_base[lane] = start; s_mask[lane] = 0ull; }
+            SD_SYNC();
+            const unsigned long long mb = __shfl(mine, bin >= 0 ? bin : 0, 64);   // (the masks were cleared above: the owners pass them on; all lanes take part)
+            if (bin >= 0) s_q[s_base[bin] + __popcll(mb & below)] = val;
+            SD_SYNC();
+            for (int k = 0; k < cnt; k += 4) {
+                const float q0v = s_q[start + k], q1v = s_q[start + k + 1], q2v = s_q[start + k + 2], q3v = s_q[start + k + 3];
+                acc += q0v; acc += k + 1 < cnt ? q1v : 0.f; acc += k + 2 < cnt ? q2v : 0.f; acc += k + 3 < cnt ? q3v : 0.f;
+            }
+            pr = npr; pl = npl; pu = npu; pd = npd;
+            SD_SYNC();
         }
         if (lane < n) s_th[2 + lane] = acc;
-        __syncthreads();
+        SD_SYNC();
         if (lane == 0) { s_th[1] = s_th[2 + n - 1]; s_th[0] = s_th[2 + n - 2]; s_th[2 + n] = s_th[2]; s_th[2 + n + 1] = s_th[3]; }
-        __syncthreads();
+        SD_SYNC();
         float hj = 0.f;
         if (lane < n) {
             const float* th = s_th + 2 + lane;
             hj = (th[-2] + th[2]) * (1.f / 16.f) + (th[-1] + th[1]) * (4.f / 16.f) + th[0] * (6.f / 16.f);
         }
-        __syncthreads();
+        SD_SYNC();
         if (lane < n) s_val[lane] = hj;
-        __syncthreads();
+        SD_SYNC();
         if (lane < n) {
             float maxval = s_val[0];
             for (int b = 1; b < n; b++) maxval = s_val[b] > maxval ? s_val[b] : maxval;
@@ -508,7 +553,7 @@ __global__ __launch_bounds__(64) void k_sb_orient(SiftGeom P, const float* gauss
                 if (slot < kp_cap) kps[(size_t)f * kp_cap + slot] = kp;
             }
         }
-        __syncthreads();
+        SD_SYNC();
     }
 }
 
@@ -659,18 +704,6 @@ __device__ __forceinline__ void sd_bins(const SdRot& R, int i, int j, float& c_r
     rbin = r_rot + (float)(SD_D / 2) - 0.5f; cbin = c_rot + (float)(SD_D / 2) - 0.5f;
 }
 
-// inclusive prefix sum over the 64 lanes: Kogge-Stone inside the 16-lane DPP rows, then the row totals (row_bcast)
-__device__ __forceinline__ int sd_wave_scan(int x)
-{
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
-    return x;
-}
-
 // first j in [jl, jh] with pred(j), pred monotone false -> true over the range; jh + 1 if there is none
 template <typename P>
 __device__ __forceinline__ int sd_first_true(int jl, int jh, P pred)
@@ -680,9 +713,6 @@ __device__ __forceinline__ int sd_first_true(int jl, int jh, P pred)
     return lo;
 }
 
-// the workgroup IS one wavefront: LDS operations of a wave execute in program order, so ordering them for the compiler is all a
-// barrier has to do here (no s_barrier, and no wait for the global loads in flight)
-#define SD_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* gauss, const SiftKp* kps, int kp_cap, const int* counts, SiftExpTab E,
                                                       uint8_t* desc, uint8_t* desc_x, int cap_x, int* norms, int* flags, int first_slot)
 {
