@@ -323,7 +323,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 // of every plane stay in registers, so the 3 x 3 x 3 extremes of the row above are three more max / min per plane.
 #define EX_COLS 62
 #ifndef EX_SEG
-#define EX_SEG 128                    // rows per wavefront sweep (32 / 64 / 128: 2.74 / 2.25 / 1.99 ms per 64 frames: fewer halo rows, longer streams)
+#define EX_SEG 256                    // rows per wavefront sweep (32 / 64 / 128 / 256 / 512: 2.74 / 2.25 / 1.99 / 1.77 / 1.95 ms per 64 frames: fewer halo rows, longer streams; then too few waves)
 #endif
 #define EX_MAXP 10                     // DoG planes of an octave (nOctaveLayers + 2 <= 10)
 template <int NP>
