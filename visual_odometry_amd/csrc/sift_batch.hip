@@ -855,13 +855,12 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
                 if (own3) s_base[lane + 128] = b2;
                 SD_SYNC();
                 // (3) every sample files its addends
-                const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (acc[k] >= 0) {
+                    if (acc[k] >= 0) {                           // position = number of lower lanes that feed the same accumulator (v_mbcnt)
                         const unsigned long long ma = s_mask[acc[k]], mb = s_mask[acc[k] + 1];
-                        s_q[s_base[acc[k]] + __popcll(ma & below)] = val[2 * k];
-                        s_q[s_base[acc[k] + 1] + __popcll(mb & below)] = val[2 * k + 1];
+                        s_q[s_base[acc[k]] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] = val[2 * k];
+                        s_q[s_base[acc[k] + 1] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = val[2 * k + 1];
                     }
                 SD_SYNC();
                 // (4) the owners add their queues, front to back (four reads in flight; the padding / the next queue's entries
