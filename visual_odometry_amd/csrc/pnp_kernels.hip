@@ -1163,73 +1163,100 @@ __device__ static inline double dp_dpp(double v)
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-// sum over the 16 lanes of a DPP row (butterfly: every lane of the row ends with the same bits), lane 0's to the whole wave
-__device__ static inline double dp_row0_sum(double v)
+// sum over the 16 lanes of a DPP row (butterfly: every lane of the row ends with the same bits)
+__device__ static inline double dp_row_sum(double v)
 {
     v += dp_dpp<0xB1>(v);                                    // quad_perm [1,0,3,2]
     v += dp_dpp<0x4E>(v);                                    // quad_perm [2,3,0,1]
     v += dp_dpp<0x141>(v);                                   // row_half_mirror
     v += dp_dpp<0x140>(v);                                   // row_mirror
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    return v;
 }
 
-// JacobiSVDImpl_ (lapack.cpp) by one wavefront: lane k < m owns column k of At (n rows of length m), lane m + k column k of Vt;
-// same pair order, rotation formulas, convergence test and final ordering as dp_jacobi_svd — the dot products over a row are
-// butterfly sums over the lanes instead of left-to-right sums.  m <= 16, m + n <= 64.  At, W, Vt in LDS.
+// One-sided Jacobi SVD (lapack.cpp JacobiSVDImpl_: the same rotation formulas, convergence test, final ordering and
+// normalisation as dp_jacobi_svd) of a square matrix by one wavefront, n <= 16.  At: n rows of length n (row i = column i of A), Vt
+// n x n, W n, all in LDS.  A 16-lane DPP row handles one column pair: lane k of the row owns element k of the two A rows and of the
+// two V rows, the row dot products are butterflies inside the row, the rotation parameters are computed per row.  The four rows of
+// the wave take FOUR DISJOINT PAIRS AT A TIME in round-robin (tournament) order instead of OpenCV's cyclic i < j order: the same
+// decomposition to rounding (each sweep still rotates every pair once), three to four times fewer dependent steps.
 __device__ static void dp_svd_wave(double* At, int m, int n, double* W, double* Vt, int lane, bool normalise_u)
 {
-    const bool isA = lane < m, isV = lane >= m && lane < m + n, act = isA || isV;
-    double* col = isA ? At + lane : Vt + (isV ? lane - m : 0);
-    const int st = isA ? m : n;
+    const int row = lane >> 4, k = lane & 15;
+    const bool act = k < n;
+    (void)m;                                                 // (square: m == n)
     DP_WAVE_SYNC();
-    for (int i = 0; i < n; i++) {
-        const double v = isA ? col[i * m] : 0.;
-        W[i] = dp_row0_sum(v * v);
-        if (isV) col[i * n] = lane - m == i ? 1. : 0.;
+    for (int i0 = 0; i0 < n; i0 += 4) {
+        const int i = i0 + row;
+        const bool has = i < n;
+        const double v = act && has ? At[i * n + k] : 0.;
+        const double sd = dp_row_sum(v * v);
+        if (has && k == 0) W[i] = sd;
+        if (has && act) Vt[i * n + k] = k == i ? 1. : 0.;
     }
+    DP_WAVE_SYNC();
     const double eps = DBL_EPSILON * 10;
-    const int max_iter = m > 30 ? m : 30;
+    const int max_iter = n > 30 ? n : 30;
+    const int np = (n + 1) & ~1, npairs = np >> 1, nrounds = np - 1;     // players of the tournament (odd n: one bye per round)
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
-        for (int i = 0; i < n - 1; i++)
-            for (int j = i + 1; j < n; j++) {
-                const double xi = act ? col[i * st] : 0., xj = act ? col[j * st] : 0.;
-                double a = W[i], b = W[j];
-                double p = dp_row0_sum(isA ? xi * xj : 0.);
-                if (fabs(p) <= eps * sqrt(a * b)) continue;
-                p *= 2;
-                double beta = a - b, gamma = dp_hypot(p, beta), c, s;
+        for (int r = 0; r < nrounds; r++)
+            for (int p0 = 0; p0 < npairs; p0 += 4) {
+                const int p = p0 + row;
+                // circle method: player np - 1 stays, the others rotate; pair p of round r
+                const int a = (r + p) % nrounds, b = p == 0 ? np - 1 : (r - p + nrounds) % nrounds;
+                const bool valid = p < npairs && a < n && b < n;
+                const int i = valid ? min(a, b) : 0, j = valid ? max(a, b) : 0;
+                double xi = 0., xj = 0., vi = 0., vj = 0.;
+                if (valid && act) { xi = At[i * n + k]; xj = At[j * n + k]; vi = Vt[i * n + k]; vj = Vt[j * n + k]; }
+                const double wa = W[i], wb = W[j];
+                double pd = dp_row_sum(xi * xj);
+                const bool rot = valid && !(fabs(pd) <= eps * sqrt(wa * wb));
+                pd *= 2;
+                const double beta = wa - wb, gamma = dp_hypot(pd, beta);
+                double c, s;
                 if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
+                    const double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);
-                    c = p / (gamma * s * 2);
+                    c = pd / (gamma * s * 2);
                 } else {
                     c = sqrt((gamma + beta) / (gamma * 2));
-                    s = p / (gamma * c * 2);
+                    s = pd / (gamma * c * 2);
                 }
                 const double t0 = c * xi + s * xj, t1 = -s * xi + c * xj;
-                if (act) { col[i * st] = t0; col[j * st] = t1; }
-                W[i] = dp_row0_sum(isA ? t0 * t0 : 0.);
-                W[j] = dp_row0_sum(isA ? t1 * t1 : 0.);
-                changed = true;
+                if (rot && act) {
+                    At[i * n + k] = t0; At[j * n + k] = t1;
+                    Vt[i * n + k] = c * vi + s * vj; Vt[j * n + k] = -s * vi + c * vj;
+                }
+                const double na = dp_row_sum(rot ? t0 * t0 : 0.), nb = dp_row_sum(rot ? t1 * t1 : 0.);
+                if (rot && k == 0) { W[i] = na; W[j] = nb; }
+                changed |= rot;
+                DP_WAVE_SYNC();
             }
-        if (!changed) break;
+        if (!__any(changed)) break;
     }
-    for (int i = 0; i < n; i++) {
-        const double v = isA ? col[i * m] : 0.;
-        W[i] = sqrt(dp_row0_sum(v * v));
+    for (int i0 = 0; i0 < n; i0 += 4) {
+        const int i = i0 + row;
+        const bool has = i < n;
+        const double v = act && has ? At[i * n + k] : 0.;
+        const double sd = dp_row_sum(v * v);
+        if (has && k == 0) W[i] = sqrt(sd);
     }
-    for (int i = 0; i < n - 1; i++) {
+    DP_WAVE_SYNC();
+    for (int i = 0; i < n - 1; i++) {                        // descending order (the rows of At and Vt follow); row 0's lanes move the data
         int j = i;
-        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
-        if (i != j) {
-            const double wi = W[i], wj = W[j];
-            W[i] = wj; W[j] = wi;
-            if (act) { const double t = col[i * st]; col[i * st] = col[j * st]; col[j * st] = t; }
+        for (int q = i + 1; q < n; q++) if (W[j] < W[q]) j = q;
+        DP_WAVE_SYNC();
+        if (i != j && row == 0) {
+            if (k == 0) { const double wi = W[i], wj = W[j]; W[i] = wj; W[j] = wi; }
+            if (act) {
+                double t = At[i * n + k]; At[i * n + k] = At[j * n + k]; At[j * n + k] = t;
+                t = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = t;
+            }
         }
+        DP_WAVE_SYNC();
     }
-    if (normalise_u && isA)
-        for (int i = 0; i < n; i++) col[i * m] *= W[i] > DBL_MIN ? 1 / W[i] : 0.;
+    if (normalise_u && row == 0 && act)
+        for (int i = 0; i < n; i++) At[i * n + k] *= W[i] > DBL_MIN ? 1 / W[i] : 0.;
     DP_WAVE_SYNC();
 }
 
