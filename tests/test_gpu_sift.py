@@ -86,3 +86,37 @@ def test_live_pair_path_sift_l2(oracle, seq_small):
     from visual_odometry_amd import synth
     Rgt, tgt = synth.relative_pose(seq_small["R"][0], seq_small["C"][0], seq_small["R"][1], seq_small["C"][1])
     assert np.linalg.norm(ip.R - Rgt) < 0.05 and abs(float(ip.t.ravel() @ tgt)) > 0.9   # (cross-check only, no ratio test: a loose sanity bound)
+
+
+def test_sift_differential_fuzz(oracle, ctx):
+    """Random sizes (odd, thin, tiny octave pyramids), textures and parameters — tap counts other than cv2's default set go through the
+    run-time form of the sweep kernel, odd widths through its single-column stores and the base kernel's tail."""
+    from visual_odometry_amd.detector import SiftDetector
+    rng = np.random.default_rng(2026)
+    found = 0
+    for case in range(14):
+        h, w = int(rng.integers(24, 220)), int(rng.integers(24, 260))
+        kind = case % 3
+        if kind == 0:
+            img = random_image(1000 + case, h, w)
+        elif kind == 1:                                                    # blobs on a gradient
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = 40.0 + 0.4 * xx + 0.2 * yy
+            for _ in range(25):
+                cy, cx, sg = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(1.5, 7)
+                img = img + rng.uniform(-90, 90) * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sg * sg))
+            img = np.clip(img, 0, 255).astype(np.uint8)
+        else:                                                              # coarse noise, up-sampled: corners at many scales
+            small = rng.integers(0, 256, (h // 5 + 2, w // 5 + 2)).astype(np.uint8)
+            img = np.kron(small, np.ones((5, 5), np.uint8))[:h, :w].copy()
+        kw = dict(nOctaveLayers=int(rng.integers(2, 6)), contrastThreshold=float(rng.uniform(0.02, 0.07)),
+                  edgeThreshold=float(rng.uniform(5, 15)), sigma=float(rng.uniform(1.2, 2.1)))
+        want = oracle.sift_detect_and_compute(img, n_layers=kw["nOctaveLayers"], contrast_threshold=kw["contrastThreshold"],
+                                              edge_threshold=kw["edgeThreshold"], sigma=kw["sigma"])
+        got = SiftDetector(ctx=ctx, **kw).detect_arrays(img)
+        assert len(got["xy"]) == want["n_found"], (case, h, w, kw)
+        for key in ("xy", "size", "angle", "response", "octave"):
+            assert np.array_equal(got[key], want[key]), (case, key)
+        assert np.array_equal(got["desc"], want["desc"]), case
+        found += want["n_found"]
+    assert found > 500
