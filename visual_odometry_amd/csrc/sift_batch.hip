@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
     __shared__ int s_rjlo[SD_ROWS];                             // its column
     __shared__ unsigned long long s_mask[SD_ACC];               // lanes (samples of the round) that feed an accumulator
     __shared__ int s_base[SD_ACC];                              // start of its queue
-    __shared__ float s_q[SD_QCAP];                              // the addends of the round, accumulator by accumulator, in sample order
+    __shared__ __attribute__((aligned(16))) float s_q[SD_QCAP]; // the addends of the round, accumulator by accumulator, in sample order
     __shared__ float s_acc[SD_ACC];
     __shared__ __attribute__((aligned(16))) float s_fin[128];
     __shared__ float s_x[64];
@@ -888,20 +888,33 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
         s_acc[lane] = e0; s_acc[lane + 64] = e1;
         if (own3) s_acc[lane + 128] = e2;
         SD_SYNC();
-#pragma unroll
-        for (int u = 0; u < 2; u++) {                            // element (cell, bin): bin 0 takes the wrap bin 8
-            const int el = lane + 64 * u, ci = el >> 3, o = el & 7;
-            float v = s_acc[ci * 9 + o];
-            if (o == 0) v += s_acc[ci * 9 + 8];
-            s_fin[el] = v;
+        // the squares (and the clipped values) are formed by all lanes; one lane only ADDS them, in element order — the order of
+        // calcSIFTDescriptor's scalar loop — from 16-byte reads
+        float v0, v1;
+        {
+            const int ci = lane >> 2, o = (2 * lane) & 7;        // elements 2 lane, 2 lane + 1: (cell, bins o, o + 1); bin 0 takes the wrap bin 8
+            v0 = s_acc[ci * 9 + o]; v1 = s_acc[ci * 9 + o + 1];
+            if (o == 0) v0 += s_acc[ci * 9 + 8];
+        }
+        float* const s_sq = s_q + 256;                           // (the queue area is idle between keypoints)
+        *(float2*)(s_sq + 2 * lane) = make_float2(v0 * v0, v1 * v1);
+        SD_SYNC();
+        if (lane == 0) {
+            float nrm2 = 0;
+            for (int k = 0; k < 128; k += 4) { const float4 q = *(const float4*)(s_sq + k); nrm2 += q.x; nrm2 += q.y; nrm2 += q.z; nrm2 += q.w; }
+            s_x[0] = sqrtf(nrm2) * 0.2f;
+        }
+        SD_SYNC();
+        {
+            const float thr = s_x[0];
+            v0 = v0 < thr ? v0 : thr; v1 = v1 < thr ? v1 : thr;
+            *(float2*)(s_fin + 2 * lane) = make_float2(v0, v1);
+            *(float2*)(s_sq + 2 * lane) = make_float2(v0 * v0, v1 * v1);
         }
         SD_SYNC();
         if (lane == 0) {
             float nrm2 = 0;
-            for (int k = 0; k < 128; k++) { const float v = s_fin[k]; nrm2 += v * v; }
-            const float thr = sqrtf(nrm2) * 0.2f;
-            nrm2 = 0;
-            for (int k = 0; k < 128; k++) { float v = s_fin[k]; v = v < thr ? v : thr; s_fin[k] = v; nrm2 += v * v; }
+            for (int k = 0; k < 128; k += 4) { const float4 q = *(const float4*)(s_sq + k); nrm2 += q.x; nrm2 += q.y; nrm2 += q.z; nrm2 += q.w; }
             s_x[0] = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
         }
         SD_SYNC();
