@@ -193,3 +193,44 @@ def test_orb_and_sift_front_ends_share_a_context(oracle):
     assert np.array_equal(again["xy"], orb0["xy"]) and np.array_equal(again["desc"], orb0["desc"])
     res, _ = fo2.run_pairs([[0, 1]], seq["K"])
     assert res["status"][0] == 0 and res["n_inl"][0] > 20
+
+
+def test_sift_overlapped_contexts_are_deterministic():
+    """Two SIFT contexts alternating chunks (asynchronous detect + pairs on their own streams) reproduce the synchronous
+    single-context results bit for bit, chunk after chunk, features included: the candidate lists are filled through
+    atomic counters in whatever order the waves arrive, the sort makes the keypoint order a function of the data alone, and the
+    descriptor / orientation kernels rely on wave-level ordering of their LDS traffic instead of barriers."""
+    from visual_odometry_amd import synth
+    from visual_odometry_amd.frontend import FrontEnd
+    C = 20
+    seq = synth.sequence(7, 640, 360, cache_dir="/tmp")
+    order = [(i % 12 if i % 12 < 7 else 12 - i % 12) for i in range(C + 1)]
+    frames = seq["frames"][order]
+    K = seq["K"]
+    pairs = np.stack([np.arange(C), np.arange(C) + 1], 1).astype(np.int32)
+    fes = [FrontEnd(360, 640, max_frames=C + 1, max_pairs=C, detector="sift") for _ in range(2)]
+    for f in fes:
+        f.upload(frames)
+
+    def key(r):
+        return np.concatenate([r[k].astype(np.float64).ravel() for k in ("status", "n_kp1", "n_match", "n_inl", "n_good", "ransac_iters", "R", "t", "E")])
+
+    fes[0].detect(0, C + 1)
+    ref = key(fes[0].run_pairs(pairs, K)[0])
+    feat = [fes[0].features(sl) for sl in (0, 3, C)]
+    assert min(len(f["xy"]) for f in feat) > 200
+    inflight = [None, None]
+    for it in range(10):
+        k = it % 2
+        if inflight[k] is not None:
+            fes[k].wait()
+            assert np.array_equal(key(inflight[k]), ref), f"chunk {it - 2} differs from the synchronous run"
+        fes[k].detect(0, C + 1, wait=False)
+        inflight[k] = fes[k].run_pairs(pairs, K, wait=False)[0]
+    for k in range(2):
+        fes[k].wait()
+        assert np.array_equal(key(inflight[k]), ref)
+        for sl, want in zip((0, 3, C), feat):
+            got = fes[k].features(sl)
+            for name in ("xy", "size", "angle", "response", "octave", "desc"):
+                assert np.array_equal(got[name], want[name]), (k, sl, name)
