@@ -44,66 +44,132 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* s_tmp, int tid, int* tot
 // ------------------------------------------------------------------ k_jpeg_unstuff
 // Byte i of the entropy-coded segment is dropped when it is the 00 of an FF 00 pair, a fill FF, or part of an RSTn
 // marker; any other FF xx ends the data.  An RSTn leaves its position in the clean stream in the restart list.
-// Every thread owns a contiguous run of bytes and reads it four at a time.
-struct UnstuffScan {
-    const uint8_t* raw; uint32_t n, lo, hi;
-    // calls f(i, c, keep, is_rst) for the bytes of [lo, min(hi, stop)); returns the index of the first terminating
-    // marker it met (then it stops there) or n
-    template <typename F>
-    __device__ __forceinline__ uint32_t run(uint32_t stop, F f) const
+// A WAVEFRONT owns a contiguous segment of the file and walks it 256 bytes at a time: one coalesced dword per lane, the byte
+// before and the byte after come from the neighbouring lanes, the positions of the kept bytes in the output are ballot
+// prefixes.  First walk: counts (lane-local sums); a scan over the eight wave totals; second walk: the writes.
+struct UnstuffWave {
+    const uint8_t* raw; uint32_t n;
+    // classifies the four bytes at `at` (this lane's dword of the 256-byte chunk): bit j of keep / rst for byte j; returns the
+    // position of the first terminating marker among them (or 0xffffffff)
+    __device__ __forceinline__ uint32_t load(uint32_t base, int lane) const
     {
-        int pv = lo > 0 ? raw[lo - 1] : 0;
-        for (uint32_t i = lo; i < hi && i < stop; i += 4) {
-            const uint32_t w = *(const u32_unaligned*)(raw + i);
-            const int after = i + 4 < n ? raw[i + 4] : 0xD9;
+        const uint32_t at = base + 4u * (uint32_t)lane;
+        return at < n ? *(const u32_unaligned*)(raw + at) : 0u;
+    }
+    // w: this lane's dword, wprev / wnext: the same lane's dword of the chunk before / after (their last / first byte are the
+    // neighbours of the chunk's ends: no extra loads on the critical path)
+    __device__ __forceinline__ uint32_t classify(uint32_t base, int lane, uint32_t hi, uint32_t w, uint32_t wprev, uint32_t wnext, int& keep, int& rst) const
+    {
+        const uint32_t at = base + 4u * (uint32_t)lane;
+        int pv = (int)(__shfl_up(w, 1, 64) >> 24), after = (int)(__shfl_down(w, 1, 64) & 255u);
+        const int pv0 = (int)((uint32_t)__shfl((int)wprev, 63, 64) >> 24), af63 = (int)((uint32_t)__shfl((int)wnext, 0, 64) & 255u);
+        if (lane == 0) pv = pv0;
+        if (lane == 63) after = at + 4 < n ? af63 : 0xD9;
+        uint32_t term = 0xffffffffu;
+        keep = 0; rst = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t at = i + j;
-                if (at >= hi || at >= stop) return n;
-                const int c = (int)((w >> (8 * j)) & 255u);
-                int nx = j < 3 ? (int)((w >> (8 * j + 8)) & 255u) : after;
-                if (at + 1 >= n) nx = 0xD9;
-                const bool rstn = nx >= 0xD0 && nx <= 0xD7;
-                if (c == 0xFF && nx != 0 && nx != 0xFF && !rstn) return at;                    // EOI or any other marker
-                const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
-                f(at, c, !drop, c == 0xFF && rstn);
-                pv = c;
-            }
+        for (int j = 0; j < 4; j++) {
+            const uint32_t p = at + j;
+            const int c = (int)((w >> (8 * j)) & 255u);
+            int nx = j < 3 ? (int)((w >> (8 * j + 8)) & 255u) : after;
+            if (p + 1 >= n) nx = 0xD9;
+            const bool rstn = nx >= 0xD0 && nx <= 0xD7;
+            const bool valid = p < hi;
+            if (valid && c == 0xFF && nx != 0 && nx != 0xFF && !rstn) term = min(term, p);     // EOI or any other marker
+            const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
+            if (valid && !drop) keep |= 1 << j;
+            if (valid && c == 0xFF && rstn) rst |= 1 << j;
+            pv = c;
         }
-        return n;
+        return term;
     }
 };
 
-__global__ __launch_bounds__(JPG_NT) void k_jpeg_unstuff(const uint8_t* blob, JpegImage* imgs, uint8_t* clean, uint32_t* rst)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    __shared__ int s_tmp[JPG_NT / 64];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+#define JPG_UNS_NT 1024                  // sixteen wavefronts per file: four per SIMD hide the shuffles and ballots of a chunk step
+__global__ __launch_bounds__(JPG_UNS_NT) void k_jpeg_unstuff(const uint8_t* blob, JpegImage* imgs, uint8_t* clean, uint32_t* rst)
+{
+    constexpr int NW = JPG_UNS_NT / 64;
+    __shared__ int s_keep[NW], s_nr[NW];
     __shared__ unsigned int s_end;
     JpegImage& im = imgs[blockIdx.x];
-    const int tid = threadIdx.x;
-    UnstuffScan sc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    UnstuffWave sc;
     sc.raw = blob + im.raw_off; sc.n = im.raw_len;
-    const uint32_t per = (((sc.n + JPG_NT - 1) / JPG_NT) + 3u) & ~3u;
-    sc.lo = min(sc.n, per * (uint32_t)tid); sc.hi = min(sc.n, sc.lo + per);
-    if (tid == 0) s_end = sc.n;
+    const uint32_t n = sc.n;
+    const uint32_t seg = (((n + NW - 1) / NW) + 255u) & ~255u;          // a whole number of 256-byte chunks per wavefront
+    const uint32_t lo = min(n, seg * (uint32_t)wave), hi = min(n, lo + seg);
+    if (tid == 0) s_end = n;
     __syncthreads();
-    int keep = 0, nr = 0;
-    const uint32_t my_end = sc.run(sc.n, [&](uint32_t, int, bool k, bool r) { keep += k; nr += r; });
-    if (my_end < sc.n) atomicMin(&s_end, my_end);
+    // 1. counts up to the first terminating marker of the segment
+    int keep_sum = 0, rst_sum = 0;
+    uint32_t my_end = 0xffffffffu;
+    // (the next chunk's dword is in flight while this one is classified; the byte before the segment rides in lane 63 of `wp`)
+    uint32_t wn = sc.load(lo, lane), wp = lo > 0 ? (uint32_t)sc.raw[lo - 1] << 24 : 0u, w = 0;
+    for (uint32_t base = lo; base < hi && my_end == 0xffffffffu; base += 256u) {
+        if (base > lo) wp = w;
+        w = wn; int km, rm;
+        wn = sc.load(base + 256u, lane);
+        const uint32_t t = sc.classify(base, lane, hi, w, wp, wn, km, rm);
+        if (__any(t != 0xffffffffu)) my_end = wave_min_u32(t);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool before = base + 4u * (uint32_t)lane + j < my_end;
+            keep_sum += before && ((km >> j) & 1); rst_sum += before && ((rm >> j) & 1);
+        }
+    }
+    if (my_end != 0xffffffffu && lane == 0) atomicMin(&s_end, my_end);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { keep_sum += __shfl_xor(keep_sum, d, 64); rst_sum += __shfl_xor(rst_sum, d, 64); }
     __syncthreads();
     const uint32_t end = s_end;
-    if (sc.lo >= end) { keep = 0; nr = 0; }                 // (a thread that starts before `end` stopped at `end` by itself)
-    int tot_keep, tot_r;
-    int kpos = wg_scan_excl(keep, s_tmp, tid, &tot_keep);
-    int rpos = wg_scan_excl(nr, s_tmp, tid, &tot_r);
+    if (lo >= end) { keep_sum = 0; rst_sum = 0; }           // (a segment that starts before `end` stopped at `end` by itself)
+    if (lane == 0) { s_keep[wave] = keep_sum; s_nr[wave] = rst_sum; }
+    __syncthreads();
+    int kpos = 0, rpos = 0, tot_keep = 0, tot_r = 0;
+#pragma unroll
+    for (int v = 0; v < NW; v++) { if (v < wave) { kpos += s_keep[v]; rpos += s_nr[v]; } tot_keep += s_keep[v]; tot_r += s_nr[v]; }
+    // 2. the writes: a kept byte goes to (bytes kept so far) + (kept bytes of lower lanes in the chunk) + (its own earlier bytes)
     uint8_t* out = clean + im.clean_off;
     uint32_t* rl = rst + im.rst_off;
     const uint32_t cap = im.rst_cap;
-    sc.run(end, [&](uint32_t, int c, bool k, bool r) {
-        if (r) { if ((uint32_t)rpos < cap) rl[rpos] = (uint32_t)kpos; rpos++; }
-        if (k) out[kpos++] = (uint8_t)c;
-    });
+    const uint32_t stop = min(hi, end);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    wn = sc.load(lo, lane); wp = lo > 0 ? (uint32_t)sc.raw[lo - 1] << 24 : 0u; w = 0;
+    for (uint32_t base = lo; base < stop; base += 256u) {
+        if (base > lo) wp = w;
+        w = wn; int km, rm;
+        wn = sc.load(base + 256u, lane);
+        sc.classify(base, lane, stop, w, wp, wn, km, rm);
+        int before_k = 0, chunk_k = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const unsigned long long bj = __ballot((km >> j) & 1); before_k += __popcll(bj & below); chunk_k += __popcll(bj); }
+        int o = kpos + before_k;
+        if (__any(rm != 0)) {                                  // restart markers: their clean-stream positions, in stream order
+            int before_r = 0, chunk_r = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const unsigned long long bj = __ballot((rm >> j) & 1); before_r += __popcll(bj & below); chunk_r += __popcll(bj); }
+            int ro = rpos + before_r, oo = o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((rm >> j) & 1) { if ((uint32_t)ro < cap) rl[ro] = (uint32_t)oo; ro++; }
+                oo += (km >> j) & 1;
+            }
+            rpos += chunk_r;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((km >> j) & 1) out[o++] = (uint8_t)(w >> (8 * j));
+        kpos += chunk_k;
+    }
     // zero padding after the data: a decoder that runs past the end reads zero bits (as libjpeg supplies them)
-    for (uint32_t i = (uint32_t)tot_keep + tid; i < (uint32_t)tot_keep + JPG_PAD; i += JPG_NT) out[i] = 0;
+    for (uint32_t i = (uint32_t)tot_keep + tid; i < (uint32_t)tot_keep + JPG_PAD; i += JPG_UNS_NT) out[i] = 0;
     if (tid == 0) { im.clean_len = (uint32_t)tot_keep; im.nrst = min((uint32_t)tot_r, cap); }
 }
 
@@ -537,7 +603,7 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const
 void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
                         int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h)
 {
-    hipLaunchKernelGGL(k_jpeg_unstuff, dim3(F), dim3(JPG_NT), 0, s, blob, imgs, clean, rst);
+    hipLaunchKernelGGL(k_jpeg_unstuff, dim3(F), dim3(JPG_UNS_NT), 0, s, blob, imgs, clean, rst);
     hipLaunchKernelGGL(k_jpeg_huffman, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, F), dim3(256), 0, s, imgs, tabs, coef, planes);
     hipLaunchKernelGGL(k_jpeg_color, dim3((max_w + 1023) / 1024, max_h, F), dim3(256), 0, s, imgs, planes, out);
