@@ -526,9 +526,12 @@ __device__ __forceinline__ uint32_t ld4(const uint8_t* row, int i0, int dw)
 
 __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const uint8_t* planes, uint8_t* out_all)
 {
-    const JpegImage& im = imgs[blockIdx.z];
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    const JpegImage& im = imgs[blockIdx.y];
     const int W = im.W, H = im.H;
+    // wavefront -> (row, 256-pixel piece of it), rows back to back (the division is scalar: a wavefront's property); at most one
+    // partly idle wavefront per row instead of a partly idle 1024-pixel workgroup
+    const int per_row = (W + 255) >> 8, idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int y = idx / per_row, x4 = ((idx - y * per_row) * 64 + (int)(threadIdx.x & 63)) * 4;
     if (y >= H || x4 >= W) return;
     const int mode = im.mode, nc = im.nc, ycc = im.ycc;
     const uint8_t* yrow = planes + im.plane_off[0] + (size_t)y * (im.bw[0] * 8);
@@ -583,17 +586,18 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const
         if (nc == 1) { px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (uint8_t)Y; continue; }
         if (!ycc) { px[3 * k] = (uint8_t)Cr[k]; px[3 * k + 1] = (uint8_t)Cb[k]; px[3 * k + 2] = (uint8_t)Y; continue; }   // stored R, G, B
         const int xb = Cb[k] - 128, xr = Cr[k] - 128;          // jdcolor.c build_ycc_rgb_table
-        const int R = Y + ((91881 * xr + 32768) >> 16);
-        const int G = Y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
-        const int B = Y + ((116130 * xb + 32768) >> 16);
+        // (24-bit multiplies: |xb|, |xr| <= 128 and the constants are below 2^17, so the products are exact — and full rate, where
+        //  a 32-bit v_mul_lo is a quarter-rate instruction)
+        const int R = Y + ((__mul24(91881, xr) + 32768) >> 16);
+        const int G = Y + ((__mul24(-22554, xb) + 32768 - __mul24(46802, xr)) >> 16);
+        const int B = Y + ((__mul24(116130, xb) + 32768) >> 16);
         px[3 * k] = (uint8_t)min(max(B, 0), 255); px[3 * k + 1] = (uint8_t)min(max(G, 0), 255); px[3 * k + 2] = (uint8_t)min(max(R, 0), 255);
     }
     const int nx = min(4, W - x4);
-    if (nx == 4 && (((size_t)(o - out_all)) & 3) == 0) {
-        uint32_t* o32 = (uint32_t*)o;
-        o32[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
-        o32[1] = px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24);
-        o32[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
+    if (nx == 4 && (((size_t)(o - out_all)) & 3) == 0) {       // one 12-byte store per lane: 768 contiguous bytes per wavefront
+        *(uint3*)o = make_uint3(px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24),
+                                px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24),
+                                px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24));
     } else {
         for (int k = 0; k < 3 * nx; k++) o[k] = px[k];
     }
@@ -606,5 +610,5 @@ void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, con
     hipLaunchKernelGGL(k_jpeg_unstuff, dim3(F), dim3(JPG_UNS_NT), 0, s, blob, imgs, clean, rst);
     hipLaunchKernelGGL(k_jpeg_huffman, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, F), dim3(256), 0, s, imgs, tabs, coef, planes);
-    hipLaunchKernelGGL(k_jpeg_color, dim3((max_w + 1023) / 1024, max_h, F), dim3(256), 0, s, imgs, planes, out);
+    hipLaunchKernelGGL(k_jpeg_color, dim3((unsigned)(((size_t)((max_w + 255) / 256) * max_h + 3) / 4), F), dim3(256), 0, s, imgs, planes, out);
 }
