@@ -213,6 +213,7 @@ struct JLocal {                                           // LDS copies of what 
     uint8_t zigzag[64];
     uint8_t dc_slot[JPG_MAX_BPM], ac_slot[JPG_MAX_BPM];
     unsigned long long slots;                            // 4 bits per block of the MCU: DC table | (AC table - 4) << 2
+    uint32_t comps;                                      // 2 bits per block of the MCU: its component
     int32_t bpm, ri, nrst, total_blocks;
     uint32_t clean_len;
 };
@@ -224,9 +225,12 @@ struct JLocal {                                           // LDS copies of what 
 // per SIMD pays ~20 cycles for every compare -> exec mask -> branch chain (283 k instructions per wave at 21 cycles each
 // with the branchy form).  Branches remain only around memory instructions and for the rare long codes; HAS_RST compiles the
 // restart-interval handling out for the files that have none.
+// DC values: dcs = the three components' running DC sums + "crossed a restart".  A counting pass starts them at zero and leaves
+// the thread's sums (since its last restart) for the scan over the threads; the writing pass starts them at the predictions that
+// scan gave the thread and stores every DC coefficient as the VALUE (prediction + difference) — no pass over the stored blocks.
 template <bool WRITE, bool HAS_RST>
 __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
-                                          JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done)
+                                          JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done, int (&dcs)[4])
 {
     JReader r; r.p = clean; r.limit = T.clean_len + JPG_PAD;
     if (st.bit >= boundary) return 0;
@@ -237,11 +241,16 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
     const int nrst = T.nrst, bpm = T.bpm;
     if (HAS_RST) {
         int lo = 0, hi = nrst;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rst[mid] * 8u > st.bit) hi = mid; else lo = mid + 1; }
+        // (a start exactly ON a restart position at an MCU boundary: the thread before stopped there without crossing it, or crossed
+        //  it with its last step — crossing it again is harmless, missing it would miss the reset of the DC predictions)
+        const uint32_t from = st.bit + (st.bk == 0 ? 0u : 1u);
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rst[mid] * 8u >= from) hi = mid; else lo = mid + 1; }
         rj = lo; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
     }
     const uint32_t total = (uint32_t)T.total_blocks;
     const unsigned long long slots = T.slots;
+    const uint32_t comps = T.comps;
+    int d0 = dcs[0], d1 = dcs[1], d2 = dcs[2], dreset = dcs[3];
     uint32_t pos = st.bit;
     while (pos < boundary && done < max_done) {
         r.refill();
@@ -253,6 +262,7 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
             if (rem == 0 || (r.buf >> (64 - rem)) == ((1ull << rem) - 1ull)) {
                 r.seek(ri_next); pos = ri_next;
                 rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
+                d0 = d1 = d2 = 0; dreset = 1;             // the predictions restart with the interval
                 continue;
             }
         }
@@ -280,7 +290,10 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
         const bool coefficient = dc || sz != 0;           // else ZRL (16 zeros) or end of block
         const int adv = coefficient ? run + 1 : run == 15 ? 16 : 64;
         k += adv;
-        if (WRITE && coefficient && k <= 64 && blk + done < total) coef[(size_t)(blk + done) * 64 + T.zigzag[k - 1]] = (int16_t)v;
+        const int cmp = (int)((comps >> (2 * b)) & 3u), dv = dc ? v : 0;
+        d0 += cmp == 0 ? dv : 0; d1 += cmp == 1 ? dv : 0; d2 += cmp == 2 ? dv : 0;
+        if (WRITE && coefficient && k <= 64 && blk + done < total)
+            coef[(size_t)(blk + done) * 64 + T.zigzag[k - 1]] = (int16_t)(dc ? (cmp == 0 ? d0 : cmp == 1 ? d1 : d2) : v);
         const bool end = k >= 64;
         k = end ? 0 : k;
         b = end ? (b + 1 == bpm ? 0 : b + 1) : b;
@@ -289,18 +302,20 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
         if (HAS_RST && pos > ri_next) {                   // ran across a restart boundary: only a mis-synchronised thread does
             r.seek(ri_next); pos = ri_next; b = 0; k = 0;
             rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
+            d0 = d1 = d2 = 0; dreset = 1;
         }
     }
+    dcs[0] = d0; dcs[1] = d1; dcs[2] = d2; dcs[3] = dreset;
     st.bit = pos; st.bk = ((uint32_t)b << 8) | (uint32_t)k;
     return done;
 }
 
 template <bool WRITE>
 __device__ __forceinline__ int jpg_span(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
-                                        JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done = 0x7fffffff)
+                                        JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int (&dcs)[4], int max_done = 0x7fffffff)
 {
-    if (T.ri && T.nrst) return jpg_span_t<WRITE, true>(T, clean, rst, st, boundary, coef, blk, max_done);
-    return jpg_span_t<WRITE, false>(T, clean, rst, st, boundary, coef, blk, max_done);
+    if (T.ri && T.nrst) return jpg_span_t<WRITE, true>(T, clean, rst, st, boundary, coef, blk, max_done, dcs);
+    return jpg_span_t<WRITE, false>(T, clean, rst, st, boundary, coef, blk, max_done, dcs);
 }
 
 __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const JpegTables* tabs, const uint8_t* clean_all,
@@ -311,7 +326,6 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     __shared__ int s_cnt[JPG_NT];
     __shared__ int s_tmp[JPG_NT / 64];
     __shared__ int s_dc[JPG_NT][4];                        // per-thread DC sums of three components + "saw a restart"
-    __shared__ int s_valid_mcus;
     const JpegImage& im = imgs[blockIdx.x];
     const JpegTables& G = tabs[im.tab_idx];
     const int tid = threadIdx.x;
@@ -325,12 +339,12 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         unsigned long long sl = 0;
         for (int j = 0; j < JPG_MAX_BPM; j++) { const int c = im.blk_comp[j < im.bpm ? j : 0]; sl |= (unsigned long long)((im.td[c] & 3) | ((im.ta[c] & 3) << 2)) << (4 * j); }
         T.slots = sl;
+        uint32_t cp = 0;
+        for (int j = 0; j < JPG_MAX_BPM && j < 16; j++) cp |= (uint32_t)(im.blk_comp[j < im.bpm ? j : 0] & 3) << (2 * j);
+        T.comps = cp;
     }
     if (tid == 0) { T.bpm = im.bpm; T.ri = im.ri; T.nrst = (int)im.nrst; T.total_blocks = im.total_blocks; T.clean_len = im.clean_len; }
     const int bpm = im.bpm, ri = im.ri, total_blocks = im.total_blocks, mcus_all = im.mx * im.my;
-    uint8_t comp_of[JPG_MAX_BPM];
-#pragma unroll
-    for (int j = 0; j < JPG_MAX_BPM; j++) comp_of[j] = im.blk_comp[j];
     const uint8_t* clean = clean_all + im.clean_off;
     const uint32_t* rst = rst_all + im.rst_off;
     int16_t* coef = coef_all + (size_t)im.coef_blk * 64;
@@ -343,7 +357,8 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     // 1. cold start: assume a block starts at the subsequence boundary (true for thread 0)
     JState mine; mine.bit = b0; mine.bk = 0;
     int cnt = 0;
-    if (live) cnt = jpg_span<false>(T, clean, rst, mine, b1, nullptr, 0);
+    int dcs[4] = {0, 0, 0, 0};                              // this thread's DC sums (of its latest decoding pass) + "crossed a restart"
+    if (live) cnt = jpg_span<false>(T, clean, rst, mine, b1, nullptr, 0, dcs);
     s_st[tid] = mine; s_cnt[tid] = cnt;
     __syncthreads();
     // 2. propagate end states until they are stable: thread i restarts from thread i-1's end state
@@ -360,57 +375,21 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         bool changed = false;
         if (redo) {
             JState st = prev;
-            const int c = jpg_span<false>(T, clean, rst, st, b1, nullptr, 0);
+            dcs[0] = dcs[1] = dcs[2] = dcs[3] = 0;
+            const int c = jpg_span<false>(T, clean, rst, st, b1, nullptr, 0, dcs);
             changed = st.bit != s_st[tid].bit || st.bk != s_st[tid].bk;
             s_st[tid] = st; s_cnt[tid] = c; used = prev;
         }
         if (!__syncthreads_or(changed ? 1 : 0)) { if (tid == 0) imgs[blockIdx.x].sync_rounds = (uint32_t)round + 1; break; }
     }
     __syncthreads();
-    // 3. first coefficient block of every subsequence; 4. decode once more, writing
+    // 3. first coefficient block of every subsequence, and the DC predictions it starts with: a segmented scan of the threads' DC
+    //    sums (operator (a, b) -> b.reset ? b : a + b: the predictions restart with every restart interval)
     int total_cnt;
     const int first = wg_scan_excl(live ? s_cnt[tid] : 0, s_tmp, tid, &total_cnt);
-    if (live) {
-        JState st; st.bit = 0; st.bk = 0;
-        if (tid > 0) st = s_st[tid - 1];
-        jpg_span<true>(T, clean, rst, st, b1, coef, (uint32_t)first);
-    }
-    // 4b. a file whose data ends early (truncated, or cut by a stray marker): libjpeg decodes the MCU in which the data
-    //     ran out from zero bits and leaves every later MCU all-zero (jdhuff.c: insufficient_data) — the last
-    //     subsequence's owner finishes that MCU from the zero padding, the MCUs after it keep their cleared coefficients
-    if (tid == 0) s_valid_mcus = mcus_all;
+    s_dc[tid][0] = live ? dcs[0] : 0; s_dc[tid][1] = live ? dcs[1] : 0; s_dc[tid][2] = live ? dcs[2] : 0; s_dc[tid][3] = live ? dcs[3] : 0;
     __syncthreads();
-    if (total_cnt < total_blocks) {
-        const int last = (int)min((uint32_t)(JPG_NT - 1), (nbits ? (nbits - 1) / (sub * 8u) : 0u));
-        if (tid == last) {
-            JState st = s_st[last];
-            if (nbits == 0) { st.bit = 0; st.bk = 0; }
-            const int mcu = total_cnt / bpm;
-            if (st.bk == 0 && st.bit > nbits) s_valid_mcus = mcu;       // the MCU just completed already took bits past the end: it was the one
-            else {
-                jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, (mcu + 1) * bpm - total_cnt);
-                s_valid_mcus = mcu + 1;
-            }
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // 5. DC differences -> DC values: a segmented scan over the MCUs (the prediction restarts every `ri` MCUs)
-    const int mcus = s_valid_mcus, per = (mcus + JPG_NT - 1) / JPG_NT;
-    const int m0 = min(mcus, per * tid), m1 = min(mcus, m0 + per);
-    int sum[3] = {0, 0, 0}, reset = 0;
-    for (int m = m0; m < m1; m++) {
-        if (ri && m % ri == 0) { sum[0] = sum[1] = sum[2] = 0; reset = 1; }
-#pragma unroll
-        for (int j = 0; j < JPG_MAX_BPM; j++)
-            if (j < bpm) {
-                const int d = coef[((size_t)m * bpm + j) * 64], c = comp_of[j];
-                sum[0] += c == 0 ? d : 0; sum[1] += c == 1 ? d : 0; sum[2] += c == 2 ? d : 0;
-            }
-    }
-    s_dc[tid][0] = sum[0]; s_dc[tid][1] = sum[1]; s_dc[tid][2] = sum[2]; s_dc[tid][3] = reset;
-    __syncthreads();
-    for (int d = 1; d < JPG_NT; d <<= 1) {                 // inclusive scan with the operator (a, b) -> b.reset ? b : a + b
+    for (int d = 1; d < JPG_NT; d <<= 1) {
         int a0 = 0, a1 = 0, a2 = 0, ar = 0;
         const bool has = tid >= d;
         if (has) { a0 = s_dc[tid - d][0]; a1 = s_dc[tid - d][1]; a2 = s_dc[tid - d][2]; ar = s_dc[tid - d][3]; }
@@ -418,19 +397,29 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         if (has && !s_dc[tid][3]) { s_dc[tid][0] += a0; s_dc[tid][1] += a1; s_dc[tid][2] += a2; s_dc[tid][3] = ar; }
         __syncthreads();
     }
-    int p0 = 0, p1 = 0, p2 = 0;
-    if (tid > 0) { p0 = s_dc[tid - 1][0]; p1 = s_dc[tid - 1][1]; p2 = s_dc[tid - 1][2]; }
-    for (int m = m0; m < m1; m++) {
-        if (ri && m % ri == 0) p0 = p1 = p2 = 0;
-#pragma unroll
-        for (int j = 0; j < JPG_MAX_BPM; j++)
-            if (j < bpm) {
-                int16_t* p = coef + ((size_t)m * bpm + j) * 64;
-                const int c = comp_of[j], d = *p;
-                p0 += c == 0 ? d : 0; p1 += c == 1 ? d : 0; p2 += c == 2 ? d : 0;
-                *p = (int16_t)(c == 0 ? p0 : c == 1 ? p1 : p2);
-            }
+    dcs[0] = dcs[1] = dcs[2] = dcs[3] = 0;
+    if (tid > 0) { dcs[0] = s_dc[tid - 1][0]; dcs[1] = s_dc[tid - 1][1]; dcs[2] = s_dc[tid - 1][2]; }
+    // 4. decode once more, writing (DC coefficients as values: prediction + difference)
+    if (live) {
+        JState st; st.bit = 0; st.bk = 0;
+        if (tid > 0) st = s_st[tid - 1];
+        jpg_span<true>(T, clean, rst, st, b1, coef, (uint32_t)first, dcs);
     }
+    // 4b. a file whose data ends early (truncated, or cut by a stray marker): libjpeg decodes the MCU in which the data
+    //     ran out from zero bits and leaves every later MCU all-zero (jdhuff.c: insufficient_data) — the last
+    //     subsequence's owner finishes that MCU from the zero padding (its predictions stand where its data ended), the MCUs
+    //     after it keep their cleared coefficients
+    if (total_cnt < total_blocks) {
+        const int last = (int)min((uint32_t)(JPG_NT - 1), (nbits ? (nbits - 1) / (sub * 8u) : 0u));
+        if (tid == last) {
+            JState st = s_st[last];
+            if (nbits == 0) { st.bit = 0; st.bk = 0; }
+            const int mcu = total_cnt / bpm;
+            if (!(st.bk == 0 && st.bit > nbits))                         // (else the MCU just completed already took bits past the end: it was the one)
+                jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, dcs, (mcu + 1) * bpm - total_cnt);
+        }
+    }
+    (void)ri; (void)mcus_all;
 }
 
 // ------------------------------------------------------------------ k_jpeg_idct  (jidctint.c jpeg_idct_islow)
