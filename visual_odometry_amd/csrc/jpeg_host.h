@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include "../../include/vo_hip.h"
 
-#define JPG_NT 512               // threads of the two entropy kernels = subsequences per image
+#ifndef JPG_NT
+#define JPG_NT 512               // threads of the Huffman kernel = subsequences per image
+#endif
 #define JPG_LOOK 10              // bits of Huffman look-ahead table
 #define JPG_LONG 4                // long-code prefixes per table with a second-level table
 #define JPG_PAD 16               // zero bytes after every clean stream

@@ -174,6 +174,9 @@ __global__ __launch_bounds__(JPG_UNS_NT) void k_jpeg_unstuff(const uint8_t* blob
 }
 
 // ------------------------------------------------------------------ k_jpeg_huffman
+#ifndef JPG_MIN_SUB
+#define JPG_MIN_SUB 32                    // bytes of a subsequence at least
+#endif
 struct JState { uint32_t bit; uint32_t bk; };              // position in the clean stream, (block in MCU << 8) | coefficient index
 
 struct JReader {
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     int16_t* coef = coef_all + (size_t)im.coef_blk * 64;
     const uint32_t nbits = im.clean_len * 8u;
     // one subsequence per thread, a whole number of bytes, at least 32 bytes
-    uint32_t sub = (im.clean_len + JPG_NT - 1) / JPG_NT; sub = sub < 32 ? 32 : sub;
+    uint32_t sub = (im.clean_len + JPG_NT - 1) / JPG_NT; sub = sub < JPG_MIN_SUB ? JPG_MIN_SUB : sub;
     const uint32_t b0 = min(nbits, sub * 8u * (uint32_t)tid), b1 = min(nbits, b0 + sub * 8u);
     const bool live = b0 < nbits;                          // threads past the end of the data hold empty subsequences
     __syncthreads();
