@@ -13,7 +13,7 @@
 //                    G[i] - G[i-1], formed while G[i-1] is still in LDS.  A workgroup owns a 128-column strip and sweeps
 //                    it top to bottom eight rows at a time: rows stream HBM -> registers -> LDS one step ahead of their use,
 //                    row-filtered rows live in an LDS ring, every source plane is read once and every output written once
-//   k_sb_half        INTER_NEAREST half-size (first image of the next octave)
+//                    (the sweep that makes layer nOctaveLayers also writes it at half size, INTER_NEAREST: the next octave's first image)
 //   k_sb_extrema     26-neighbour extrema of the DoG stack above the contrast pre-threshold: a workgroup streams a
 //                    62-column strip of the three planes top to bottom (rows in registers, column maxima shared through
 //                    LDS); a pixel is an extremum iff it equals the max (min) of the 3 x 3 x 3 block
@@ -126,16 +126,6 @@ __global__ __launch_bounds__(256) void k_sb_base(const uint8_t* src, int channel
     else for (int j = 0; j < 4 && dx0 + j < dw; j++) o[j] = out[j];
 }
 
-__global__ __launch_bounds__(256) void k_sb_half(const float* src, size_t sframe, int sw, int sh, int sstride,
-                                                 float* dst, size_t dframe, int dw, int dh, int dstride)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= dw) return;
-    const double fx = (double)sw / dw, fy = (double)sh / dh;
-    const int sx = min((int)floor(x * fx), sw - 1), sy = min((int)floor(y * fy), sh - 1);
-    dst[(size_t)blockIdx.z * dframe + (size_t)y * dstride + x] = src[(size_t)blockIdx.z * sframe + (size_t)sy * sstride + sx];
-}
-
 // ------------------------------------------------------------------ one scale-space layer: Gaussian blur + DoG, one sweep
 #define SW_TW 128                      // columns of a strip
 #define SW_RS 8                        // source rows per step
@@ -168,7 +158,7 @@ struct SweepDims {
 
 template <int N>
 __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs,
-                                                         int w, int h, int stride, int seg, SiftTaps t)
+                                                         int w, int h, int stride, int seg, SiftTaps t, float* dstH, size_t h_fs, int hstride, int hw, int hh)
 {
     typedef SweepDims<N> DM;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -197,6 +187,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     src += (size_t)blockIdx.z * src_fs;
     if (dstG) dstG += (size_t)blockIdx.z * g_fs;
     if (dstD) dstD += (size_t)blockIdx.z * d_fs;
+    if (dstH) dstH += (size_t)blockIdx.z * h_fs;      // the next octave's first image: this layer at half size (INTER_NEAREST: every other pixel of every other row)
     const int xa = x0 - R4;                                // first source column of a segment (multiple of 4)
     const bool interior = xa >= 0 && xa + INW <= w;        // whole segments inside the image: aligned 16-byte loads, no reflection
     const int per_row = INW / 4;                           // 16-byte pieces of a row segment (<= 48)
@@ -306,6 +297,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
                         }
                         if (two) { if (dstG) *(v2f*)(dstG + o) = acc[q]; if (dstD) *(v2f*)(dstD + o) = dg; }
                         else { if (dstG) dstG[o] = acc[q].x; if (dstD) dstD[o] = dg.x; }
+                        // (row y of q = 0 and column x are even: steps, segments and a thread's column pair start at even indices)
+                        if (dstH && q == 0 && (y >> 1) < hh && (x >> 1) < hw) dstH[(size_t)(y >> 1) * hstride + (x >> 1)] = acc[0].x;
                     }
                 }
             }
@@ -962,13 +955,9 @@ void launch_sb_base(hipStream_t s, const uint8_t* src, int channels, int row_str
     hipLaunchKernelGGL(k_sb_base, dim3((2 * sw + 1023) / 1024, 2 * sh, F), dim3(256), 0, s, src, channels, row_stride, frame_stride, sw, sh, dst, dstride, dframe);
 }
 
-void launch_sb_half(hipStream_t s, const float* src, size_t sframe, int sw, int sh, int sstride, float* dst, size_t dframe, int dw, int dh, int dstride, int F)
-{
-    hipLaunchKernelGGL(k_sb_half, dim3((dw + 255) / 256, dh, F), dim3(256), 0, s, src, sframe, sw, sh, sstride, dst, dframe, dw, dh, dstride);
-}
-
 template <int N>
-static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F, const SiftTaps& t)
+static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F, const SiftTaps& t,
+                    float* dstH, size_t h_fs, int hstride, int hw, int hh)
 {
     // segments: tall enough that the 2 r halo rows stay a small fraction, short enough that a small batch still fills the chip
     const int strips = (w + SW_TW - 1) / SW_TW;
@@ -977,20 +966,20 @@ static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG,
     const int n = N > 0 ? N : t.n, r = n / 2, R4 = (r + 3) & ~3;
     const size_t lds = N > 0 ? (size_t)SweepDims<N>::LDS_FLOATS * 4
                              : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + (SweepDims<0>::CTR ? ((r + SW_RS + 7) & ~7) : 0)) * SW_TW) * 4;
-    hipLaunchKernelGGL(k_sb_sweep<N>, dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t);
+    hipLaunchKernelGGL(k_sb_sweep<N>, dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t, dstH, h_fs, hstride, hw, hh);
 }
 
 int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
-                    const float* taps, int ntaps)
+                    const float* taps, int ntaps, float* dstH, size_t h_fs, int hstride, int hw, int hh)
 {
     if (ntaps < 1 || ntaps > SW_NMAX || !(ntaps & 1)) return -1;
     SiftTaps t; t.n = ntaps;
     for (int i = 0; i < SIFT_MAX_TAPS; i++) t.k[i] = i < ntaps ? taps[i] : 0.f;
     switch (ntaps) {                                        // the sizes cv2's defaults produce are 11, 13, 17, 21, 27
-#define SW_CASE(N) case N: sweep_n<N>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t); break;
+#define SW_CASE(N) case N: sweep_n<N>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh); break;
         SW_CASE(11) SW_CASE(13) SW_CASE(17) SW_CASE(21) SW_CASE(27)
 #undef SW_CASE
-        default: sweep_n<0>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t);
+        default: sweep_n<0>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh);
     }
     return 0;
 }

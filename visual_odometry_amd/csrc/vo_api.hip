@@ -1860,13 +1860,14 @@ static int sift_detect_enqueue(vo_ctx* ctx, SiftState& S, const uint8_t* src, in
         {
             StageTimer t(ctx, ST_SIFT_SCALE);
             float* g0 = S.G + P.goff[o];
-            if (o > 0) launch_sb_half(s, S.G + P.goff[o - 1] + (size_t)L * P.plane[o - 1], P.gframe, P.w[o - 1], P.h[o - 1], P.stride[o - 1],
-                                      g0, P.gframe, P.w[o], P.h[o], P.stride[o], F);
             for (int i = 1; i < L + 3; i++) {
-                // G[i] = blur(G[i-1]) and D[i-1] = G[i] - G[i-1] in one pass; the last Gaussian of the octave is not stored
+                // G[i] = blur(G[i-1]) and D[i-1] = G[i] - G[i-1] in one pass; the last Gaussian of the octave is not stored; the sweep
+                // that makes layer L also writes it at half size: the first image of the next octave (cv::resize INTER_NEAREST)
                 float* gi = i < L + 2 ? g0 + (size_t)i * P.plane[o] : nullptr;
+                const bool seed = i == L && o + 1 < P.nOct;
                 launch_sb_sweep(s, g0 + (size_t)(i - 1) * P.plane[o], P.gframe, gi, P.gframe, S.D + P.doff[o] + (size_t)(i - 1) * P.plane[o], P.dframe,
-                                P.w[o], P.h[o], P.stride[o], F, S.taps[i], S.ntaps[i]);
+                                P.w[o], P.h[o], P.stride[o], F, S.taps[i], S.ntaps[i],
+                                seed ? S.G + P.goff[o + 1] : nullptr, P.gframe, seed ? P.stride[o + 1] : 0, seed ? P.w[o + 1] : 0, seed ? P.h[o + 1] : 0);
             }
         }
         { StageTimer t(ctx, ST_SIFT_EXTREMA); launch_sb_extrema(s, P, S.D, o, threshold, S.cand, S.counts, S.cand_cap, F); }

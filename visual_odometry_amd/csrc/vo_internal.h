@@ -179,9 +179,8 @@ struct SiftSurv { SiftKp kp; int o, layer, r, c; };      // a refined extremum a
 struct SiftExpTab { float tab[64]; };                   // 2^(i/64), the table of cv::hal::exp32f
 // per-frame counters of a sub-batch: counts[f][4] = {extrema candidates, refined extrema, oriented keypoints, final keypoints}
 void launch_sb_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh, float* dst, int dstride, size_t dframe, int F);
-void launch_sb_half(hipStream_t s, const float* src, size_t sframe, int sw, int sh, int sstride, float* dst, size_t dframe, int dw, int dh, int dstride, int F);
 int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
-                    const float* taps, int ntaps);
+                    const float* taps, int ntaps, float* dstH = nullptr, size_t h_fs = 0, int hstride = 0, int hw = 0, int hh = 0);
 void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o, float threshold, SiftCand* cand, int* counts, int cap, int F);
 void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr,
                              float edgeThr, float sigma, const SiftExpTab& E, SiftSurv* surv, int surv_cap, SiftKp* kps, int kp_cap, int* counts, int F, int waves);
