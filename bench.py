@@ -52,8 +52,8 @@ STAGE_KERNELS = {"fast_score_nms": [("k_fast<false>", 1)], "gaussian_blur": [("k
                  "match_nn": [("k_nn_fp4<false>", 1)], "essential_ransac": [("k_ransac", 1)], "recover_pose": [("k_pose", 1)],
                  "cv2_keypoint_order": [("k_cv2_order", 1), ("k_sel_rows<false>", 1), ("k_sel_rows<true>", 1)],
                  "sift_descriptor": [("k_sb_descriptor", 1)], "sift_extrema": [("k_sb_extrema<5>", 9)],
-                 "sift_scale_space": [("k_sb_sweep<11>", 10), ("k_sb_sweep<13>", 9), ("k_sb_sweep<17>", 9), ("k_sb_sweep<21>", 9), ("k_sb_sweep<27>", 9),
-                                      ("k_sb_base", 1)],
+                 "sift_scale_space": [("k_sb_sweep<11, true>", 1), ("k_sb_sweep<11, false>", 8), ("k_sb_sweep<13, false>", 8), ("k_sb_sweep<17, false>", 8),
+                                      ("k_sb_sweep<21, false>", 8), ("k_sb_sweep<27, false>", 8)],
                  "sift_refine_orient": [("k_sb_refine", 1), ("k_sb_orient", 1)]}
 STAGE_BOUND = {"gray": "hbm", "pyramid_resize": "hbm", "fast_score_nms": "hbm", "gaussian_blur": "hbm", "sift_scale_space": "hbm",
                "sift_extrema": "hbm", "match_nn": "mfma", "essential_ransac": "latency", "recover_pose": "latency", "triangulate": "latency",

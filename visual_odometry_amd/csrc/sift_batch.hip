@@ -7,7 +7,7 @@
 // Every kernel takes a batch of frames (grid.z or grid.y = frame); nothing returns to the host between the stages —
 // candidate / survivor / keypoint counts stay in HBM.  One frame's scale space is 5 Gaussian + 5 DoG float planes per
 // octave (the 6th Gaussian of an octave only exists inside the kernel that forms the last DoG plane):
-//   k_sb_base        gray -> float -> 2x INTER_LINEAR up-sampling (createInitialImage)
+//   (createInitialImage: gray -> float -> 2x INTER_LINEAR up-sampling is done by the loader of the first sweep; the base image is never stored)
 //   k_sb_sweep<N>    ONE pass per scale-space layer: separable float Gaussian (BORDER_REFLECT_101; row taps left to right,
 //                    column taps centre first then symmetric pairs: RowFilter / SymmColumnFilter) + the DoG plane
 //                    G[i] - G[i-1], formed while G[i-1] is still in LDS.  A workgroup owns a 128-column strip and sweeps
@@ -83,30 +83,46 @@ __device__ __forceinline__ int sd_wave_scan(int x)
 __device__ __forceinline__ int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; }
 
 // ------------------------------------------------------------------ base image
-// A thread makes FOUR consecutive destination pixels (one 16-byte store) from the 4 x 2 source pixels they touch; the weights
-// and the border rule are cv::resize's (INTER_LINEAR, float coefficients: 0.25 / 0.75, or 0 / 1 where the source index is
+// createInitialImage's 2 x INTER_LINEAR up-sampling, made on the fly by the loader of the FIRST sweep (the base image itself is never
+// stored): the weights and the border rule are cv::resize's (float coefficients: 0.25 / 0.75, or 0 / 1 where the source index is
 // clamped — a clamped tap has weight 0, so which finite neighbour stands in for it does not matter).
-__global__ __launch_bounds__(256) void k_sb_base(const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh,
-                                                 float* dst, int dstride, size_t dframe)
+struct SiftBaseSrc { const uint8_t* img; int channels, row_stride, sw, sh; long long frame_stride; };
+__device__ __forceinline__ float sb_src_px(const SiftBaseSrc& B, const uint8_t* f, int y, int x)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, dx0 = 4 * t, dy = blockIdx.y, dw = 2 * sw;
-    if (dx0 >= dw) return;
-    src += (size_t)blockIdx.z * frame_stride;
+    const uint8_t* p = f + (size_t)y * B.row_stride + (size_t)x * B.channels;
+    const int v = B.channels == 1 ? p[0] : (p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15;
+    return (float)v;
+}
+// destination row dy -> source rows sy, sy1 and their weights
+__device__ __forceinline__ void sb_base_row(const SiftBaseSrc& B, int dy, int& sy, int& sy1, float& b0, float& b1)
+{
     float fy = (float)((dy + 0.5) * 0.5 - 0.5);
-    int sy = (int)floorf(fy);
+    sy = (int)floorf(fy);
     fy -= (float)sy;
     if (sy < 0) { fy = 0; sy = 0; }
-    if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
-    const int sy1 = min(sy + 1, sh - 1);
-    auto px = [&](int y, int x) -> float {
-        const uint8_t* p = src + (size_t)y * row_stride + (size_t)x * channels;
-        const int v = channels == 1 ? p[0] : (p[0] * 3735 + p[1] * 19235 + p[2] * 9798 + (1 << 14)) >> 15;
-        return (float)v;
-    };
+    if (sy >= B.sh - 1) { fy = 0; sy = B.sh - 1; }
+    sy1 = min(sy + 1, B.sh - 1);
+    b0 = 1.f - fy; b1 = fy;
+}
+__device__ __forceinline__ float sb_base_px(const SiftBaseSrc& B, const uint8_t* f, int sy, int sy1, float b0, float b1, int dx)
+{
+    float fx = (float)((dx + 0.5) * 0.5 - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= B.sw - 1) { fx = 0; sx = B.sw - 1; }
+    const int sx1 = min(sx + 1, B.sw - 1);
+    const float a0 = 1.f - fx, a1 = fx;
+    const float r0 = sb_src_px(B, f, sy, sx) * a0 + sb_src_px(B, f, sy, sx1) * a1, r1 = sb_src_px(B, f, sy1, sx) * a0 + sb_src_px(B, f, sy1, sx1) * a1;
+    return r0 * b0 + r1 * b1;
+}
+// four consecutive destination pixels dx0 .. dx0 + 3 (dx0 a multiple of 4, all inside the image) from the 4 x 2 source pixels they touch
+__device__ __forceinline__ float4 sb_base_px4(const SiftBaseSrc& B, const uint8_t* f, int sy, int sy1, float b0, float b1, int dx0)
+{
+    const int t = dx0 >> 2;
     float v0[4], v1[4];                                       // source columns 2 t - 1 .. 2 t + 2 (clamped) of the two rows
 #pragma unroll
-    for (int i = 0; i < 4; i++) { const int c = min(max(2 * t - 1 + i, 0), sw - 1); v0[i] = px(sy, c); v1[i] = px(sy1, c); }
-    const float b0 = 1.f - fy, b1 = fy;
+    for (int i = 0; i < 4; i++) { const int c = min(max(2 * t - 1 + i, 0), B.sw - 1); v0[i] = sb_src_px(B, f, sy, c); v1[i] = sb_src_px(B, f, sy1, c); }
     float out[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -115,15 +131,13 @@ __global__ __launch_bounds__(256) void k_sb_base(const uint8_t* src, int channel
         int sx = (int)floorf(fx);
         fx -= (float)sx;
         if (sx < 0) { fx = 0; sx = 0; }
-        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        if (sx >= B.sw - 1) { fx = 0; sx = B.sw - 1; }
         const int n0 = (j + 1) >> 1;                          // first tap among the four cached columns: 0, 1, 1, 2
         const float a0 = 1.f - fx, a1 = fx;
         const float r0 = v0[n0] * a0 + v0[n0 + 1] * a1, r1 = v1[n0] * a0 + v1[n0 + 1] * a1;
         out[j] = r0 * b0 + r1 * b1;
     }
-    float* o = dst + (size_t)blockIdx.z * dframe + (size_t)dy * dstride + dx0;
-    if (dx0 + 3 < dw) *(float4*)o = make_float4(out[0], out[1], out[2], out[3]);
-    else for (int j = 0; j < 4 && dx0 + j < dw; j++) o[j] = out[j];
+    return make_float4(out[0], out[1], out[2], out[3]);
 }
 
 // ------------------------------------------------------------------ one scale-space layer: Gaussian blur + DoG, one sweep
@@ -156,9 +170,10 @@ struct SweepDims {
     static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + (CTR ? CRING * SW_TW : 0);
 };
 
-template <int N>
+template <int N, bool BASE>
 __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs,
-                                                         int w, int h, int stride, int seg, SiftTaps t, float* dstH, size_t h_fs, int hstride, int hw, int hh)
+                                                         int w, int h, int stride, int seg, SiftTaps t, float* dstH, size_t h_fs, int hstride, int hw, int hh,
+                                                         SiftBaseSrc B)
 {
     typedef SweepDims<N> DM;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
@@ -184,7 +199,8 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * SW_TW, Y0 = blockIdx.y * seg, Y1 = min(h, Y0 + seg);
     if (Y0 >= h) return;
-    src += (size_t)blockIdx.z * src_fs;
+    if (!BASE) src += (size_t)blockIdx.z * src_fs;
+    const uint8_t* bimg = BASE ? B.img + (size_t)blockIdx.z * B.frame_stride : nullptr;    // BASE: the source is the 2 x up-sampled input image, made here
     if (dstG) dstG += (size_t)blockIdx.z * g_fs;
     if (dstD) dstD += (size_t)blockIdx.z * d_fs;
     if (dstH) dstH += (size_t)blockIdx.z * h_fs;      // the next octave's first image: this layer at half size (INTER_NEAREST: every other pixel of every other row)
@@ -200,8 +216,18 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int yy = reflect101(Y0 - r + k * SW_RS + wave + 4 * q, h);
-            const float* p = src + (size_t)yy * stride;
             const int x = xa + 4 * lane;
+            if (BASE) {
+                int sy, sy1; float b0, b1;
+                sb_base_row(B, yy, sy, sy1, b0, b1);
+                if (lane < per_row) {
+                    if (interior) ld[q] = sb_base_px4(B, bimg, sy, sy1, b0, b1, x);
+                    else { ld[q].x = sb_base_px(B, bimg, sy, sy1, b0, b1, reflect101(x, w)); ld[q].y = sb_base_px(B, bimg, sy, sy1, b0, b1, reflect101(x + 1, w));
+                           ld[q].z = sb_base_px(B, bimg, sy, sy1, b0, b1, reflect101(x + 2, w)); ld[q].w = sb_base_px(B, bimg, sy, sy1, b0, b1, reflect101(x + 3, w)); }
+                }
+                continue;
+            }
+            const float* p = src + (size_t)yy * stride;
             if (lane < per_row) {
                 if (interior) ld[q] = *(const float4*)(p + x);
                 else { ld[q].x = p[reflect101(x, w)]; ld[q].y = p[reflect101(x + 1, w)]; ld[q].z = p[reflect101(x + 2, w)]; ld[q].w = p[reflect101(x + 3, w)]; }
@@ -950,14 +976,9 @@ __global__ __launch_bounds__(256) void k_sb_unpack(const SiftKp* kps, int kp_cap
 }
 
 // ------------------------------------------------------------------ launchers
-void launch_sb_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh, float* dst, int dstride, size_t dframe, int F)
-{
-    hipLaunchKernelGGL(k_sb_base, dim3((2 * sw + 1023) / 1024, 2 * sh, F), dim3(256), 0, s, src, channels, row_stride, frame_stride, sw, sh, dst, dstride, dframe);
-}
-
-template <int N>
+template <int N, bool BASE>
 static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F, const SiftTaps& t,
-                    float* dstH, size_t h_fs, int hstride, int hw, int hh)
+                    float* dstH, size_t h_fs, int hstride, int hw, int hh, const SiftBaseSrc& B)
 {
     // segments: tall enough that the 2 r halo rows stay a small fraction, short enough that a small batch still fills the chip
     const int strips = (w + SW_TW - 1) / SW_TW;
@@ -966,7 +987,7 @@ static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG,
     const int n = N > 0 ? N : t.n, r = n / 2, R4 = (r + 3) & ~3;
     const size_t lds = N > 0 ? (size_t)SweepDims<N>::LDS_FLOATS * 4
                              : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + (SweepDims<0>::CTR ? ((r + SW_RS + 7) & ~7) : 0)) * SW_TW) * 4;
-    hipLaunchKernelGGL(k_sb_sweep<N>, dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t, dstH, h_fs, hstride, hw, hh);
+    hipLaunchKernelGGL((k_sb_sweep<N, BASE>), dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t, dstH, h_fs, hstride, hw, hh, B);
 }
 
 int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
@@ -975,12 +996,26 @@ int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG,
     if (ntaps < 1 || ntaps > SW_NMAX || !(ntaps & 1)) return -1;
     SiftTaps t; t.n = ntaps;
     for (int i = 0; i < SIFT_MAX_TAPS; i++) t.k[i] = i < ntaps ? taps[i] : 0.f;
+    const SiftBaseSrc none = {nullptr, 0, 0, 0, 0, 0};
     switch (ntaps) {                                        // the sizes cv2's defaults produce are 11, 13, 17, 21, 27
-#define SW_CASE(N) case N: sweep_n<N>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh); break;
+#define SW_CASE(N) case N: sweep_n<N, false>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh, none); break;
         SW_CASE(11) SW_CASE(13) SW_CASE(17) SW_CASE(21) SW_CASE(27)
 #undef SW_CASE
-        default: sweep_n<0>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh);
+        default: sweep_n<0, false>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh, none);
     }
+    return 0;
+}
+
+// the first sweep of the scale space: source = the input frames (u8, 1 / 3 / 4 channels), up-sampled 2 x by the loader (createInitialImage)
+int launch_sb_sweep_base(hipStream_t s, const uint8_t* img, int channels, int row_stride, int64_t frame_stride, int sw, int sh,
+                         float* dstG, size_t g_fs, int stride, int F, const float* taps, int ntaps)
+{
+    if (ntaps < 1 || ntaps > SW_NMAX || !(ntaps & 1)) return -1;
+    SiftTaps t; t.n = ntaps;
+    for (int i = 0; i < SIFT_MAX_TAPS; i++) t.k[i] = i < ntaps ? taps[i] : 0.f;
+    const SiftBaseSrc B = {img, channels, row_stride, sw, sh, (long long)frame_stride};
+    if (ntaps == 11) sweep_n<11, true>(s, nullptr, 0, dstG, g_fs, nullptr, 0, 2 * sw, 2 * sh, stride, F, t, nullptr, 0, 0, 0, 0, B);
+    else sweep_n<0, true>(s, nullptr, 0, dstG, g_fs, nullptr, 0, 2 * sw, 2 * sh, stride, F, t, nullptr, 0, 0, 0, 0, B);
     return 0;
 }
 

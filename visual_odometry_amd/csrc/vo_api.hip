@@ -1792,7 +1792,7 @@ static int sift_setup(vo_ctx* ctx, SiftState& S, int h, int w, const vo_sift_par
     sift_free(S);
     S.h = h; S.w = w; S.prm = *p; S.max_frames = max_frames; S.kp_cap = kp_cap; S.raw_cap = raw_cap; S.cand_cap = cand_cap; S.surv_cap = surv_cap;
     S.fb = fb; S.with_operands = with_operands; S.cap_x = desc_x_rows(kp_cap);
-    S.fstride = w;                                             // dense rows: a batch of frames is one transfer (k_sb_base reads bytes)
+    S.fstride = w;                                             // dense rows: a batch of frames is one transfer (the first sweep's loader reads bytes)
     const int L = p->n_octave_layers;
     SiftGeom& P = S.P; memset(&P, 0, sizeof(P));
     P.nLayers = L;
@@ -1832,7 +1832,7 @@ static int sift_setup(vo_ctx* ctx, SiftState& S, int h, int w, const vo_sift_par
         HIPCHK(dmalloc(&S.desc_x, F * (size_t)S.cap_x * 128)); HIPCHK(dmalloc(&S.norms, F * (size_t)S.cap_x));
         HIPCHK(hipMemset(S.desc_x, 0, F * (size_t)S.cap_x * 128)); HIPCHK(hipMemset(S.norms, 0, F * (size_t)S.cap_x * sizeof(int)));
     }
-    HIPCHK(dmalloc(&S.G, B * gtot)); HIPCHK(dmalloc(&S.D, B * dtot)); HIPCHK(dmalloc(&S.up, B * P.plane[0]));
+    HIPCHK(dmalloc(&S.G, B * gtot)); HIPCHK(dmalloc(&S.D, B * dtot));     // (the up-sampled base image is never stored: S.up stays null)
     HIPCHK(dmalloc(&S.cand, B * cand_cap)); HIPCHK(dmalloc(&S.surv, B * surv_cap));
     HIPCHK(dmalloc(&S.kraw, B * raw_cap)); HIPCHK(dmalloc(&S.ksorted, B * raw_cap)); HIPCHK(dmalloc(&S.kfin, B * kp_cap));
     HIPCHK(dmalloc(&S.rank, B * 4097)); HIPCHK(dmalloc(&S.counts, B * 4)); HIPCHK(dmalloc(&S.fin_count, B)); HIPCHK(dmalloc(&S.fin_flags, B));
@@ -1851,8 +1851,8 @@ static int sift_detect_enqueue(vo_ctx* ctx, SiftState& S, const uint8_t* src, in
     HIPCHK(hipMemsetAsync(S.counts, 0, (size_t)F * 4 * sizeof(int), s));
     {
         StageTimer t(ctx, ST_SIFT_SCALE);
-        launch_sb_base(s, src, channels, row_stride, frame_stride, S.w, S.h, S.up, P.stride[0], P.plane[0], F);
-        if (launch_sb_sweep(s, S.up, P.plane[0], S.G + P.goff[0], P.gframe, nullptr, 0, P.w[0], P.h[0], P.stride[0], F, S.taps[0], S.ntaps[0]))
+        // G[0] of octave 0 = blur(2 x up-sampled input): the up-sampling happens in the sweep's loader
+        if (launch_sb_sweep_base(s, src, channels, row_stride, frame_stride, S.w, S.h, S.G + P.goff[0], P.gframe, P.stride[0], F, S.taps[0], S.ntaps[0]))
             FAIL(VO_ERR_UNSUPPORTED, "SIFT: unsupported blur size");
     }
     const float threshold = (float)(int)floor(0.5 * S.prm.contrast_threshold / L * 255);

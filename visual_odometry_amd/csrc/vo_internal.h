@@ -178,7 +178,8 @@ struct SiftKp { float x, y, size, angle, response; int octave; };
 struct SiftSurv { SiftKp kp; int o, layer, r, c; };      // a refined extremum awaiting its orientation(s)
 struct SiftExpTab { float tab[64]; };                   // 2^(i/64), the table of cv::hal::exp32f
 // per-frame counters of a sub-batch: counts[f][4] = {extrema candidates, refined extrema, oriented keypoints, final keypoints}
-void launch_sb_base(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int sw, int sh, float* dst, int dstride, size_t dframe, int F);
+int launch_sb_sweep_base(hipStream_t s, const uint8_t* img, int channels, int row_stride, int64_t frame_stride, int sw, int sh,
+                         float* dstG, size_t g_fs, int stride, int F, const float* taps, int ntaps);
 int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
                     const float* taps, int ntaps, float* dstH = nullptr, size_t h_fs = 0, int hstride = 0, int hw = 0, int hh = 0);
 void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o, float threshold, SiftCand* cand, int* counts, int cap, int F);
