@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--detector", choices=["orb", "sift"], default="orb")
-    ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs of a chunk (default 256 for ORB, 63 for SIFT: 64 frames = one launch chain)")
+    ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs of a chunk (default 256 for ORB, 191 for SIFT: 192 frames = one launch chain)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=2000)
@@ -248,7 +248,7 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     sift = args.detector == "sift"
-    C = args.pairs_per_step or (63 if sift else 256)
+    C = args.pairs_per_step or (191 if sift else 256)
     S = max(1, args.pair_stride)
     device = local_rank
     use_dist = world > 1 or args.force_dist

@@ -9,7 +9,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r03}
 DET=${2:-orb}
-if [ $DET = sift ]; then SUF=_sift; DARGS="--detector sift"; FR=64; else SUF=""; DARGS=""; FR=257; fi
+if [ $DET = sift ]; then SUF=_sift; DARGS="--detector sift"; FR=192; else SUF=""; DARGS=""; FR=257; fi
 O=$R/gpurun_out/prof_$TAG$SUF
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp

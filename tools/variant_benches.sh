@@ -21,4 +21,4 @@ run independent_pairs --workload independent
 run matcher_int8 --matcher-kernel mfma
 run matcher_popcount --matcher-kernel popcount
 run sift_1152x648 --detector sift --width 1152 --height 648
-run sift_independent --detector sift --workload independent --pairs-per-step 32
+run sift_independent --detector sift --workload independent --pairs-per-step 96

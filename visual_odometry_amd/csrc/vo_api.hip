@@ -1980,11 +1980,20 @@ extern "C" int vo_batch_configure_sift(vo_ctx* ctx, int h, int w, const vo_sift_
     if (kp_cap > 65536) FAIL(VO_ERR_INVALID, "kp_cap > 65536");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    // frames per launch chain: the small octaves' launches are latency-bound (a dependent chain of ~60 launches per sub-batch),
-    // so the more frames share them the better; 64 frames = 13.5 GB of scale-space scratch at 1280 x 720
+    // frames per launch chain: the small octaves' launches are latency-bound (a dependent chain of ~50 launches per sub-batch)
+    // and the wave-per-keypoint kernels like long grids, so the more frames share a chain the better (1280 x 720, pairs/s with
+    // 64 / 96 / 128 / 192 / 256 frames: 4.59 / 4.68 / 4.79 / 4.94 / 4.94 k): up to 192 frames, within 48 GB of scale-space scratch
+    // (211 MB per 1280 x 720 frame: the card has 288 GB)
     const char* ev = getenv("VO_SIFT_SUBBATCH");
-    int fb = ev ? atoi(ev) : 64;
-    if (fb < 1) fb = 1;
+    int fb = ev ? atoi(ev) : 0;
+    if (fb < 1) {
+        size_t px = 0;                                         // floats of one frame's Gaussian + DoG planes (the geometry of sift_setup)
+        for (int ww = 2 * w, hh = 2 * h; ww >= 1 && hh >= 1; ww /= 2, hh /= 2) px += (size_t)align_up(ww, 16) * hh;
+        const size_t per_frame = px * 2 * (size_t)(params->n_octave_layers + 2) * sizeof(float);
+        const size_t fit = ((size_t)48 << 30) / (per_frame ? per_frame : 1);
+        fb = (int)(fit < 192 ? fit : 192);
+        if (fb < 1) fb = 1;
+    }
     if (fb > max_frames) fb = max_frames;
     // the intermediate lists (sub-batch scratch) are generous whatever kp_cap is: only the final list is cut at kp_cap, in cv2's
     // list order, as long as they do not overflow themselves (flagged)
