@@ -19,14 +19,15 @@
 //                    LDS); a pixel is an extremum iff it equals the max (min) of the 3 x 3 x 3 block
 //   k_sb_refine      lane per candidate: adjustLocalExtrema (<= 5 steps, Matx33f::solve closed form), contrast and edge tests
 //   k_sb_orient      wavefront per refined extremum: calcOrientationHist (cv::exp32f's table algorithm, cv::fastAtan2); the 36
-//                    bins are owned by 36 lanes that add their samples in window order (bit masks by LDS atomic OR)
+//                    bins are owned by 36 lanes; the samples of a step are filed into per-bin queues in window order (LDS masks +
+//                    popcounts) and the owners add their queue front to back
 //   k_sb_bucket / k_sb_rank / k_sb_emit   KeyPointsFilter::removeDuplicatedSorted on the device: records are binned by the
 //                    top bits of their 64-bit (x, y) key (4096 buckets per frame), ranked inside their bucket under
 //                    KeyPoint_LessThan (full comparator on key ties), scattered, repeats dropped
-//   k_sb_descriptor  wavefront per keypoint: calcSIFTDescriptor.  The window is first compacted to the samples that fall
-//                    inside the rotated 4 x 4 grid; 64 of them are evaluated in parallel (gradient, fastAtan2, exp32f,
-//                    trilinear split); the 128 + 16 histogram bins that matter live in REGISTERS of their owner lanes
-//                    (lane = inner cell x orientation-bin pair), which add their samples in window order.
+//   k_sb_descriptor  wavefront per keypoint: calcSIFTDescriptor.  The valid positions of every window row form one interval
+//                    (found exactly by bisection); 64 valid samples are evaluated in parallel (gradient, fastAtan2, exp32f,
+//                    trilinear split -> 8 addends); the 144 histogram bins that matter are accumulators in REGISTERS of their
+//                    owner lanes; the addends reach them through per-accumulator queues in LDS, filled in sample order.
 #include "vo_internal.h"
 #include <float.h>
 #include <math.h>
