@@ -4,13 +4,15 @@
 //
 // Device pipeline for a batch of files (one launch each, one workgroup per image for the two entropy kernels):
 //   k_jpeg_unstuff   byte stuffing (FF 00) and RSTn markers removed from the entropy-coded segment; the restart
-//                    positions and the end of the data found in parallel (flags -> workgroup scans -> scatter);
+//                    positions and the end of the data found in parallel: sixteen wavefronts per file, each walking its
+//                    segment 256 bytes at a time (coalesced dwords, neighbour bytes by shuffles, ballot prefixes);
 //   k_jpeg_huffman   Huffman decoding IN PARALLEL inside one scan: the clean stream is cut into one subsequence per
 //                    thread; every thread decodes its subsequence from a guessed state, then the end states are
 //                    propagated (thread i restarts from thread i-1's end state) until nothing changes — Huffman codes
 //                    self-synchronise after a few symbols, so this takes two or three rounds; a scan of the per-thread
-//                    block counts gives every thread its first coefficient block, a last pass writes the coefficients
-//                    (de-zigzagged, DC as differences), and a segmented scan turns the DC differences into values;
+//                    block counts gives every thread its first coefficient block, a segmented scan of the per-thread DC
+//                    sums (kept in registers by every pass) its DC predictions, and a last pass writes the coefficients
+//                    (de-zigzagged, DC coefficients as values);
 //   k_jpeg_idct      lane per 8x8 block: dequantisation + jidctint.c's two-pass 13-bit integer IDCT;
 //   k_jpeg_color     lane per 4 output pixels: h2v1 / h2v2 triangle upsampling (jdsample.c), jdcolor.c's fixed-point
 //                    YCbCr -> RGB, stores B G R.
