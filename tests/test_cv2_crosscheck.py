@@ -188,4 +188,14 @@ def test_solve_pnp_ransac_and_rodrigues(oracle):
     ref = np.zeros(240, bool); ref[inl.ravel()] = True
     assert (ref == (mask > 0)).mean() > 0.98                    # threshold-edge points may flip with the hypothesis noise
     assert np.abs(rvec.ravel() - rv).max() < 1e-3 and np.abs(tvec.ravel() - tv).max() < 1e-2
+    if np.array_equal(ref, mask > 0):                            # the same consensus set: the final solvePnP(ITERATIVE) is restated step by
+        assert np.abs(rvec.ravel() - rv).max() < 1e-6 and np.abs(tvec.ravel() - tv).max() < 1e-6     # step (DLT start, CvLevMarq): only LAPACK's SVDs differ
     assert np.abs(cv2.Rodrigues(rv)[0] - oracle.rodrigues(rv)).max() < 1e-12
+    # a planar map takes cvFindExtrinsicCameraParams2's homography start
+    Xp = X.copy(); Xp[:, 2] = 0.2 * Xp[:, 0] - 0.1 * Xp[:, 1] + 0.5
+    Xc = Xp @ cv2.Rodrigues(r_true)[0].T + t_true
+    uvp = ((Xc / Xc[:, 2:]) @ K.T)[:, :2] + rng.normal(0, 0.3, (240, 2))
+    ok, rvec, tvec, inl = cv2.solvePnPRansac(Xp, uvp, K, np.zeros(4))
+    rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(Xp, uvp, K)
+    assert ok and rc == 0
+    assert np.abs(rvec.ravel() - rv).max() < 1e-3 and np.abs(tvec.ravel() - tv).max() < 1e-2
