@@ -134,6 +134,30 @@ def test_ingest_jpeg_equals_decode_resize_gray(oracle, ctx):
     assert np.array_equal(fe.ingest_jpeg(empty, want_resized=True), resized)
 
 
+@pytest.mark.parametrize("h,w,ss", [(324, 576, 2), (201, 333, 2), (203, 330, 1), (161, 235, 0)])
+def test_ingest_jpeg_of_the_configured_size_writes_gray_directly(oracle, ctx, h, w, ss):
+    """Files of the front end's own size and no colour frames wanted: the decoder's colour conversion writes level 0 itself
+    (k_jpeg_color<GRAY>, no B G R frames, no k_gray) — the features must be those of imread -> BGR2GRAY -> ORB, and the
+    same as through the B G R path (want_resized=True).  Also a single-component (grayscale) file."""
+    from visual_odometry_amd.frontend import FrontEnd
+    bufs = [encode(scene(900 + k, h, w, "boxes"), quality=90, subsampling=ss) for k in range(2)]
+    g = io.BytesIO(); Image.fromarray(scene(7, h, w, "boxes")[:, :, 1].copy()).save(g, "JPEG", quality=85)
+    fe = FrontEnd(h, w, max_frames=2, max_pairs=1, nfeatures=300, ctx=ctx)
+    p = oracle.orb_params(nfeatures=300)
+    for files in (bufs, [g.getvalue(), bufs[1]]):
+        assert fe.ingest_jpeg(files) is None
+        fe.detect(0, 2)
+        direct = [fe.features(k) for k in range(2)]
+        fe.ingest_jpeg(files, want_resized=True)
+        fe.detect(0, 2)
+        for k in range(2):
+            o = oracle.orb_detect_and_compute(oracle.jpeg_decode(files[k]), p)
+            via = fe.features(k)
+            assert len(o["xy"]) > 20
+            for key in ("desc", "xy"):
+                assert np.array_equal(direct[k][key], o[key]) and np.array_equal(via[key], o[key]), (k, key)
+
+
 def test_corrupt_entropy_data_is_survived(oracle, ctx):
     """Random damage inside the entropy-coded segment (flipped bytes, spliced markers, random tails): whatever comes out,
     every access of the kernels stays inside its buffers and the call returns an image of the right shape; damage that

@@ -180,6 +180,17 @@ __global__ __launch_bounds__(JPG_UNS_NT) void k_jpeg_unstuff(const uint8_t* blob
 #define JPG_MIN_SUB 32                    // bytes of a subsequence at least
 #endif
 struct JState { uint32_t bit; uint32_t bk; };              // position in the clean stream, (block in MCU << 8) | coefficient index
+#ifndef JPG_NCK
+#define JPG_NCK 2                         // checkpoints inside a subsequence (0: none — every propagation round decodes whole subsequences)
+#endif
+#ifndef JPG_CK0_SHIFT
+#define JPG_CK0_SHIFT 3                   // first checkpoint after 1 / 8 of the subsequence,
+#endif
+#ifndef JPG_CK1_SHIFT
+#define JPG_CK1_SHIFT 1                   // second after 1 / 2
+#endif
+#define JPG_NSEG (JPG_NCK + 1)
+struct JSeg { uint32_t bit, bk; int cnt; int d[4]; };      // state behind a segment; blocks completed and DC sums (+ "crossed a restart") inside it
 
 struct JReader {
     const uint8_t* p; uint32_t limit;                     // stream, number of readable bytes (data + padding)
@@ -297,7 +308,11 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
         k += adv;
         const int cmp = (int)((comps >> (2 * b)) & 3u), dv = dc ? v : 0;
         d0 += cmp == 0 ? dv : 0; d1 += cmp == 1 ? dv : 0; d2 += cmp == 2 ? dv : 0;
+#ifdef JPG_EXP_NOSTORE
+        if (WRITE && coefficient && k <= 64 && blk + done < total && v == 0x12345)
+#else
         if (WRITE && coefficient && k <= 64 && blk + done < total)
+#endif
             coef[(size_t)(blk + done) * 64 + T.zigzag[k - 1]] = (int16_t)(dc ? (cmp == 0 ? d0 : cmp == 1 ? d1 : d2) : v);
         const bool end = k >= 64;
         k = end ? 0 : k;
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
 {
     __shared__ JLocal T;
     __shared__ JState s_st[JPG_NT];
-    __shared__ int s_cnt[JPG_NT];
+    __shared__ JSeg s_seg[JPG_NSEG][JPG_NT];               // per segment of the thread's subsequence: state behind it, blocks and DC sums inside it
     __shared__ int s_tmp[JPG_NT / 64];
     __shared__ int s_dc[JPG_NT][4];                        // per-thread DC sums of three components + "saw a restart"
     const JpegImage& im = imgs[blockIdx.x];
@@ -359,12 +374,27 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     const uint32_t b0 = min(nbits, sub * 8u * (uint32_t)tid), b1 = min(nbits, b0 + sub * 8u);
     const bool live = b0 < nbits;                          // threads past the end of the data hold empty subsequences
     __syncthreads();
+    // A subsequence is decoded in JPG_NSEG segments; the state at the first symbol boundary behind each segment's end is a
+    // CHECKPOINT.  A later decode of the subsequence from another start state that arrives at a checkpoint in the very state
+    // recorded there has synchronised: everything behind it (counts, DC sums, end state) stands as recorded, so the decode
+    // stops — Huffman streams synchronise within a few dozen symbols, so a propagation round costs the first segment, not a
+    // whole pass.  (The writing pass runs through the same segments, so every pass follows the same path by construction.)
+    const uint32_t sub_bits = sub * 8u;
+    auto seg_end = [&](int j) -> uint32_t {
+        return j == 0 && JPG_NCK >= 1 ? min(b1, b0 + (sub_bits >> JPG_CK0_SHIFT)) : j == 1 && JPG_NCK >= 2 ? min(b1, b0 + (sub_bits >> JPG_CK1_SHIFT)) : b1;
+    };
     // 1. cold start: assume a block starts at the subsequence boundary (true for thread 0)
     JState mine; mine.bit = b0; mine.bk = 0;
-    int cnt = 0;
-    int dcs[4] = {0, 0, 0, 0};                              // this thread's DC sums (of its latest decoding pass) + "crossed a restart"
-    if (live) cnt = jpg_span<false>(T, clean, rst, mine, b1, nullptr, 0, dcs);
-    s_st[tid] = mine; s_cnt[tid] = cnt;
+    if (live) {
+#pragma unroll 1
+        for (int j = 0; j < JPG_NSEG; j++) {
+            int dz[4] = {0, 0, 0, 0};
+            const int c = jpg_span<false>(T, clean, rst, mine, seg_end(j), nullptr, 0, dz);
+            JSeg g; g.bit = mine.bit; g.bk = mine.bk; g.cnt = c; g.d[0] = dz[0]; g.d[1] = dz[1]; g.d[2] = dz[2]; g.d[3] = dz[3];
+            s_seg[j][tid] = g;
+        }
+    }
+    s_st[tid] = mine;
     __syncthreads();
     // 2. propagate end states until they are stable: thread i restarts from thread i-1's end state
     JState used; used.bit = 0xffffffffu; used.bk = 0xffffffffu;      // the start state the current result was computed from
@@ -380,19 +410,38 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         bool changed = false;
         if (redo) {
             JState st = prev;
-            dcs[0] = dcs[1] = dcs[2] = dcs[3] = 0;
-            const int c = jpg_span<false>(T, clean, rst, st, b1, nullptr, 0, dcs);
-            changed = st.bit != s_st[tid].bit || st.bk != s_st[tid].bk;
-            s_st[tid] = st; s_cnt[tid] = c; used = prev;
+            bool same = false;
+#pragma unroll 1
+            for (int j = 0; j < JPG_NSEG && !same; j++) {
+                int dz[4] = {0, 0, 0, 0};
+                const int c = jpg_span<false>(T, clean, rst, st, seg_end(j), nullptr, 0, dz);
+                same = st.bit == s_seg[j][tid].bit && st.bk == s_seg[j][tid].bk;
+                JSeg g; g.bit = st.bit; g.bk = st.bk; g.cnt = c; g.d[0] = dz[0]; g.d[1] = dz[1]; g.d[2] = dz[2]; g.d[3] = dz[3];
+                s_seg[j][tid] = g;
+            }
+            changed = !same;
+            if (changed) s_st[tid] = st;
+            used = prev;
         }
         if (!__syncthreads_or(changed ? 1 : 0)) { if (tid == 0) imgs[blockIdx.x].sync_rounds = (uint32_t)round + 1; break; }
     }
     __syncthreads();
     // 3. first coefficient block of every subsequence, and the DC predictions it starts with: a segmented scan of the threads' DC
     //    sums (operator (a, b) -> b.reset ? b : a + b: the predictions restart with every restart interval)
+    int cnt = 0;
+    int dcs[4] = {0, 0, 0, 0};                              // this thread's DC sums since its last restart + "crossed a restart"
+    if (live) {
+#pragma unroll 1
+        for (int j = 0; j < JPG_NSEG; j++) {
+            const JSeg g = s_seg[j][tid];
+            cnt += g.cnt;
+            if (g.d[3]) { dcs[0] = g.d[0]; dcs[1] = g.d[1]; dcs[2] = g.d[2]; dcs[3] = 1; }
+            else { dcs[0] += g.d[0]; dcs[1] += g.d[1]; dcs[2] += g.d[2]; }
+        }
+    }
     int total_cnt;
-    const int first = wg_scan_excl(live ? s_cnt[tid] : 0, s_tmp, tid, &total_cnt);
-    s_dc[tid][0] = live ? dcs[0] : 0; s_dc[tid][1] = live ? dcs[1] : 0; s_dc[tid][2] = live ? dcs[2] : 0; s_dc[tid][3] = live ? dcs[3] : 0;
+    const int first = wg_scan_excl(cnt, s_tmp, tid, &total_cnt);
+    s_dc[tid][0] = dcs[0]; s_dc[tid][1] = dcs[1]; s_dc[tid][2] = dcs[2]; s_dc[tid][3] = dcs[3];
     __syncthreads();
     for (int d = 1; d < JPG_NT; d <<= 1) {
         int a0 = 0, a1 = 0, a2 = 0, ar = 0;
@@ -405,11 +454,15 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     dcs[0] = dcs[1] = dcs[2] = dcs[3] = 0;
     if (tid > 0) { dcs[0] = s_dc[tid - 1][0]; dcs[1] = s_dc[tid - 1][1]; dcs[2] = s_dc[tid - 1][2]; }
     // 4. decode once more, writing (DC coefficients as values: prediction + difference)
+#ifndef JPG_EXP_NOWRITEPASS
     if (live) {
         JState st; st.bit = 0; st.bk = 0;
         if (tid > 0) st = s_st[tid - 1];
-        jpg_span<true>(T, clean, rst, st, b1, coef, (uint32_t)first, dcs);
+        int done = 0;
+#pragma unroll 1
+        for (int j = 0; j < JPG_NSEG; j++) done += jpg_span<true>(T, clean, rst, st, seg_end(j), coef, (uint32_t)(first + done), dcs);
     }
+#endif
     // 4b. a file whose data ends early (truncated, or cut by a stray marker): libjpeg decodes the MCU in which the data
     //     ran out from zero bits and leaves every later MCU all-zero (jdhuff.c: insufficient_data) — the last
     //     subsequence's owner finishes that MCU from the zero padding (its predictions stand where its data ended), the MCUs
@@ -518,6 +571,9 @@ __device__ __forceinline__ uint32_t ld4(const uint8_t* row, int i0, int dw)
     return w << sh;
 }
 
+// GRAY: the B G R values go straight through cvtColor's BGR2GRAY (color_rgb RGB2Gray<uchar>, 15-bit) into level 0 of the
+// frame slots (out_off / out_stride then describe that plane) — the frame-ingest path when nobody asks for the colour frames.
+template <bool GRAY>
 __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const uint8_t* planes, uint8_t* out_all)
 {
     const JpegImage& im = imgs[blockIdx.y];
@@ -529,7 +585,7 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const
     if (y >= H || x4 >= W) return;
     const int mode = im.mode, nc = im.nc, ycc = im.ycc;
     const uint8_t* yrow = planes + im.plane_off[0] + (size_t)y * (im.bw[0] * 8);
-    uint8_t* o = out_all + im.out_off + (size_t)y * im.out_stride + (size_t)x4 * 3;
+    uint8_t* o = out_all + im.out_off + (size_t)y * im.out_stride + (size_t)x4 * (GRAY ? 1 : 3);
     const uint32_t yw = *(const uint32_t*)(yrow + x4);       // plane rows are multiples of 8 bytes, planes 256-byte aligned
     int Cb[4], Cr[4];
     if (nc == 3) {
@@ -587,6 +643,13 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const
         const int B = Y + ((__mul24(116130, xb) + 32768) >> 16);
         px[3 * k] = (uint8_t)min(max(B, 0), 255); px[3 * k + 1] = (uint8_t)min(max(G, 0), 255); px[3 * k + 2] = (uint8_t)min(max(R, 0), 255);
     }
+    if (GRAY) {                                               // (rows of the level are padded to 64 bytes: the whole dword is inside)
+        uint32_t g = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) g |= (uint32_t)((px[3 * k] * 3735 + px[3 * k + 1] * 19235 + px[3 * k + 2] * 9798 + (1 << 14)) >> 15) << (8 * k);
+        *(uint32_t*)o = g;
+        return;
+    }
     const int nx = min(4, W - x4);
     if (nx == 4 && (((size_t)(o - out_all)) & 3) == 0) {       // one 12-byte store per lane: 768 contiguous bytes per wavefront
         *(uint3*)o = make_uint3(px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24),
@@ -599,10 +662,12 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const
 
 // ------------------------------------------------------------------ launchers
 void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
-                        int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h)
+                        int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h, bool gray)
 {
     hipLaunchKernelGGL(k_jpeg_unstuff, dim3(F), dim3(JPG_UNS_NT), 0, s, blob, imgs, clean, rst);
     hipLaunchKernelGGL(k_jpeg_huffman, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, F), dim3(256), 0, s, imgs, tabs, coef, planes);
-    hipLaunchKernelGGL(k_jpeg_color, dim3((unsigned)(((size_t)((max_w + 255) / 256) * max_h + 3) / 4), F), dim3(256), 0, s, imgs, planes, out);
+    const dim3 cgrid((unsigned)(((size_t)((max_w + 255) / 256) * max_h + 3) / 4), F);
+    if (gray) hipLaunchKernelGGL(k_jpeg_color<true>, cgrid, dim3(256), 0, s, imgs, planes, out);
+    else hipLaunchKernelGGL(k_jpeg_color<false>, cgrid, dim3(256), 0, s, imgs, planes, out);
 }

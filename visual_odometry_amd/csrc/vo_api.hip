@@ -2085,7 +2085,10 @@ extern "C" int vo_jpeg_info(const uint8_t* data, size_t nbytes, int32_t* h, int3
 
 // Decodes files [f0, f0 + n) of the blob into ctx->jpg_out (device, B G R, image k at k * out_frame bytes, rows of
 // out_w * 3 bytes).  Every file must be exactly out_h x out_w.  Leaves the work queued on the context's stream.
-static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int f0, int n, int out_h, int out_w)
+// With `gray` (device; image k's plane at gray + k * gray_frame, rows of gray_stride >= align_up(out_w, 4) bytes) the colour
+// conversion writes cvtColor(BGR2GRAY) of the decoded pixels there instead and ctx->jpg_out is not touched.
+static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int f0, int n, int out_h, int out_w,
+                              uint8_t* gray = nullptr, size_t gray_frame = 0, int gray_stride = 0)
 {
     std::vector<JpegImage> imgs((size_t)n);
     std::vector<JpegTables> tabs;                          // one per DISTINCT header (the frames of one camera share theirs)
@@ -2111,7 +2114,8 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
         im.rst_off = (uint32_t)rst; im.rst_cap = im.ri ? (uint32_t)((im.mx * im.my + im.ri - 1) / im.ri + 2) : 0; rst += im.rst_cap;
         im.coef_blk = (uint32_t)blocks; blocks += (size_t)im.total_blocks;
         for (int c = 0; c < im.nc; c++) { im.plane_off[c] = planes; planes += ((size_t)im.bw[c] * 8 * im.bh[c] * 8 + 255) & ~(size_t)255; }
-        im.out_off = (uint64_t)k * out_h * out_w * 3; im.out_stride = (uint32_t)out_w * 3;
+        if (gray) { im.out_off = (uint64_t)k * gray_frame; im.out_stride = (uint32_t)gray_stride; }
+        else { im.out_off = (uint64_t)k * out_h * out_w * 3; im.out_stride = (uint32_t)out_w * 3; }
         if (im.total_blocks > max_blocks) max_blocks = im.total_blocks;
         if (clean > 0xf0000000ull || blocks > 0xf0000000ull) FAIL(VO_ERR_UNSUPPORTED, "JPEG batch too large for one launch");
     }
@@ -2122,7 +2126,7 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     if ((rc = ensure_bytes(ctx, &ctx->jpg_rst, &ctx->jpg_rst_n, (rst + 4) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure_bytes(ctx, &ctx->jpg_coef, &ctx->jpg_coef_n, blocks * 128 + 16))) return rc;
     if ((rc = ensure_bytes(ctx, &ctx->jpg_planes, &ctx->jpg_planes_n, planes + 256))) return rc;
-    if ((rc = ensure_bytes(ctx, &ctx->jpg_out, &ctx->jpg_out_n, (size_t)n * out_h * out_w * 3 + 16))) return rc;
+    if (!gray && (rc = ensure_bytes(ctx, &ctx->jpg_out, &ctx->jpg_out_n, (size_t)n * out_h * out_w * 3 + 16))) return rc;
     if ((rc = ensure_bytes(ctx, &ctx->jpg_img, &ctx->jpg_img_n, (size_t)n * sizeof(JpegImage)))) return rc;
     if ((rc = ensure_bytes(ctx, &ctx->jpg_tab, &ctx->jpg_tab_n, tabs.size() * sizeof(JpegTables)))) return rc;
     hipStream_t s = ctx->stream;
@@ -2133,7 +2137,7 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     {
         StageTimer t(ctx, ST_MISC);
         launch_jpeg_decode(s, ctx->jpg_blob, (JpegImage*)ctx->jpg_img, (const JpegTables*)ctx->jpg_tab, n, ctx->jpg_clean, (uint32_t*)ctx->jpg_rst,
-                           (int16_t*)ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out, max_blocks, out_w, out_h);
+                           (int16_t*)ctx->jpg_coef, ctx->jpg_planes, gray ? gray : ctx->jpg_out, max_blocks, out_w, out_h, gray != nullptr);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));                  // the host vectors must outlive their copies
@@ -2206,6 +2210,15 @@ extern "C" int vo_frames_ingest_jpeg(vo_ctx* ctx, const uint8_t* blob, const int
     const size_t dper = (size_t)ctx->w * ctx->h * 3;
     for (int f0 = 0; f0 < F; f0 += chunk) {
         const int n = F - f0 < chunk ? F - f0 : chunk;
+        if (sw == ctx->w && sh == ctx->h && !resized_out) {
+            // files of the configured size and nobody wants the colour frames: cv::resize is a copy, so the decoder's colour
+            // conversion writes the gray level 0 of the slots itself (no B G R frames in memory, no k_gray pass)
+            const LevelGeom& lv = ctx->g.lv[0];
+            const int rc = jpeg_decode_device(ctx, blob, offsets, f0, n, sh, sw, ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes + lv.off,
+                                              ctx->g.frame_bytes, lv.stride);
+            if (rc) return rc;
+            continue;
+        }
         int rc = jpeg_decode_device(ctx, blob, offsets, f0, n, sh, sw);
         if (rc) return rc;
         rc = ingest_from_device(ctx, ctx->jpg_out, n, sh, sw, 3, sw * 3, (int64_t)sh * sw * 3, first_slot + f0,
