@@ -158,6 +158,27 @@ def test_ingest_jpeg_of_the_configured_size_writes_gray_directly(oracle, ctx, h,
                 assert np.array_equal(direct[k][key], o[key]) and np.array_equal(via[key], o[key]), (k, key)
 
 
+def test_eight_slot_table_kernel_equals_the_packed_one(oracle, ctx, tmp_path):
+    """k_jpeg_huffman<4> keeps only the (at most four) Huffman tables a scan names in LDS; a file that names more takes
+    k_jpeg_huffman<8>.  Pillow never writes such a file, so the eight-slot kernel is forced for a whole process
+    (VO_JPEG_FULL_TABLES) and must give the packed kernel's — the oracle's — pixels."""
+    import os, subprocess, sys
+    from visual_odometry_amd import ingest
+    bufs = [encode(scene(40 + k, 123, 187, kind), quality=q, subsampling=ss, **kw)
+            for k, (kind, q, ss, kw) in enumerate([("boxes", 90, 2, {}), ("noise", 35, 0, {}), ("boxes", 75, 1, dict(optimize=True)),
+                                                    ("saturated", 60, 2, dict(restart_marker_blocks=1))])]
+    np.savez(tmp_path / "in.npz", **{f"f{k}": np.frombuffer(b, np.uint8) for k, b in enumerate(bufs)})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from visual_odometry_amd import ingest; d = np.load(sys.argv[1]); "
+            "np.savez(sys.argv[2], **{k: ingest.imdecode(d[k].tobytes()) for k in d.files})" % root)
+    subprocess.run([sys.executable, "-c", code, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")], check=True, timeout=300,
+                   env=dict(os.environ, VO_JPEG_FULL_TABLES="1"))
+    out = np.load(tmp_path / "out.npz")
+    for k, b in enumerate(bufs):
+        assert np.array_equal(out[f"f{k}"], oracle.jpeg_decode(b)), k
+        assert np.array_equal(out[f"f{k}"], ingest.imdecode(b, ctx)), k
+
+
 def test_corrupt_entropy_data_is_survived(oracle, ctx):
     """Random damage inside the entropy-coded segment (flipped bytes, spliced markers, random tails): whatever comes out,
     every access of the kernels stays inside its buffers and the call returns an image of the right shape; damage that

@@ -192,46 +192,86 @@ struct JState { uint32_t bit; uint32_t bk; };              // position in the cl
 #define JPG_NSEG (JPG_NCK + 1)
 struct JSeg { uint32_t bit, bk; int cnt; int d[4]; };      // state behind a segment; blocks completed and DC sums (+ "crossed a restart") inside it
 
+// The bit reader.  Its input reaches the lane through a small ring in LDS (JPG_RING dwords per lane): every second symbol —
+// at the same instruction for the whole wavefront — a lane whose ring has room fetches its next 16 bytes, and stores them
+// into the ring two symbols later, so the load has two symbols' time to arrive and nothing waits for it (a load placed in the
+// refill itself is waited for at once: the lanes refill at different symbols, so some lane needs "the latest load" at every
+// symbol).  The refill takes one dword from the ring, read one refill early.
+#define JPG_RING 8
 struct JReader {
     const uint8_t* p; uint32_t limit;                     // stream, number of readable bytes (data + padding)
-    uint64_t buf; int nb; uint32_t bytepos;
-    uint32_t ahead;                                       // the word at bytepos, loaded one refill early (its latency hides behind ~5 symbols)
-    __device__ __forceinline__ uint32_t word(uint32_t at) const
+    uint32_t* ring;                                       // this lane's ring: dword k of the stream at ring[(k & 7) * JPG_NT]
+    uint64_t buf; int nb;
+    uint32_t nx, wr;                                      // stream dwords: next to leave the ring / next to be fetched (ring holds [nx, wr))
+    uint32_t ahead;                                       // dword nx - 1, raw byte order: goes into buf at the next refill
+    uint4 pend; bool has_pend;                            // fetched, not yet in the ring
+    __device__ __forceinline__ uint4 fetch(uint32_t dw) const
     {
-        return at + 4 <= limit ? __builtin_bswap32(*(const u32_unaligned*)(p + at)) : 0u;
+        const uint32_t at = dw * 4u;
+        if (at + 16 <= limit) return *(const uint4*)(p + at);
+        uint4 q;                                          // the last dwords of the stream: nothing is read behind `limit` (zero bits follow)
+        q.x = at + 4 <= limit ? *(const uint32_t*)(p + at) : 0u; q.y = at + 8 <= limit ? *(const uint32_t*)(p + at + 4) : 0u;
+        q.z = at + 12 <= limit ? *(const uint32_t*)(p + at + 8) : 0u; q.w = 0u;
+        return q;
+    }
+    __device__ __forceinline__ void put(uint32_t dw, const uint4& q)
+    {
+        ring[((dw) & 7u) * JPG_NT] = q.x; ring[((dw + 1) & 7u) * JPG_NT] = q.y; ring[((dw + 2) & 7u) * JPG_NT] = q.z; ring[((dw + 3) & 7u) * JPG_NT] = q.w;
     }
     __device__ __forceinline__ void seek(uint32_t bit)
     {
-        bytepos = bit >> 3; buf = 0; nb = 0;
-        ahead = word(bytepos);
-        refill();
-        const int skip = (int)(bit & 7u);
+        const uint32_t dw = bit >> 5;
+        const uint4 q0 = fetch(dw), q1 = fetch(dw + 4);
+        put(dw, q0); put(dw + 4, q1);
+        wr = dw + 8; has_pend = false;
+        buf = (uint64_t)__builtin_bswap32(q0.x) << 32; nb = 32;
+        ahead = q0.y; nx = dw + 2;
+        const int skip = (int)(bit & 31u);
         buf <<= skip; nb -= skip;
+    }
+    // every second symbol: what was fetched two symbols ago goes into the ring; a ring with room for 16 more bytes fetches them
+    // (at most one dword leaves per symbol, so with >= 2 dwords after every service the ring never runs dry)
+    __device__ __forceinline__ void service()
+    {
+        if (has_pend) { put(wr, pend); wr += 4; has_pend = false; }
+        if (wr - nx <= JPG_RING - 4) { pend = fetch(wr); has_pend = true; }
     }
     __device__ __forceinline__ void refill()
     {
         if (nb <= 32) {
-            buf |= (uint64_t)ahead << (32 - nb);
-            nb += 32; bytepos += 4;
-            ahead = word(bytepos);
+            buf |= (uint64_t)__builtin_bswap32(ahead) << (32 - nb);
+            nb += 32;
+            ahead = ring[(nx & 7u) * JPG_NT]; nx++;
         }
     }
-    __device__ __forceinline__ uint32_t pos() const { return bytepos * 8u - (uint32_t)nb; }
+    __device__ __forceinline__ uint32_t pos() const { return (nx - 1u) * 32u - (uint32_t)nb; }
     __device__ __forceinline__ void skip(int n) { buf <<= n; nb -= n; }
+    // forward by a few bits (restart padding) without a new fetch; anything else is a fresh start
+    __device__ __forceinline__ void seek_from(uint32_t cur, uint32_t bit)
+    {
+        if (bit >= cur && bit - cur < (uint32_t)nb) skip((int)(bit - cur)); else seek(bit);
+    }
 };
 
-struct JLocal {                                           // LDS copies of what the decoding loop reads per symbol
-    uint16_t lut[8][1 << JPG_LOOK];
-    uint16_t sub[8][JPG_LONG][64];
-    int32_t maxcode[8][18];
-    int32_t valoff[8][18];
-    uint8_t vals[8][256];
+// NTAB = 8: the file's tables at their T.81 slots (DC 0-3, AC 4-7); NTAB = 4: only the (at most four) tables its scan names,
+// packed — 12 KB instead of 24 KB of LDS, which lets two files share a CU.
+template <int NTAB>
+struct JLocalT {                                          // LDS copies of what the decoding loop reads per symbol
+    uint16_t lut[NTAB][1 << JPG_LOOK];
+    uint16_t sub[NTAB][JPG_LONG][64];
+    int32_t maxcode[NTAB][18];
+    int32_t valoff[NTAB][18];
+    uint8_t vals[NTAB][256];
     uint8_t zigzag[64];
-    uint8_t dc_slot[JPG_MAX_BPM], ac_slot[JPG_MAX_BPM];
-    unsigned long long slots;                            // 4 bits per block of the MCU: DC table | (AC table - 4) << 2
+    uint8_t gslot[8];                                    // NTAB = 4: the T.81 slot behind each packed table
+    unsigned long long slots;                            // 4 bits per block of the MCU: DC table | AC table << 2 (NTAB = 8: AC table - 4)
     uint32_t comps;                                      // 2 bits per block of the MCU: its component
     int32_t bpm, ri, nrst, total_blocks;
     uint32_t clean_len;
+    __device__ __forceinline__ int slot(bool dc, uint32_t sl) const
+    {
+        return NTAB == 8 ? (dc ? (int)(sl & 3u) : 4 + (int)((sl >> 2) & 3u)) : (dc ? (int)(sl & 3u) : (int)((sl >> 2) & 3u));
+    }
 };
 
 // Decodes symbols from state st until the bit position reaches `boundary` (or max_done blocks are complete).  Returns
@@ -244,11 +284,11 @@ struct JLocal {                                           // LDS copies of what 
 // DC values: dcs = the three components' running DC sums + "crossed a restart".  A counting pass starts them at zero and leaves
 // the thread's sums (since its last restart) for the scan over the threads; the writing pass starts them at the predictions that
 // scan gave the thread and stores every DC coefficient as the VALUE (prediction + difference) — no pass over the stored blocks.
-template <bool WRITE, bool HAS_RST>
-__device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
-                                          JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done, int (&dcs)[4])
+template <bool WRITE, bool HAS_RST, typename JL>
+__device__ __forceinline__ int jpg_span_t(const JL& T, const uint8_t* clean, const uint32_t* rst,
+                                          JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int max_done, int (&dcs)[4], uint32_t* ring)
 {
-    JReader r; r.p = clean; r.limit = T.clean_len + JPG_PAD;
+    JReader r; r.p = clean; r.limit = T.clean_len + JPG_PAD; r.ring = ring;
     if (st.bit >= boundary) return 0;
     r.seek(st.bit);
     int b = (int)(st.bk >> 8), k = (int)(st.bk & 255u), done = 0;
@@ -268,7 +308,9 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
     const uint32_t comps = T.comps;
     int d0 = dcs[0], d1 = dcs[1], d2 = dcs[2], dreset = dcs[3];
     uint32_t pos = st.bit;
+    int sym_i = 0;
     while (pos < boundary && done < max_done) {
+        if ((sym_i++ & 1) == 0) r.service();
         r.refill();
         const bool dc = k == 0;
         if (HAS_RST && dc && b == 0 && pos + 8 > ri_next) {
@@ -276,14 +318,13 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
             // no Huffman code is all ones, so a real MCU cannot start like that)
             const int rem = (int)(ri_next - pos);
             if (rem == 0 || (r.buf >> (64 - rem)) == ((1ull << rem) - 1ull)) {
-                r.seek(ri_next); pos = ri_next;
+                r.seek_from(pos, ri_next); pos = ri_next;
                 rj++; ri_next = rj < nrst ? rst[rj] * 8u : 0xffffffffu;
                 d0 = d1 = d2 = 0; dreset = 1;             // the predictions restart with the interval
                 continue;
             }
         }
-        const uint32_t sl = (uint32_t)(slots >> (4 * b));
-        const int slot = dc ? (int)(sl & 3u) : 4 + (int)((sl >> 2) & 3u);
+        const int slot = T.slot(dc, (uint32_t)(slots >> (4 * b)));
         const uint32_t e = T.lut[slot][(uint32_t)(r.buf >> (64 - JPG_LOOK))];
         int l = (int)(e >> 8), sym = (int)(e & 255u);
         if ((e & 0x8000u) || e == 0u) {                   // a code of 11 .. 16 bits: second-level table, or the canonical walk
@@ -330,41 +371,68 @@ __device__ __forceinline__ int jpg_span_t(const JLocal& T, const uint8_t* clean,
     return done;
 }
 
-template <bool WRITE>
-__device__ __forceinline__ int jpg_span(const JLocal& T, const uint8_t* clean, const uint32_t* rst,
-                                        JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int (&dcs)[4], int max_done = 0x7fffffff)
+template <bool WRITE, typename JL>
+__device__ __forceinline__ int jpg_span(const JL& T, const uint8_t* clean, const uint32_t* rst,
+                                        JState& st, uint32_t boundary, int16_t* coef, uint32_t blk, int (&dcs)[4], uint32_t* ring, int max_done = 0x7fffffff)
 {
-    if (T.ri && T.nrst) return jpg_span_t<WRITE, true>(T, clean, rst, st, boundary, coef, blk, max_done, dcs);
-    return jpg_span_t<WRITE, false>(T, clean, rst, st, boundary, coef, blk, max_done, dcs);
+    if (T.ri && T.nrst) return jpg_span_t<WRITE, true>(T, clean, rst, st, boundary, coef, blk, max_done, dcs, ring);
+    return jpg_span_t<WRITE, false>(T, clean, rst, st, boundary, coef, blk, max_done, dcs, ring);
 }
 
+template <int NTAB>
 __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const JpegTables* tabs, const uint8_t* clean_all,
                                                          const uint32_t* rst_all, int16_t* coef_all)
 {
-    __shared__ JLocal T;
+    // what the counting passes keep per thread (per segment of its subsequence: state behind it, blocks and DC sums inside it),
+    // and — once the totals are in registers — the scan of the DC sums in the same bytes
+    union Scratch { JSeg seg[JPG_NSEG][JPG_NT]; int dc[JPG_NT][4]; };
+    __shared__ JLocalT<NTAB> T;
     __shared__ JState s_st[JPG_NT];
-    __shared__ JSeg s_seg[JPG_NSEG][JPG_NT];               // per segment of the thread's subsequence: state behind it, blocks and DC sums inside it
+    __shared__ Scratch u;
     __shared__ int s_tmp[JPG_NT / 64];
-    __shared__ int s_dc[JPG_NT][4];                        // per-thread DC sums of three components + "saw a restart"
+    __shared__ uint32_t s_ring[JPG_RING][JPG_NT];          // the bit readers' input rings
+    JSeg (*const s_seg)[JPG_NT] = u.seg;
+    int (*const s_dc)[4] = u.dc;                           // per-thread DC sums of three components + "saw a restart"
     const JpegImage& im = imgs[blockIdx.x];
     const JpegTables& G = tabs[im.tab_idx];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 8 * (1 << JPG_LOOK) / 2; i += JPG_NT) ((uint32_t*)&T.lut[0][0])[i] = ((const uint32_t*)&G.lut[0][0])[i];
-    for (int i = tid; i < 8 * JPG_LONG * 64 / 2; i += JPG_NT) ((uint32_t*)&T.sub[0][0][0])[i] = ((const uint32_t*)&G.sub[0][0][0])[i];
-    for (int i = tid; i < 8 * 18; i += JPG_NT) { (&T.maxcode[0][0])[i] = (&G.maxcode[0][0])[i]; (&T.valoff[0][0])[i] = (&G.valoff[0][0])[i]; }
-    for (int i = tid; i < 8 * 256; i += JPG_NT) (&T.vals[0][0])[i] = (&G.vals[0][0])[i];
-    if (tid < 64) T.zigzag[tid] = d_zigzag[tid];
-    if (tid < JPG_MAX_BPM) { const int c = im.blk_comp[tid]; T.dc_slot[tid] = (uint8_t)im.td[c]; T.ac_slot[tid] = (uint8_t)(4 + im.ta[c]); }
+    uint32_t* const ring = &s_ring[0][tid];
     if (tid == 0) {
-        unsigned long long sl = 0;
-        for (int j = 0; j < JPG_MAX_BPM; j++) { const int c = im.blk_comp[j < im.bpm ? j : 0]; sl |= (unsigned long long)((im.td[c] & 3) | ((im.ta[c] & 3) << 2)) << (4 * j); }
-        T.slots = sl;
-        uint32_t cp = 0;
-        for (int j = 0; j < JPG_MAX_BPM && j < 16; j++) cp |= (uint32_t)(im.blk_comp[j < im.bpm ? j : 0] & 3) << (2 * j);
-        T.comps = cp;
+        // the tables the scan names: at their own slots (NTAB = 8) or packed in the order the components name them (NTAB = 4; the
+        // launcher takes that kernel only when no file of the batch names more than four)
+        uint8_t gs[8] = {0, 1, 2, 3, 4, 5, 6, 7}; int ng = NTAB == 8 ? 8 : 0;
+        int dcid[3] = {0, 0, 0}, acid[3] = {0, 0, 0};
+        for (int c = 0; c < im.nc && c < 3; c++) {
+            if (NTAB == 8) { dcid[c] = im.td[c] & 3; acid[c] = im.ta[c] & 3; continue; }
+            for (int pass = 0; pass < 2; pass++) {
+                const int want = pass ? 4 + (im.ta[c] & 3) : (im.td[c] & 3);
+                int at = -1;
+                for (int q = 0; q < ng; q++) if (gs[q] == want) at = q;
+                if (at < 0 && ng < 4) { at = ng; gs[ng++] = (uint8_t)want; }
+                if (at < 0) at = 0;                        // (cannot happen: see the launcher)
+                (pass ? acid : dcid)[c] = at;
+            }
+        }
+        for (int q = 0; q < 8; q++) T.gslot[q] = q < ng ? gs[q] : gs[0];
+        unsigned long long sl = 0; uint32_t cp = 0;
+        for (int j = 0; j < JPG_MAX_BPM; j++) {
+            const int cc = im.blk_comp[j < im.bpm ? j : 0], c = cc < 3 ? cc : 0;
+            sl |= (unsigned long long)(dcid[c] | (acid[c] << 2)) << (4 * j);
+            cp |= (uint32_t)(c & 3) << (2 * j);
+        }
+        T.slots = sl; T.comps = cp;
+        T.bpm = im.bpm; T.ri = im.ri; T.nrst = (int)im.nrst; T.total_blocks = im.total_blocks; T.clean_len = im.clean_len;
     }
-    if (tid == 0) { T.bpm = im.bpm; T.ri = im.ri; T.nrst = (int)im.nrst; T.total_blocks = im.total_blocks; T.clean_len = im.clean_len; }
-    const int bpm = im.bpm, ri = im.ri, total_blocks = im.total_blocks, mcus_all = im.mx * im.my;
+    if (tid < 64) T.zigzag[tid] = d_zigzag[tid];
+    __syncthreads();
+    {
+        constexpr int LW = (1 << JPG_LOOK) / 2, SW = JPG_LONG * 64 / 2;
+        for (int i = tid; i < NTAB * LW; i += JPG_NT) { const int t = i / LW, w = i - t * LW; ((uint32_t*)&T.lut[t][0])[w] = ((const uint32_t*)&G.lut[T.gslot[t]][0])[w]; }
+        for (int i = tid; i < NTAB * SW; i += JPG_NT) { const int t = i / SW, w = i - t * SW; ((uint32_t*)&T.sub[t][0][0])[w] = ((const uint32_t*)&G.sub[T.gslot[t]][0][0])[w]; }
+        for (int i = tid; i < NTAB * 18; i += JPG_NT) { const int t = i / 18, w = i - t * 18; T.maxcode[t][w] = G.maxcode[T.gslot[t]][w]; T.valoff[t][w] = G.valoff[T.gslot[t]][w]; }
+        for (int i = tid; i < NTAB * 256; i += JPG_NT) { const int t = i >> 8, w = i & 255; T.vals[t][w] = G.vals[T.gslot[t]][w]; }
+    }
+    const int bpm = im.bpm, total_blocks = im.total_blocks;
     const uint8_t* clean = clean_all + im.clean_off;
     const uint32_t* rst = rst_all + im.rst_off;
     int16_t* coef = coef_all + (size_t)im.coef_blk * 64;
@@ -389,7 +457,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
 #pragma unroll 1
         for (int j = 0; j < JPG_NSEG; j++) {
             int dz[4] = {0, 0, 0, 0};
-            const int c = jpg_span<false>(T, clean, rst, mine, seg_end(j), nullptr, 0, dz);
+            const int c = jpg_span<false>(T, clean, rst, mine, seg_end(j), nullptr, 0, dz, ring);
             JSeg g; g.bit = mine.bit; g.bk = mine.bk; g.cnt = c; g.d[0] = dz[0]; g.d[1] = dz[1]; g.d[2] = dz[2]; g.d[3] = dz[3];
             s_seg[j][tid] = g;
         }
@@ -414,7 +482,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
 #pragma unroll 1
             for (int j = 0; j < JPG_NSEG && !same; j++) {
                 int dz[4] = {0, 0, 0, 0};
-                const int c = jpg_span<false>(T, clean, rst, st, seg_end(j), nullptr, 0, dz);
+                const int c = jpg_span<false>(T, clean, rst, st, seg_end(j), nullptr, 0, dz, ring);
                 same = st.bit == s_seg[j][tid].bit && st.bk == s_seg[j][tid].bk;
                 JSeg g; g.bit = st.bit; g.bk = st.bk; g.cnt = c; g.d[0] = dz[0]; g.d[1] = dz[1]; g.d[2] = dz[2]; g.d[3] = dz[3];
                 s_seg[j][tid] = g;
@@ -440,7 +508,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         }
     }
     int total_cnt;
-    const int first = wg_scan_excl(cnt, s_tmp, tid, &total_cnt);
+    const int first = wg_scan_excl(cnt, s_tmp, tid, &total_cnt);     // (its barriers also separate the reads of the segments from the scan that reuses their bytes)
     s_dc[tid][0] = dcs[0]; s_dc[tid][1] = dcs[1]; s_dc[tid][2] = dcs[2]; s_dc[tid][3] = dcs[3];
     __syncthreads();
     for (int d = 1; d < JPG_NT; d <<= 1) {
@@ -460,7 +528,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         if (tid > 0) st = s_st[tid - 1];
         int done = 0;
 #pragma unroll 1
-        for (int j = 0; j < JPG_NSEG; j++) done += jpg_span<true>(T, clean, rst, st, seg_end(j), coef, (uint32_t)(first + done), dcs);
+        for (int j = 0; j < JPG_NSEG; j++) done += jpg_span<true>(T, clean, rst, st, seg_end(j), coef, (uint32_t)(first + done), dcs, ring);
     }
 #endif
     // 4b. a file whose data ends early (truncated, or cut by a stray marker): libjpeg decodes the MCU in which the data
@@ -474,10 +542,9 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
             if (nbits == 0) { st.bit = 0; st.bk = 0; }
             const int mcu = total_cnt / bpm;
             if (!(st.bk == 0 && st.bit > nbits))                         // (else the MCU just completed already took bits past the end: it was the one)
-                jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, dcs, (mcu + 1) * bpm - total_cnt);
+                jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, dcs, ring, (mcu + 1) * bpm - total_cnt);
         }
     }
-    (void)ri; (void)mcus_all;
 }
 
 // ------------------------------------------------------------------ k_jpeg_idct  (jidctint.c jpeg_idct_islow)
@@ -662,10 +729,11 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const
 
 // ------------------------------------------------------------------ launchers
 void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
-                        int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h, bool gray)
+                        int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h, bool gray, bool packed_tables)
 {
     hipLaunchKernelGGL(k_jpeg_unstuff, dim3(F), dim3(JPG_UNS_NT), 0, s, blob, imgs, clean, rst);
-    hipLaunchKernelGGL(k_jpeg_huffman, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
+    if (packed_tables) hipLaunchKernelGGL(k_jpeg_huffman<4>, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
+    else hipLaunchKernelGGL(k_jpeg_huffman<8>, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, F), dim3(256), 0, s, imgs, tabs, coef, planes);
     const dim3 cgrid((unsigned)(((size_t)((max_w + 255) / 256) * max_h + 3) / 4), F);
     if (gray) hipLaunchKernelGGL(k_jpeg_color<true>, cgrid, dim3(256), 0, s, imgs, planes, out);

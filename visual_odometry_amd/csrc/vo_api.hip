@@ -2097,6 +2097,8 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     const size_t base = (size_t)offsets[f0], bytes = (size_t)(offsets[f0 + n] - offsets[f0]);
     size_t clean = 0, rst = 0, blocks = 0, planes = 0;
     int max_blocks = 0;
+    static const bool full_tables = getenv("VO_JPEG_FULL_TABLES") != nullptr;    // (test hook: the eight-slot kernel for every batch)
+    bool packed_tables = !full_tables;
     for (int k = 0; k < n; k++) {
         const char* why = "";
         const size_t o = (size_t)offsets[f0 + k], len = (size_t)(offsets[f0 + k + 1] - offsets[f0 + k]);
@@ -2117,6 +2119,11 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
         if (gray) { im.out_off = (uint64_t)k * gray_frame; im.out_stride = (uint32_t)gray_stride; }
         else { im.out_off = (uint64_t)k * out_h * out_w * 3; im.out_stride = (uint32_t)out_w * 3; }
         if (im.total_blocks > max_blocks) max_blocks = im.total_blocks;
+        {
+            unsigned named = 0;                            // Huffman tables the scan names (bits 0-3: DC, 4-7: AC)
+            for (int c = 0; c < im.nc && c < 3; c++) named |= (1u << (im.td[c] & 3)) | (16u << (im.ta[c] & 3));
+            if (__builtin_popcount(named) > 4) packed_tables = false;
+        }
         if (clean > 0xf0000000ull || blocks > 0xf0000000ull) FAIL(VO_ERR_UNSUPPORTED, "JPEG batch too large for one launch");
     }
     if (bytes > 0xf0000000ull) FAIL(VO_ERR_UNSUPPORTED, "JPEG batch too large for one launch");
@@ -2137,7 +2144,7 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     {
         StageTimer t(ctx, ST_MISC);
         launch_jpeg_decode(s, ctx->jpg_blob, (JpegImage*)ctx->jpg_img, (const JpegTables*)ctx->jpg_tab, n, ctx->jpg_clean, (uint32_t*)ctx->jpg_rst,
-                           (int16_t*)ctx->jpg_coef, ctx->jpg_planes, gray ? gray : ctx->jpg_out, max_blocks, out_w, out_h, gray != nullptr);
+                           (int16_t*)ctx->jpg_coef, ctx->jpg_planes, gray ? gray : ctx->jpg_out, max_blocks, out_w, out_h, gray != nullptr, packed_tables);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));                  // the host vectors must outlive their copies
