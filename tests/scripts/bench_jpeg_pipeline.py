@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1280); ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--pairs", type=int, default=256); ap.add_argument("--contexts", type=int, default=3)
-    ap.add_argument("--chunks", type=int, default=6, help="chunks per context in the timed region")
+    ap.add_argument("--chunks", type=int, default=40, help="chunks per context in the timed region")
     ap.add_argument("--scale", type=float, default=1.0, help="cv2.resize factor applied at ingest (the reference uses 0.3 on 4K footage)")
     ap.add_argument("--quality", type=int, default=90); ap.add_argument("--distinct", type=int, default=64)
     a = ap.parse_args()

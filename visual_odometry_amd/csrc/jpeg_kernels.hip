@@ -9,13 +9,16 @@
 //   k_jpeg_huffman   Huffman decoding IN PARALLEL inside one scan: the clean stream is cut into one subsequence per
 //                    thread; every thread decodes its subsequence from a guessed state, then the end states are
 //                    propagated (thread i restarts from thread i-1's end state) until nothing changes — Huffman codes
-//                    self-synchronise after a few symbols, so this takes two or three rounds; a scan of the per-thread
+//                    self-synchronise, so this takes two or three rounds, and a round stops at the first checkpoint inside
+//                    the subsequence that it reaches in the state recorded there; the bit readers take their input from
+//                    LDS rings that are refilled two symbols ahead of the need; a scan of the per-thread
 //                    block counts gives every thread its first coefficient block, a segmented scan of the per-thread DC
 //                    sums (kept in registers by every pass) its DC predictions, and a last pass writes the coefficients
 //                    (de-zigzagged, DC coefficients as values);
 //   k_jpeg_idct      lane per 8x8 block: dequantisation + jidctint.c's two-pass 13-bit integer IDCT;
 //   k_jpeg_color     lane per 4 output pixels: h2v1 / h2v2 triangle upsampling (jdsample.c), jdcolor.c's fixed-point
-//                    YCbCr -> RGB, stores B G R.
+//                    YCbCr -> RGB, stores B G R — or, for the frame ingest at the files' own size, cvtColor's gray value
+//                    of them straight into level 0 of the frame slots.
 // Headers (SOI .. SOS) are parsed on the host (jpeg_parse): a few hundred bytes per file.
 #include "vo_internal.h"
 #include <string.h>
@@ -190,7 +193,13 @@ struct JState { uint32_t bit; uint32_t bk; };              // position in the cl
 #define JPG_CK1_SHIFT 1                   // second after 1 / 2
 #endif
 #define JPG_NSEG (JPG_NCK + 1)
-struct JSeg { uint32_t bit, bk; int cnt; int d[4]; };      // state behind a segment; blocks completed and DC sums (+ "crossed a restart") inside it
+struct JSeg {                                              // a segment of a subsequence as one decode left it:
+    uint32_t bit, bkr;                                     // the state behind it (bkr: JState::bk | "crossed a restart" << 16),
+    int cnt, d[3];                                         // blocks completed and DC sums inside it
+    __device__ __forceinline__ void set(const JState& st, int c, const int (&dz)[4])
+    { bit = st.bit; bkr = st.bk | (dz[3] ? 0x10000u : 0u); cnt = c; d[0] = dz[0]; d[1] = dz[1]; d[2] = dz[2]; }
+    __device__ __forceinline__ bool at(const JState& st) const { return bit == st.bit && (bkr & 0xffffu) == st.bk; }
+};
 
 // The bit reader.  Its input reaches the lane through a small ring in LDS (JPG_RING dwords per lane): every second symbol —
 // at the same instruction for the whole wavefront — a lane whose ring has room fetches its next 16 bytes, and stores them
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         for (int j = 0; j < JPG_NSEG; j++) {
             int dz[4] = {0, 0, 0, 0};
             const int c = jpg_span<false>(T, clean, rst, mine, seg_end(j), nullptr, 0, dz, ring);
-            JSeg g; g.bit = mine.bit; g.bk = mine.bk; g.cnt = c; g.d[0] = dz[0]; g.d[1] = dz[1]; g.d[2] = dz[2]; g.d[3] = dz[3];
+            JSeg g; g.set(mine, c, dz);
             s_seg[j][tid] = g;
         }
     }
@@ -483,8 +492,8 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
             for (int j = 0; j < JPG_NSEG && !same; j++) {
                 int dz[4] = {0, 0, 0, 0};
                 const int c = jpg_span<false>(T, clean, rst, st, seg_end(j), nullptr, 0, dz, ring);
-                same = st.bit == s_seg[j][tid].bit && st.bk == s_seg[j][tid].bk;
-                JSeg g; g.bit = st.bit; g.bk = st.bk; g.cnt = c; g.d[0] = dz[0]; g.d[1] = dz[1]; g.d[2] = dz[2]; g.d[3] = dz[3];
+                same = s_seg[j][tid].at(st);
+                JSeg g; g.set(st, c, dz);
                 s_seg[j][tid] = g;
             }
             changed = !same;
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
         for (int j = 0; j < JPG_NSEG; j++) {
             const JSeg g = s_seg[j][tid];
             cnt += g.cnt;
-            if (g.d[3]) { dcs[0] = g.d[0]; dcs[1] = g.d[1]; dcs[2] = g.d[2]; dcs[3] = 1; }
+            if (g.bkr >> 16) { dcs[0] = g.d[0]; dcs[1] = g.d[1]; dcs[2] = g.d[2]; dcs[3] = 1; }
             else { dcs[0] += g.d[0]; dcs[1] += g.d[1]; dcs[2] += g.d[2]; }
         }
     }
