@@ -453,17 +453,11 @@ void launch_match_nn(hipStream_t s, const uint8_t* desc_x, const int* kp_count, 
 // nearer), and keeps per lane the best (and second best) value with the group it came from: strict > keeps the earliest.
 #define L8_STAGE_ROWS 128
 #define L8_LD (L8_STAGE_ROWS * 128 / 16 / MM_THREADS)
-template <bool KNN2>
-__global__ __launch_bounds__(MM_THREADS) void k_nn_l2i8(const uint8_t* desc_x, const int* norms, const int* kp_count, int kp_cap, int cap_x,
-                                                 PairBuf pb, int dir_first, int row_blocks)
+template <bool KNN2, bool PACKED>
+__device__ __forceinline__ void nn_l2i8_body(uint8_t (*s_b)[L8_STAGE_ROWS * 128], const uint8_t* desc_x, const int* norms, int kp_cap, int cap_x,
+                                             const PairBuf& pb, int p, int dir, int fa, int fb, int na, int nb, int row0)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_b[2][L8_STAGE_ROWS * 128];
-    const int bid = xcd_tile(blockIdx.x, gridDim.x);
-    const int p = bid / row_blocks, dir = dir_first + blockIdx.z;
-    const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
-    const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
-    const int row0 = (bid % row_blocks) * MM_BLOCK_ROWS;
-    if (row0 >= na) return;
+    constexpr bool packed = PACKED;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const uint8_t* A = desc_x + (size_t)fa * cap_x * 128;
@@ -483,20 +477,34 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_l2i8(const uint8_t* desc_x, c
 
     const int nstages = (nb + L8_STAGE_ROWS - 1) / L8_STAGE_ROWS;
     const bool active = wrow0 < na;
+
 #define L8_GLDS(stage, buf)                                                                                        \
     _Pragma("unroll") for (int q = 0; q < L8_LD; q++)                                                              \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)(stage) * (L8_STAGE_ROWS * 128) + (size_t)(q * MM_THREADS + tid) * 16), \
                                          (__attribute__((address_space(3))) void*)(s_b[buf] + (q * MM_THREADS + wave * 64) * 16), 16, 0, 0)
-    if (nstages > 0) { L8_GLDS(0, 0); }
+    // |b - 128|^2 of the stage's train rows: loaded a stage ahead, like the rows themselves (a load inside the group loop is
+    // waited for at once: ~600 cycles per group with four waves per SIMD to hide it)
+    constexpr int NGS = L8_STAGE_ROWS / 16;
+    int nbn[NGS], nbs[NGS];
+#define L8_NORMS(stage)                                                                                            \
+    _Pragma("unroll") for (int g = 0; g < NGS; g++) {                                                              \
+        const int jn = ((stage) * NGS + g) * 16 + li;                                                              \
+        nbn[g] = jn < nb ? nB[jn] : 0x3fffffff;          /* columns past the end can never win */                  \
+    }
+    if (nstages > 0) { L8_NORMS(0); L8_GLDS(0, 0); }
     for (int sg = 0; sg < nstages; sg++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (sg + 1 < nstages) { L8_GLDS(sg + 1, (sg + 1) & 1); }
+#pragma unroll
+        for (int g = 0; g < NGS; g++) nbs[g] = nbn[g];
+        if (sg + 1 < nstages) { L8_NORMS(sg + 1); L8_GLDS(sg + 1, (sg + 1) & 1); }
         const uint8_t* sb = s_b[sg & 1];
         const int ng = active ? min(L8_STAGE_ROWS / 16, (nb - sg * L8_STAGE_ROWS + 15) >> 4) : 0;
-        for (int g = 0; g < ng; g++) {
+#pragma unroll
+        for (int g = 0; g < NGS; g++) {
+            if (g >= ng) break;
             const int gi = sg * (L8_STAGE_ROWS / 16) + g, j = gi * 16 + li;
-            const int nbj = j < nb ? nB[j] : 0x3fffffff;          // columns past the end can never win
+            const int nbj = nbs[g];
             v4i b[2], acc[MM_RB];
 #pragma unroll
             for (int s = 0; s < 2; s++) b[s] = *(const v4i*)(sb + g * 2048 + (4 * s + lg) * 256 + li * 16);
@@ -505,6 +513,22 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_l2i8(const uint8_t* desc_x, c
             for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][0], b[0], zero, 0, 0, 0);
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++) acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[rb][1], b[1], acc[rb], 0, 0, 0);
+            if (packed) {
+                // value and group in ONE word: key = val * 256 + (255 - group) = (dot << 9) + c with c = 255 - group - |b|^2 * 256 per
+                // lane and group; the maximum key is the largest value and, among equal values, the earliest group — the
+                // same selection in two instructions per element instead of four
+                const int c = (255 - gi) - ((j < nb ? nbj : 0) << 8);
+                const bool dead = j >= nb;                        // (columns past the end exist in the frame's last group only)
+#pragma unroll
+                for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        int key = (int)(((unsigned)acc[rb][r] << 9) + (unsigned)c);
+                        if (gi * 16 + 16 > nb) key = dead ? INT_MIN : key;
+                        bv[rb][r] = max(bv[rb][r], key);
+                    }
+                continue;
+            }
 #pragma unroll
             for (int rb = 0; rb < MM_RB; rb++)
 #pragma unroll
@@ -525,6 +549,17 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_l2i8(const uint8_t* desc_x, c
         }
     }
 #undef L8_GLDS
+#undef L8_NORMS
+    if (packed) {
+#pragma unroll
+        for (int rb = 0; rb < MM_RB; rb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int key = bv[rb][r];
+                bg[rb][r] = key == INT_MIN ? -1 : 255 - (key & 255);
+                bv[rb][r] = key >> 8;
+            }
+    }
     // fold the 16 lanes (columns li of every group) of a row: 64-bit keys (value + 2^31) << 32 | ~column — larger value first,
     // then the lower column
     const int* nA = norms + (size_t)fa * cap_x;
@@ -556,6 +591,23 @@ __global__ __launch_bounds__(MM_THREADS) void k_nn_l2i8(const uint8_t* desc_x, c
                 }
             }
         }
+}
+
+template <bool KNN2>
+__global__ __launch_bounds__(MM_THREADS) void k_nn_l2i8(const uint8_t* desc_x, const int* norms, const int* kp_count, int kp_cap, int cap_x,
+                                                 PairBuf pb, int dir_first, int row_blocks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[2][L8_STAGE_ROWS * 128];
+    const int bid = xcd_tile(blockIdx.x, gridDim.x);
+    const int p = bid / row_blocks, dir = dir_first + blockIdx.z;
+    const int fa = pb.slots[2 * p + dir], fb = pb.slots[2 * p + (dir ^ 1)];
+    const int na = min(kp_count[fa], kp_cap), nb = min(kp_count[fb], kp_cap);
+    const int row0 = (bid % row_blocks) * MM_BLOCK_ROWS;
+    if (row0 >= na) return;
+    // one-word keys (value * 256 + 255 - group): |val| < 2^23 (d^2 < 2^22 for the rows k_sb_descriptor does not flag, |b - 128|^2 <= 2^21)
+    // and up to 256 groups of 16 train rows fit an int32
+    if (!KNN2 && nb <= 4096) nn_l2i8_body<false, true>(s_b, desc_x, norms, kp_cap, cap_x, pb, p, dir, fa, fb, na, nb, row0);
+    else nn_l2i8_body<KNN2, false>(s_b, desc_x, norms, kp_cap, cap_x, pb, p, dir, fa, fb, na, nb, row0);
 }
 
 void launch_match_nn_l2i8(hipStream_t s, const uint8_t* desc_x, const int* norms, const int* kp_count, int kp_cap, int cap_x, PairBuf pb, int P,

@@ -140,6 +140,50 @@ __device__ __forceinline__ float4 sb_base_px4(const SiftBaseSrc& B, const uint8_
     }
     return make_float4(out[0], out[1], out[2], out[3]);
 }
+// The same four pixels for a single-channel source, in two halves, so that the loads of a step are in flight during the previous
+// step's arithmetic like the float sources': sb_base_raw issues one unaligned dword per source row (the columns 2 t - 1 .. 2 t + 2
+// the four pixels touch; at the image's left / right edge the dword starts one column later / earlier), sb_base_finish turns the
+// bytes into the pixels.  The weights of cv::resize's float path at scale 1 / 2 are 0.25 / 0.75 by the pixel's parity, 1 / 0 at the
+// two clamped columns 0 and w - 1 (and rows 0 and h - 1).
+typedef uint32_t __attribute__((aligned(1))) sb_u32_unaligned;
+__device__ __forceinline__ uint2 sb_base_raw(const SiftBaseSrc& B, const uint8_t* f, int sy, int sy1, int dx0)
+{
+    const int c = min(max(2 * (dx0 >> 2) - 1, 0), B.sw - 4);
+    return make_uint2(*(const sb_u32_unaligned*)(f + (size_t)sy * B.row_stride + c), *(const sb_u32_unaligned*)(f + (size_t)sy1 * B.row_stride + c));
+}
+// Every weight is 1/4 or 3/4 (or 1 / 0 at a clamped row / column) and every source value an integer below 256, so each product
+// and each sum of the float formula (r0 = v a0 + v' a1; r0 b0 + r1 b1) is exact — multiples of 1/16 below 256 — whatever
+// the order: the pixel IS N / 16 with N = the integer dot product of the four source bytes with the weights 16 a b (1, 3, 9; 4, 12,
+// 16 at clamped positions).  One byte permute + one v_dot4_u32_u8 + one conversion + one exact multiply per pixel.
+// bw: the row weights 4 b0 | 4 b1 << 8 (sb_base_row_w).
+__device__ __forceinline__ void sb_base_row_w(const SiftBaseSrc& B, int dy, int& sy, int& sy1, uint32_t& bw)
+{
+    // fy = dy / 2 - 1/4: floor (dy - 1) >> 1, fraction 3/4 (dy even) or 1/4 (dy odd); clamped rows take weight 1 / 0 — sb_base_row in integers
+    sy = (dy - 1) >> 1;
+    uint32_t w1 = (dy & 1) ? 1u : 3u;
+    if (sy < 0) { w1 = 0u; sy = 0; }
+    if (sy >= B.sh - 1) { w1 = 0u; sy = B.sh - 1; }
+    sy1 = min(sy + 1, B.sh - 1);
+    bw = (4u - w1) | (w1 << 8);
+}
+__device__ __forceinline__ float4 sb_base_finish(const SiftBaseSrc& B, uint2 raw, uint32_t bw, int dx0, int w)
+{
+    const int c0 = 2 * (dx0 >> 2) - 1;
+    uint32_t w0 = raw.x, w1 = raw.y;
+    if (c0 < 0) { w0 = (w0 << 8) | (w0 & 255u); w1 = (w1 << 8) | (w1 & 255u); }                            // columns 0 0 1 2
+    else if (c0 > B.sw - 4) { w0 = (w0 >> 8) | (w0 & 0xff000000u); w1 = (w1 >> 8) | (w1 & 0xff000000u); }   // columns sw-3 sw-2 sw-1 sw-1
+    const uint32_t b0 = bw & 255u, b1 = bw >> 8;
+    // weight words for the byte order (row 0 left, row 0 right, row 1 left, row 1 right)
+    const uint32_t We = b0 * 0x0301u + b1 * 0x03010000u;       // even pixel: a = 1/4, 3/4
+    const uint32_t Wo = b0 * 0x0103u + b1 * 0x01030000u;       // odd pixel:  a = 3/4, 1/4
+    const uint32_t Wc = b0 * 0x0004u + b1 * 0x00040000u;       // clamped column: a = 1, 0
+    const uint32_t W0 = dx0 == 0 ? Wc : We, W3 = dx0 + 3 == w - 1 ? Wc : Wo;
+    // pixel j takes the cached columns n0 = (j + 1) >> 1 and n0 + 1 of both rows (perm selectors: bytes 0-3 = w0, 4-7 = w1)
+    const uint32_t p0 = __builtin_amdgcn_perm(w1, w0, 0x05040100u), p1 = __builtin_amdgcn_perm(w1, w0, 0x06050201u), p3 = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+    const float s = 0.0625f;
+    return make_float4((float)__builtin_amdgcn_udot4(p0, W0, 0u, false) * s, (float)__builtin_amdgcn_udot4(p1, Wo, 0u, false) * s,
+                       (float)__builtin_amdgcn_udot4(p1, We, 0u, false) * s, (float)__builtin_amdgcn_udot4(p3, W3, 0u, false) * s);
+}
 
 // ------------------------------------------------------------------ one scale-space layer: Gaussian blur + DoG, one sweep
 #define SW_TW 128                      // columns of a strip
@@ -213,6 +257,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     // loads: wavefront v brings rows v and v + 4 of a step's eight source rows, lane = 16-byte piece of the row; the row index
     // (and its reflection at the image border) is a scalar
     float4 ld[2];
+    const bool bfast = BASE && interior && B.channels == 1;   // single-channel frames: bytes now, pixels when the registers go to LDS
+    uint2 braw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    uint32_t bbw[2] = {0u, 0u};
     auto issue = [&](int k) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -220,6 +267,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
             const int x = xa + 4 * lane;
             if (BASE) {
                 int sy, sy1; float b0, b1;
+                if (bfast) { sb_base_row_w(B, yy, sy, sy1, bbw[q]); if (lane < per_row) braw[q] = sb_base_raw(B, bimg, sy, sy1, x); continue; }
                 sb_base_row(B, yy, sy, sy1, b0, b1);
                 if (lane < per_row) {
                     if (interior) ld[q] = sb_base_px4(B, bimg, sy, sy1, b0, b1, x);
@@ -244,6 +292,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     for (int k = 0; k < nsteps; k++) {
         // the segment of step k: registers -> LDS (all threads are past the row pass of step k - 1: second barrier below)
         if (lane < per_row) {
+            if (bfast) { ld[0] = sb_base_finish(B, braw[0], bbw[0], xa + 4 * lane, w); ld[1] = sb_base_finish(B, braw[1], bbw[1], xa + 4 * lane, w); }
             *(float4*)(s_in + wave * INP + 4 * lane) = ld[0];
             *(float4*)(s_in + (wave + 4) * INP + 4 * lane) = ld[1];
         }
