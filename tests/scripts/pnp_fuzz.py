@@ -1,4 +1,4 @@
-"""Diagnostic (GPU box): random PnP problems (sizes, outlier rates, noise, planar maps, near-planar maps) through the library and the
+"""Checker script (GPU box; imports the oracle, so it lives under tests/): random PnP problems (sizes, outlier rates, noise, planar maps, near-planar maps) through the library and the
 oracle in both refinement modes: identical inlier sets, and the largest pose difference seen."""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
