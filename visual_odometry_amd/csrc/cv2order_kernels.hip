@@ -237,6 +237,90 @@ __device__ __forceinline__ void introselect_loop(A a, int& first, int& last, int
     }
 }
 
+// ---- the same passes by ONE wavefront, for a range of at most CV_WAVE_CAP entries in LDS: no workgroup barriers (the wave's own
+// LDS accesses are ordered; a fence keeps the compiler from moving them), 64-ary search for the number of swaps.  The recursion
+// spends about ten of its ~ 25 passes on ranges this short, where a pass of the whole workgroup is six barriers for a handful of
+// elements (measured, stage time per 257 frames: no wave tail 0.360 ms, below 256 / 1024 / 4096 entries 0.327 / 0.339 / 0.368).
+#ifndef CV_WAVE_CAP
+#define CV_WAVE_CAP 256
+#endif
+#define CV_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+template <typename P>
+__device__ __forceinline__ int first_true_wave(int m, int lane, P pred)
+{
+    int lo = 0, hi = m;                                       // answer in [lo, hi]; pred(hi) counts as true
+    while (hi > lo) {
+        const int step = (hi - lo + 63) / 64;
+        const int k = lo + lane * step;
+        const bool t = k < hi ? pred(k) : true;
+        const unsigned long long m64 = __ballot(t);
+        const int tf = m64 ? (int)__ffsll((long long)m64) - 1 : 64;
+        const int kt = lo + tf * step;
+        const int nhi = tf < 64 && kt < hi ? kt : hi;
+        const int nlo = tf > 0 ? min(lo + (tf - 1) * step + 1, nhi) : lo;
+        lo = nlo; hi = nhi;
+        if (step == 1) break;
+    }
+    return hi;
+}
+
+// std::__unguarded_partition_pivot on [first, last) of the LDS copy, by the calling wavefront (all 64 lanes); returns the cut
+__device__ __forceinline__ int partition_pivot_wave(uint2* a, int first, int last, uint16_t* lpos, uint16_t* rpos)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) {                                           // std::__move_median_to_first(first, first + 1, mid, last - 1)
+        const int Ai = first + 1, B = first + (last - first) / 2, C = last - 1;
+        int m;
+        if (el_gt(a[Ai], a[B])) m = el_gt(a[B], a[C]) ? B : el_gt(a[Ai], a[C]) ? C : Ai;
+        else m = el_gt(a[Ai], a[C]) ? Ai : el_gt(a[B], a[C]) ? C : B;
+        const uint2 t = a[first]; a[first] = a[m]; a[m] = t;
+    }
+    CV_WSYNC();
+    const uint2 pivot = a[first];
+    const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    int nl = 0, nr = 0;
+    for (int base = first + 1; base < last; base += 64) {
+        const int i = base + lane;
+        bool fl = false, fr = false;
+        if (i < last) { const uint2 v = a[i]; fl = !el_gt(v, pivot); fr = !el_gt(pivot, v); }
+        const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
+        if (fl) lpos[nl + (int)__popcll(ml & below)] = (uint16_t)i;
+        if (fr) rpos[nr + (int)__popcll(mr & below)] = (uint16_t)i;
+        nl += (int)__popcll(ml); nr += (int)__popcll(mr);
+    }
+    CV_WSYNC();
+    // K = first k with L[k] >= R[k] (L[k] = lpos[k], R[k] = rpos[nr - 1 - k]); cut = min(L[K], R[K - 1])
+    const int K = first_true_wave(min(nl, nr), lane, [&](int k) { return lpos[k] >= rpos[nr - 1 - k]; });
+    const int INF = 1 << 30;
+    const int lk = K < nl ? (int)lpos[K] : INF, rk = K > 0 ? (int)rpos[nr - K] : INF;
+    for (int k = lane; k < K; k += 64) {
+        const int i = (int)lpos[k], j = (int)rpos[nr - 1 - k];
+        const uint2 x = a[i], y = a[j];
+        a[i] = y; a[j] = x;
+    }
+    CV_WSYNC();
+    return lk < rk ? lk : rk;
+}
+
+// the rest of std::__introselect on the LDS copy (range [first, last) <= CV_WAVE_CAP), including its insertion-sort / heap-select
+// tails: called by ONE wavefront
+__device__ __forceinline__ void introselect_wave(uint2* a, int first, int last, int nth, int depth, uint16_t* lpos, uint16_t* rpos)
+{
+    const int lane = threadIdx.x & 63;
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) { heap_select(a, first, nth + 1, last); const uint2 t = a[first]; a[first] = a[nth]; a[nth] = t; }
+            CV_WSYNC();
+            return;
+        }
+        depth--;
+        const int cut = partition_pivot_wave(a, first, last, lpos, rpos);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (lane == 0) insertion_sort(a, first, last);
+    CV_WSYNC();
+}
+
 // The final std::partition(a + first, a + last, response >= thr) of retainBest when few elements satisfy the predicate (the
 // ties with the n-th response; everything in front of `first` is already >= thr, everything behind is <= thr).  Only the kept
 // prefix survives the resize, and it is determined by the right stoppers (the ties, taken from the back) and by the left
@@ -309,9 +393,9 @@ __device__ int retain_best_cv2(uint2* a, int n, int n_points, PosT* lpos, PosT* 
         for (int i = tid; i < len; i += CV_THREADS) s_a[i] = a[first + i];
         __syncthreads();
         int f2 = 0, l2 = len;
-        introselect_loop(s_a, f2, l2, nth - first, depth, done, 3, s_l, s_r, sh);
+        introselect_loop(s_a, f2, l2, nth - first, depth, done, CV_WAVE_CAP, s_l, s_r, sh);     // the whole workgroup while the range is long,
         if (!done) {
-            if (tid == 0) insertion_sort(s_a, f2, l2);
+            if (tid < 64) introselect_wave(s_a, f2, l2, nth - first, depth, s_l, s_r);          // one wavefront for the rest
             __syncthreads();
         }
         for (int i = tid; i < len; i += CV_THREADS) a[first + i] = s_a[i];
