@@ -103,8 +103,12 @@ static int build_huff(huff_t* h)
 static int32_t descale(int32_t x, int n) { return ADD(x, 1 << (n - 1)) >> n; }
 static uint8_t idct_limit(int32_t v)
 {
-    const int s = (int)(((uint32_t)v & 1023u) ^ 512u) - 512;             /* the 10-bit wrap of IDCT_range_limit & RANGE_MASK */
-    const int r = s + 128;
+    /* jidctint.c looks the sample up in IDCT_range_limit[v & RANGE_MASK] — a 10-bit WRAP: 512 <= v < 896 comes out as 0, not
+     * 255.  The libjpeg-turbo that cv2 (and Pillow) ship runs its SIMD transform (jidctint-sse2 / -avx2 / -neon), which narrows
+     * with SATURATION (packssdw, packsswb) and then adds 128: an overshoot stays at the end of the range.  The two differ only
+     * for samples more than four times out of range (quality 1 on saturated noise: one pixel in 53 000 random files,
+     * tests/golden/jpeg_gray_q1_saturated_329x267.jpg); the SIMD behaviour is what cv2.imread returns. */
+    const int r = v + 128;
     return (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
 }
 
@@ -343,10 +347,14 @@ int voo_jpeg_decode(const uint8_t* data, size_t n, uint8_t* out, int out_stride,
             if (ri && mcu && mcu % ri == 0) {                                 /* restart: byte-align, expect RSTn */
                 b.cnt = 0;
                 if (!b.marker) {                                              /* (padding bits were not all consumed) */
-                    if (b.pos + 1 < n && b.p[b.pos] == 0xFF && b.p[b.pos + 1] >= 0xD0 && b.p[b.pos + 1] <= 0xD7) b.marker = b.p[b.pos + 1];
+                    if (b.pos + 1 < n && b.p[b.pos] == 0xFF && b.p[b.pos + 1] >= 0xC0) b.marker = b.p[b.pos + 1];
+                    else if (b.pos >= n) b.marker = 0xD9;                     /* the file simply ends (the data source supplies an EOI) */
                 }
                 if (b.marker >= 0xD0 && b.marker <= 0xD7) { b.pos += 2; b.marker = 0; b.insufficient = 0; }
-                else if (!b.insufficient) goto done;
+                /* any other marker where RSTn should stand — a file cut exactly at the end of an interval: jdmarker.c
+                 * jpeg_resync_to_restart, action 3: "valid non-restart marker: return without advancing" — the marker stays
+                 * unread, process_restart resets the predictions (below), and the next MCU runs out of data as usual */
+                else if (!b.marker && !b.insufficient) goto done;             /* neither a marker nor the end: damaged data */
                 for (int i = 0; i < nc; i++) C[i].pred = 0;
             }
             /* jdhuff.c decode_mcu: "If we've run out of data, just leave the MCU set to zeroes" — the MCU during which the
@@ -369,8 +377,9 @@ int voo_jpeg_decode(const uint8_t* data, size_t n, uint8_t* out, int out_stride,
                             const int r = rs >> 4, sz = rs & 15;
                             if (sz == 0) { if (r == 15) { k += 15; continue; } break; }
                             k += r;
-                            if (k > 63) goto done;
-                            coef[ZIGZAG[k]] = (int16_t)extend(receive(&b, sz), sz);
+                            /* a run that leaves the block (damaged or zero-filled data): jdhuff.c stores through the 16 extra
+                             * entries of jpeg_natural_order[], all 63 — the value lands in the last coefficient, the block ends */
+                            coef[ZIGZAG[k > 63 ? 63 : k]] = (int16_t)extend(receive(&b, sz), sz);
                         }
                         idct_islow(coef, Q[C[i].tq], C[i].plane + (size_t)py * (C[i].bw * 8) + px, C[i].bw * 8);
                     }

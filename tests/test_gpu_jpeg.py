@@ -209,9 +209,18 @@ def test_data_cut_at_every_offset_equals_oracle(oracle, ctx):
     """An EOI spliced into the entropy-coded segment at every byte offset (data ending inside codes, values, at block and
     MCU boundaries, in the last block of an MCU, after a stuffed FF): kernel and oracle apply the same zero-fill rule."""
     from visual_odometry_amd import ingest
-    for ss, step in ((2, 1), (0, 3), (1, 3)):
-        f = encode(scene(302, 90, 150, "boxes"), quality=80, subsampling=ss)
+    for ss, step, kw in ((2, 1, {}), (0, 3, {}), (1, 3, {}), (2, 1, dict(restart_marker_blocks=2)), (0, 1, dict(restart_marker_blocks=1))):
+        f = encode(scene(302, 90, 150, "boxes") if not kw else scene(303, 70, 120, "boxes"), quality=80, subsampling=ss, **kw)   # (with restart intervals the cut also falls ON the RSTn markers)
         sos = f.index(b"\xff\xda"); start = sos + 2 + ((f[sos + 2] << 8) | f[sos + 3])
         for i0 in range(start, len(f) - 4, step):
             fb = bytearray(f); fb[i0:i0 + 2] = b"\xff\xd9"
             assert np.array_equal(ingest.imdecode(bytes(fb), ctx), oracle.jpeg_decode(bytes(fb))), (ss, i0)
+
+
+def test_far_out_of_range_samples_saturate(oracle, ctx):
+    """The file of test_oracle_jpeg.py::test_far_out_of_range_samples_saturate_like_libjpeg_turbos_simd_idct through the kernels."""
+    import os
+    from visual_odometry_amd import ingest
+    buf = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_gray_q1_saturated_329x267.jpg"), "rb").read()
+    got = ingest.imdecode(buf, ctx)
+    assert np.array_equal(got, oracle.jpeg_decode(buf)) and np.array_equal(got, pil_bgr(buf))

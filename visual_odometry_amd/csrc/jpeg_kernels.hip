@@ -361,9 +361,11 @@ __device__ __forceinline__ int jpg_span_t(const JL& T, const uint8_t* clean, con
 #ifdef JPG_EXP_NOSTORE
         if (WRITE && coefficient && k <= 64 && blk + done < total && v == 0x12345)
 #else
-        if (WRITE && coefficient && k <= 64 && blk + done < total)
+        if (WRITE && coefficient && blk + done < total)
 #endif
-            coef[(size_t)(blk + done) * 64 + T.zigzag[k - 1]] = (int16_t)(dc ? (cmp == 0 ? d0 : cmp == 1 ? d1 : d2) : v);
+            // (a run that leaves the block — damaged or zero-filled data — stores into the last coefficient, as jdhuff.c does through
+            //  the extra entries of jpeg_natural_order[])
+            coef[(size_t)(blk + done) * 64 + T.zigzag[min(k, 64) - 1]] = (int16_t)(dc ? (cmp == 0 ? d0 : cmp == 1 ? d1 : d2) : v);
         const bool end = k >= 64;
         k = end ? 0 : k;
         b = end ? (b + 1 == bpm ? 0 : b + 1) : b;
@@ -550,6 +552,29 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
             JState st = s_st[last];
             if (nbits == 0) { st.bit = 0; st.bk = 0; }
             const int mcu = total_cnt / bpm;
+            // Data that ends exactly where a restart marker should stand (a file cut at the end of an interval; its RSTn is not
+            // in the restart list, the terminating marker took its place): jdhuff.c's process_restart still runs before the
+            // next MCU — the padding bits of the last byte are dropped and the predictions restart (jdmarker.c leaves the other
+            // marker unread) — whereas the passes above took the padding for the start of that MCU (one symbol, no block).
+            // Whether the last MCU boundary is such a place depends on the MCU's number, so the owner walks its subsequence once
+            // more, block by block, from its settled start state (only files that end early AND have restart intervals).
+            if (T.ri > 0 && nbits > 0 && total_cnt % bpm == 0 && mcu > 0 && mcu % T.ri == 0) {
+                JState w; w.bit = 0; w.bk = 0;
+                if (last > 0) w = s_st[last - 1];
+                int fb = first, dz[4] = {0, 0, 0, 0};
+                while (w.bit <= nbits && fb <= total_cnt) {
+                    if (fb == total_cnt && w.bk == 0) {                  // the boundary in front of the MCU that ran out of data
+                        const uint32_t rem = nbits - w.bit;
+                        if (rem < 8 && (rem == 0 || (clean[(nbits >> 3) - 1] & ((1u << rem) - 1u)) == (1u << rem) - 1u)) {
+                            st.bit = nbits; st.bk = 0; dcs[0] = dcs[1] = dcs[2] = 0;
+                        }
+                        break;
+                    }
+                    const int c = jpg_span<false>(T, clean, rst, w, nbits, nullptr, 0, dz, ring, 1);
+                    if (c == 0) break;
+                    fb += c;
+                }
+            }
             if (!(st.bk == 0 && st.bit > nbits))                         // (else the MCU just completed already took bits past the end: it was the one)
                 jpg_span<true>(T, clean, rst, st, 0xffffffffu, coef, (uint32_t)total_cnt, dcs, ring, (mcu + 1) * bpm - total_cnt);
         }
@@ -588,8 +613,9 @@ __device__ __forceinline__ void jidct_1d(const int32_t* in, int32_t* out)
 
 __device__ __forceinline__ uint32_t jlimit(int32_t v)
 {
-    const int s = (int)(((uint32_t)v & 1023u) ^ 512u) - 512;              // IDCT_range_limit[v & RANGE_MASK]
-    return (uint32_t)min(max(s + 128, 0), 255);
+    // libjpeg-turbo's SIMD transform (what cv2 runs) narrows with saturation and adds 128; jidctint.c's table look-up
+    // IDCT_range_limit[v & RANGE_MASK] would wrap a sample that is more than four times out of range (oracle/voo_jpeg.c idct_limit)
+    return (uint32_t)min(max(v + 128, 0), 255);
 }
 
 __global__ __launch_bounds__(256) void k_jpeg_idct(const JpegImage* imgs, const JpegTables* tabs, const int16_t* coef_all, uint8_t* planes)
