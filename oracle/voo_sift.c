@@ -92,8 +92,9 @@ int voo_sift_gauss_kernel(double sigma, float* k /* >= n entries */)
 /* GaussianBlur(src, dst, Size(), sigma, sigma) for CV_32F: separable, BORDER_REFLECT_101 */
 static void gauss_blur(const fimg* src, fimg* dst, double sigma)
 {
-    float k[64];
-    const int n = voo_sift_gauss_kernel(sigma, k), r = n / 2, w = src->w, h = src->h;
+    const int n = voo_sift_gauss_kernel(sigma, NULL), r = n / 2, w = src->w, h = src->h;
+    float* k = (float*)malloc(sizeof(float) * (size_t)n);                      /* (one octave layer and a large sigma need > 100 taps) */
+    voo_sift_gauss_kernel(sigma, k);
     float* tmp = (float*)malloc(sizeof(float) * (size_t)w * h);
     for (int y = 0; y < h; y++) {                                              /* RowFilter: taps left to right */
         const float* s = src->p + (size_t)y * w;
@@ -110,7 +111,7 @@ static void gauss_blur(const fimg* src, fimg* dst, double sigma)
                 acc += k[r + i] * (tmp[(size_t)reflect101(y + i, h) * w + x] + tmp[(size_t)reflect101(y - i, h) * w + x]);
             dst->p[(size_t)y * w + x] = acc;
         }
-    free(tmp);
+    free(tmp); free(k);
 }
 
 /* resize(src, dst, Size(2w, 2h), INTER_LINEAR) for CV_32F (resizeGeneric_: horizontal pass, then vertical) */

@@ -120,3 +120,22 @@ def test_sift_differential_fuzz(oracle, ctx):
         assert np.array_equal(got["desc"], want["desc"]), case
         found += want["n_found"]
     assert found > 500
+
+
+def test_contrast_threshold_that_rounds_to_zero(oracle, ctx):
+    """tests/golden/sift_flat_threshold0_265x354.npz (found by tests/scripts/soak_sift.py): contrastThreshold 0.0156 with five layers
+    per octave makes the extrema threshold floor(0.5 * 0.0156 / 5 * 255) = 0, so every sample of the flat regions is a scale-space
+    "extremum" (>= comparisons) — 1.9 million candidates of which the refinement keeps 57.  The per-image call's candidate list
+    holds every DoG sample (cv2's lists are unbounded); with nfeatures = 50 retainBest keeps 51 (a tie)."""
+    import os
+    from visual_odometry_amd.detector import SiftDetector
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sift_flat_threshold0_265x354.npz"))
+    kw = dict(nOctaveLayers=int(d["nOctaveLayers"]), contrastThreshold=float(d["contrastThreshold"]), edgeThreshold=float(d["edgeThreshold"]),
+              sigma=float(d["sigma"]))
+    for nf, count in ((0, 57), (50, 51)):
+        want = oracle.sift_detect_and_compute(d["img"], nfeatures=nf, n_layers=kw["nOctaveLayers"], contrast_threshold=kw["contrastThreshold"],
+                                              edge_threshold=kw["edgeThreshold"], sigma=kw["sigma"])
+        got = SiftDetector(nfeatures=nf, ctx=ctx, **kw).detect_arrays(d["img"])
+        assert want["n_found"] == count and len(got["xy"]) == count and not got["truncated"]
+        for key in ("xy", "size", "angle", "response", "octave", "desc"):
+            assert np.array_equal(got[key], want[key]), (nf, key)

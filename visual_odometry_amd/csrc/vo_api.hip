@@ -1913,7 +1913,13 @@ extern "C" int vo_sift_detect_and_compute(vo_ctx* ctx, const uint8_t* img, int h
     HIPCHK(hipSetDevice(ctx->device));
     // the single-image call = the batched pipeline with one frame; capacities as generous as the per-image lists of cv2 need
     SiftState& S = ctx->sift1;
-    int rc = sift_setup(ctx, S, h, w, p, 1, 1 << 18, 1 << 18, 1 << 20, 1 << 18, 1, false);
+    // the candidate list can hold EVERY sample of every DoG layer that is searched: with a contrast threshold that rounds to 0
+    // (floor(0.5 * contrastThreshold / nOctaveLayers * 255) — e.g. 0.015 with five layers) every sample of a flat region is a
+    // scale-space "extremum" (cv2 compares with >=) and only the refinement throws them out again; cv2's lists are unbounded
+    long long cand_all = (long long)(2 * w) * (2 * h) * 4 / 3 * (p->n_octave_layers > 0 ? p->n_octave_layers : 1) + 4096;
+    if (cand_all < (1 << 20)) cand_all = 1 << 20;
+    if (cand_all > (1 << 27)) cand_all = 1 << 27;
+    int rc = sift_setup(ctx, S, h, w, p, 1, 1 << 18, 1 << 18, (int)cand_all, 1 << 18, 1, false);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
     const size_t img_bytes = (size_t)row_stride * h;
