@@ -17,7 +17,7 @@ def main():
     from oracle import oracle as O
     ctx = _lib.default_context(0)
     rng = np.random.default_rng(a.seed)
-    t0 = time.time(); n = 0; nbatch = 0; ntrunc = 0
+    t0 = time.time(); n = 0; nbatch = 0; ntrunc = 0; ningest = 0
     pending = {}; tick = t0
     while time.time() - t0 < a.seconds:
         if time.time() - tick > 30: tick = time.time(); print(f"... {n} files identical so far", flush=True)
@@ -65,6 +65,15 @@ def main():
         if not ok:
             print("MISMATCH", dict(h=h, w=w, kind=str(kind), gray=bool(gray), trunc=bool(trunc), seed=a.seed, n=n, **kw)); sys.exit(1)
         n += 1
+        if h >= 70 and w >= 70 and not trunc and rng.random() < 0.04:
+            # the frame ingest at the file's own size: gray level 0 straight from the decoder's colour conversion, then ORB
+            from visual_odometry_amd.frontend import FrontEnd
+            fe = FrontEnd(h, w, max_frames=1, max_pairs=1, nfeatures=200, ctx=ctx)
+            fe.ingest_jpeg([buf]); fe.detect(0, 1)
+            f, o = fe.features(0), O.orb_detect_and_compute(want, O.orb_params(nfeatures=200))
+            if not (np.array_equal(f["desc"], o["desc"]) and np.array_equal(f["xy"], o["xy"])):
+                print("INGEST MISMATCH", dict(h=h, w=w, kind=str(kind), gray=bool(gray), seed=a.seed, n=n, **kw)); sys.exit(1)
+            ningest += 1
         pending.setdefault((h, w), []).append((buf, got))
         if len(pending[(h, w)]) >= 3 or (rng.random() < 0.02 and pending):
             key = (h, w) if len(pending[(h, w)]) >= 3 else next(iter(pending))
@@ -73,7 +82,7 @@ def main():
             for o, (_, g) in zip(outs, items):
                 if not np.array_equal(o, g): print("BATCH MISMATCH", key, a.seed, n); sys.exit(1)
             nbatch += 1
-    print(json.dumps({"files": n, "truncated": ntrunc, "mixed_batches": nbatch, "seconds": round(time.time() - t0, 1), "identical": True}))
+    print(json.dumps({"files": n, "truncated": ntrunc, "mixed_batches": nbatch, "ingests_checked_through_orb": ningest, "seconds": round(time.time() - t0, 1), "identical": True}))
 
 
 if __name__ == "__main__":
