@@ -2146,7 +2146,6 @@ static int jpeg_decode_device(vo_ctx* ctx, const uint8_t* blob, const int64_t* o
     HIPCHK(hipMemcpyAsync(ctx->jpg_blob, blob + base, bytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->jpg_img, imgs.data(), (size_t)n * sizeof(JpegImage), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ctx->jpg_tab, tabs.data(), tabs.size() * sizeof(JpegTables), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(ctx->jpg_coef, 0, blocks * 128, s));
     {
         StageTimer t(ctx, ST_MISC);
         launch_jpeg_decode(s, ctx->jpg_blob, (JpegImage*)ctx->jpg_img, (const JpegTables*)ctx->jpg_tab, n, ctx->jpg_clean, (uint32_t*)ctx->jpg_rst,
