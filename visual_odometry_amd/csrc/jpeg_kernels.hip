@@ -5,7 +5,7 @@
 // Device pipeline for a batch of files (one launch each, one workgroup per image for the two entropy kernels):
 //   k_jpeg_unstuff   byte stuffing (FF 00) and RSTn markers removed from the entropy-coded segment; the restart
 //                    positions and the end of the data found in parallel: sixteen wavefronts per file, each walking its
-//                    segment 256 bytes at a time (coalesced dwords, neighbour bytes by shuffles, ballot prefixes);
+//                    segment 1024 bytes at a time (sixteen bytes per lane, only the FFs and the bytes behind them looked at);
 //   k_jpeg_huffman   Huffman decoding IN PARALLEL inside one scan: the clean stream is cut into one subsequence per
 //                    thread; every thread decodes its subsequence from a guessed state, then the end states are
 //                    propagated (thread i restarts from thread i-1's end state) until nothing changes — Huffman codes
@@ -49,42 +49,67 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* s_tmp, int tid, int* tot
 // ------------------------------------------------------------------ k_jpeg_unstuff
 // Byte i of the entropy-coded segment is dropped when it is the 00 of an FF 00 pair, a fill FF, or part of an RSTn
 // marker; any other FF xx ends the data.  An RSTn leaves its position in the clean stream in the restart list.
-// A WAVEFRONT owns a contiguous segment of the file and walks it 256 bytes at a time: one coalesced dword per lane, the byte
-// before and the byte after come from the neighbouring lanes, the positions of the kept bytes in the output are ballot
-// prefixes.  First walk: counts (lane-local sums); a scan over the eight wave totals; second walk: the writes.
+// A WAVEFRONT owns a contiguous segment of the file and walks it 1024 bytes at a time: sixteen bytes per lane (one load), the
+// byte before and the byte after from the neighbouring lanes.  Only an FF and the byte behind an FF can be anything but "kept":
+// a lane without either (15 of 16) keeps its sixteen bytes as they are — one 16-byte store at its place in the output (a scan of the
+// kept counts over the lanes) — and the others visit just those bytes.  First walk: counts; a scan over the sixteen wave
+// totals; second walk: the writes.
+typedef uint32_t jpg_u32x4 __attribute__((ext_vector_type(4)));
+typedef jpg_u32x4 __attribute__((aligned(1))) u128_unaligned;     // sixteen bytes at any address (the hardware takes unaligned vector accesses)
 struct UnstuffWave {
     const uint8_t* raw; uint32_t n;
-    // classifies the four bytes at `at` (this lane's dword of the 256-byte chunk): bit j of keep / rst for byte j; returns the
-    // position of the first terminating marker among them (or 0xffffffff)
-    __device__ __forceinline__ uint32_t load(uint32_t base, int lane) const
+    __device__ __forceinline__ uint4 load(uint32_t base, int lane) const
     {
-        const uint32_t at = base + 4u * (uint32_t)lane;
-        return at < n ? *(const u32_unaligned*)(raw + at) : 0u;
+        const uint32_t at = base + 16u * (uint32_t)lane;
+        if (at + 16u <= n) { const jpg_u32x4 v = *(const u128_unaligned*)(raw + at); return make_uint4(v.x, v.y, v.z, v.w); }
+        uint32_t w[4] = {0u, 0u, 0u, 0u};                      // the file's last bytes, one at a time; zeros behind them
+        for (uint32_t j = 0; j < 16u && at + j < n; j++) w[j >> 2] |= (uint32_t)raw[at + j] << (8u * (j & 3u));
+        return make_uint4(w[0], w[1], w[2], w[3]);
     }
-    // w: this lane's dword, wprev / wnext: the same lane's dword of the chunk before / after (their last / first byte are the
-    // neighbours of the chunk's ends: no extra loads on the critical path)
-    __device__ __forceinline__ uint32_t classify(uint32_t base, int lane, uint32_t hi, uint32_t w, uint32_t wprev, uint32_t wnext, int& keep, int& rst) const
+    static __device__ __forceinline__ int byte_of(const uint4& q, int j)
     {
-        const uint32_t at = base + 4u * (uint32_t)lane;
-        int pv = (int)(__shfl_up(w, 1, 64) >> 24), after = (int)(__shfl_down(w, 1, 64) & 255u);
-        const int pv0 = (int)((uint32_t)__shfl((int)wprev, 63, 64) >> 24), af63 = (int)((uint32_t)__shfl((int)wnext, 0, 64) & 255u);
+        const uint32_t w = j < 8 ? (j < 4 ? q.x : q.y) : (j < 12 ? q.z : q.w);
+        return (int)((w >> (8 * (j & 3))) & 255u);
+    }
+    static __device__ __forceinline__ uint32_t ff_bytes(uint32_t w)       // bit 7 of every byte that is 0xFF
+    {
+        return ((w & 0x7f7f7f7fu) + 0x01010101u) & w & 0x80808080u;
+    }
+    // q: this lane's sixteen bytes of the chunk at `base`, qprev / qnext: the same lane's bytes of the chunk before / after (only
+    // their last / first byte matter: the neighbours of the chunk's ends).  keep / rstm: bit j for byte j; bytes at or behind `hi`
+    // are not valid (never kept).  Returns the position of the first terminating marker among the valid bytes (or 0xffffffff).
+    __device__ __forceinline__ uint32_t classify(uint32_t base, int lane, uint32_t hi, const uint4& q, const uint4& qprev, const uint4& qnext,
+                                                 uint32_t& keep, uint32_t& rstm) const
+    {
+        const uint32_t at = base + 16u * (uint32_t)lane;
+        int pv = (int)((uint32_t)__shfl_up((int)q.w, 1, 64) >> 24), after = (int)((uint32_t)__shfl_down((int)q.x, 1, 64) & 255u);
+        const int pv0 = (int)((uint32_t)__shfl((int)qprev.w, 63, 64) >> 24), af63 = (int)((uint32_t)__shfl((int)qnext.x, 0, 64) & 255u);
         if (lane == 0) pv = pv0;
-        if (lane == 63) after = at + 4 < n ? af63 : 0xD9;
+        if (lane == 63) after = af63;
+        const int nvalid = at < hi ? (int)min(16u, hi - at) : 0;
+        keep = nvalid >= 16 ? 0xffffu : (1u << nvalid) - 1u;
+        rstm = 0u;
         uint32_t term = 0xffffffffu;
-        keep = 0; rst = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t p = at + j;
-            const int c = (int)((w >> (8 * j)) & 255u);
-            int nx = j < 3 ? (int)((w >> (8 * j + 8)) & 255u) : after;
-            if (p + 1 >= n) nx = 0xD9;
-            const bool rstn = nx >= 0xD0 && nx <= 0xD7;
-            const bool valid = p < hi;
-            if (valid && c == 0xFF && nx != 0 && nx != 0xFF && !rstn) term = min(term, p);     // EOI or any other marker
-            const bool drop = (c == 0xFF && nx != 0) || (pv == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
-            if (valid && !drop) keep |= 1 << j;
-            if (valid && c == 0xFF && rstn) rst |= 1 << j;
-            pv = c;
+        const uint32_t f0 = ff_bytes(q.x), f1 = ff_bytes(q.y), f2 = ff_bytes(q.z), f3 = ff_bytes(q.w);
+        if ((f0 | f1 | f2 | f3) != 0u || pv == 0xFF) {
+            // bit j: byte j is FF
+            auto nib = [](uint32_t f) { return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u); };
+            const uint32_t ffm = nib(f0) | (nib(f1) << 4) | (nib(f2) << 8) | (nib(f3) << 12);
+            uint32_t todo = (ffm | (ffm << 1) | (pv == 0xFF ? 1u : 0u)) & 0xffffu;     // the FFs and the bytes behind an FF
+            while (todo) {
+                const int j = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                if (j >= nvalid) break;
+                const uint32_t p = at + (uint32_t)j;
+                const int c = byte_of(q, j), pb = j > 0 ? byte_of(q, j - 1) : pv;
+                int nx = j < 15 ? byte_of(q, j + 1) : after;
+                if (p + 1 >= n) nx = 0xD9;
+                const bool rstn = nx >= 0xD0 && nx <= 0xD7;
+                if (c == 0xFF && nx != 0 && nx != 0xFF && !rstn) term = min(term, p);          // EOI or any other marker
+                const bool drop = (c == 0xFF && nx != 0) || (pb == 0xFF && (c == 0 || (c >= 0xD0 && c <= 0xD7)));
+                if (drop) keep &= ~(1u << j);
+                if (c == 0xFF && rstn) rstm |= 1u << j;
+            }
         }
         return term;
     }
@@ -96,9 +121,17 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     for (int d = 1; d < 64; d <<= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
     return v;
 }
+__device__ __forceinline__ int wave_scan_incl(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
 
-#define JPG_UNS_NT 1024                  // sixteen wavefronts per file: four per SIMD hide the shuffles and ballots of a chunk step
-__global__ __launch_bounds__(JPG_UNS_NT) void k_jpeg_unstuff(const uint8_t* blob, JpegImage* imgs, uint8_t* clean, uint32_t* rst)
+#define JPG_UNS_NT 1024                  // sixteen wavefronts per file
+#define JPG_UNS_CHUNK 1024u              // bytes per wavefront step
+__global__ __launch_bounds__(JPG_UNS_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two files per CU: 257 files are one round, not two
+void k_jpeg_unstuff(const uint8_t* blob, JpegImage* imgs, uint8_t* clean, uint32_t* rst)
 {
     constexpr int NW = JPG_UNS_NT / 64;
     __shared__ int s_keep[NW], s_nr[NW];
@@ -108,26 +141,31 @@ __global__ __launch_bounds__(JPG_UNS_NT) void k_jpeg_unstuff(const uint8_t* blob
     UnstuffWave sc;
     sc.raw = blob + im.raw_off; sc.n = im.raw_len;
     const uint32_t n = sc.n;
-    const uint32_t seg = (((n + NW - 1) / NW) + 255u) & ~255u;          // a whole number of 256-byte chunks per wavefront
+    const uint32_t seg = (((n + NW - 1) / NW) + (JPG_UNS_CHUNK - 1u)) & ~(JPG_UNS_CHUNK - 1u);   // a whole number of chunks per wavefront
     const uint32_t lo = min(n, seg * (uint32_t)wave), hi = min(n, lo + seg);
     if (tid == 0) s_end = n;
     __syncthreads();
+    // the byte before the segment rides in lane 63 of the "previous chunk"
+    const uint4 before_seg = make_uint4(0u, 0u, 0u, lo > 0 ? (uint32_t)sc.raw[lo - 1] << 24 : 0u);
     // 1. counts up to the first terminating marker of the segment
     int keep_sum = 0, rst_sum = 0;
     uint32_t my_end = 0xffffffffu;
-    // (the next chunk's dword is in flight while this one is classified; the byte before the segment rides in lane 63 of `wp`)
-    uint32_t wn = sc.load(lo, lane), wp = lo > 0 ? (uint32_t)sc.raw[lo - 1] << 24 : 0u, w = 0;
-    for (uint32_t base = lo; base < hi && my_end == 0xffffffffu; base += 256u) {
-        if (base > lo) wp = w;
-        w = wn; int km, rm;
-        wn = sc.load(base + 256u, lane);
-        const uint32_t t = sc.classify(base, lane, hi, w, wp, wn, km, rm);
-        if (__any(t != 0xffffffffu)) my_end = wave_min_u32(t);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const bool before = base + 4u * (uint32_t)lane + j < my_end;
-            keep_sum += before && ((km >> j) & 1); rst_sum += before && ((rm >> j) & 1);
+    // (the next chunk's bytes are in flight while this one is classified; 64 vector registers: two files per CU)
+    uint4 qn = sc.load(lo, lane), qp = before_seg, q = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t base = lo; base < hi && my_end == 0xffffffffu; base += JPG_UNS_CHUNK) {
+        if (base > lo) qp = q;
+        q = qn;
+        qn = sc.load(base + JPG_UNS_CHUNK, lane);
+        uint32_t km, rm;
+        const uint32_t t = sc.classify(base, lane, hi, q, qp, qn, km, rm);
+        if (__any(t != 0xffffffffu)) {
+            my_end = wave_min_u32(t);
+            const uint32_t at = base + 16u * (uint32_t)lane;    // only what lies in front of the marker counts
+            const uint32_t upto = my_end > at ? min(16u, my_end - at) : 0u;
+            const uint32_t m = upto >= 16u ? 0xffffu : (1u << upto) - 1u;
+            km &= m; rm &= m;
         }
+        keep_sum += __popc(km); rst_sum += __popc(rm);
     }
     if (my_end != 0xffffffffu && lane == 0) atomicMin(&s_end, my_end);
 #pragma unroll
@@ -140,37 +178,39 @@ __global__ __launch_bounds__(JPG_UNS_NT) void k_jpeg_unstuff(const uint8_t* blob
     int kpos = 0, rpos = 0, tot_keep = 0, tot_r = 0;
 #pragma unroll
     for (int v = 0; v < NW; v++) { if (v < wave) { kpos += s_keep[v]; rpos += s_nr[v]; } tot_keep += s_keep[v]; tot_r += s_nr[v]; }
-    // 2. the writes: a kept byte goes to (bytes kept so far) + (kept bytes of lower lanes in the chunk) + (its own earlier bytes)
+    // 2. the writes: a lane's kept bytes go to (bytes kept so far) + (kept bytes of the lower lanes of the chunk)
     uint8_t* out = clean + im.clean_off;
     uint32_t* rl = rst + im.rst_off;
     const uint32_t cap = im.rst_cap;
     const uint32_t stop = min(hi, end);
-    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    wn = sc.load(lo, lane); wp = lo > 0 ? (uint32_t)sc.raw[lo - 1] << 24 : 0u; w = 0;
-    for (uint32_t base = lo; base < stop; base += 256u) {
-        if (base > lo) wp = w;
-        w = wn; int km, rm;
-        wn = sc.load(base + 256u, lane);
-        sc.classify(base, lane, stop, w, wp, wn, km, rm);
-        int before_k = 0, chunk_k = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { const unsigned long long bj = __ballot((km >> j) & 1); before_k += __popcll(bj & below); chunk_k += __popcll(bj); }
-        int o = kpos + before_k;
-        if (__any(rm != 0)) {                                  // restart markers: their clean-stream positions, in stream order
-            int before_r = 0, chunk_r = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { const unsigned long long bj = __ballot((rm >> j) & 1); before_r += __popcll(bj & below); chunk_r += __popcll(bj); }
-            int ro = rpos + before_r, oo = o;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((rm >> j) & 1) { if ((uint32_t)ro < cap) rl[ro] = (uint32_t)oo; ro++; }
-                oo += (km >> j) & 1;
+    qn = sc.load(lo, lane); qp = before_seg;
+    for (uint32_t base = lo; base < stop; base += JPG_UNS_CHUNK) {
+        if (base > lo) qp = q;
+        q = qn;
+        qn = sc.load(base + JPG_UNS_CHUNK, lane);
+        uint32_t km, rm;
+        sc.classify(base, lane, stop, q, qp, qn, km, rm);
+        const int mine = __popc(km);
+        const int incl = wave_scan_incl(mine, lane);
+        const int chunk_k = __shfl(incl, 63, 64);
+        int o = kpos + incl - mine;
+        if (__any(rm != 0u)) {                                 // restart markers: their clean-stream positions, in stream order
+            const int rmine = __popc(rm), rincl = wave_scan_incl(rmine, lane);
+            int ro = rpos + rincl - rmine;
+            uint32_t r = rm;
+            while (r) {
+                const int j = __ffs((int)r) - 1;
+                r &= r - 1u;
+                if ((uint32_t)ro < cap) rl[ro] = (uint32_t)(o + __popc(km & ((1u << j) - 1u)));
+                ro++;
             }
-            rpos += chunk_r;
+            rpos += __shfl(rincl, 63, 64);
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if ((km >> j) & 1) out[o++] = (uint8_t)(w >> (8 * j));
+        if (km == 0xffffu) { jpg_u32x4 v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w; *(u128_unaligned*)(out + o) = v; }   // (15 lanes of 16)
+        else {
+            uint32_t k = km;
+            while (k) { const int j = __ffs((int)k) - 1; k &= k - 1u; out[o++] = (uint8_t)UnstuffWave::byte_of(q, j); }
+        }
         kpos += chunk_k;
     }
     // zero padding after the data: a decoder that runs past the end reads zero bits (as libjpeg supplies them)
