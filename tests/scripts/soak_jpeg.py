@@ -71,7 +71,8 @@ def main():
             fe = FrontEnd(h, w, max_frames=1, max_pairs=1, nfeatures=200, ctx=ctx)
             fe.ingest_jpeg([buf]); fe.detect(0, 1)
             f, o = fe.features(0), O.orb_detect_and_compute(want, O.orb_params(nfeatures=200))
-            if not (np.array_equal(f["desc"], o["desc"]) and np.array_equal(f["xy"], o["xy"])):
+            if f["truncated"]: pass                            # (a capacity of DESIGN.md section 7 was reached — saturated noise: flagged, not claimed exact)
+            elif not (np.array_equal(f["desc"], o["desc"]) and np.array_equal(f["xy"], o["xy"])):
                 print("INGEST MISMATCH", dict(h=h, w=w, kind=str(kind), gray=bool(gray), seed=a.seed, n=n, **kw)); sys.exit(1)
             ningest += 1
         pending.setdefault((h, w), []).append((buf, got))
