@@ -123,6 +123,22 @@ def test_sift_matcher_modes_and_small_frames(oracle, kernel_dk_rule):
     _check_pairs(oracle, fe, feats, pairs, seq["K"], F.MATCH_RATIO, "ratio", ratio=0.8)
 
 
+def test_l2_matcher_on_both_sides_of_4096_rows(oracle, kernel_dk_rule):
+    """k_nn_l2i8 keeps value and 16-row group in one 32-bit key while the train frame has at most 4096 rows (256 groups) and falls
+    back to separate value / group registers above: a pair with 4415 keypoints per frame (contrastThreshold 0.025 at 1280x720)
+    takes the second form in both directions — same pairs, distances, masks, E, R | t as the oracle."""
+    from visual_odometry_amd import frontend as F
+    w, h = 1280, 720
+    seq = _flight(2, w, h)
+    fe = F.FrontEnd(h, w, max_frames=2, max_pairs=1, detector="sift", kp_cap=8192, contrastThreshold=0.025)
+    fe.upload(seq["frames"]); fe.detect(0, 2)
+    feats = [fe.features(s) for s in range(2)]
+    for s in range(2):
+        _same_features(feats[s], oracle.sift_detect_and_compute(seq["frames"][s], contrast_threshold=0.025))
+    assert min(len(f["xy"]) for f in feats) > 4096
+    _check_pairs(oracle, fe, feats, [[0, 1]], seq["K"], F.MATCH_CROSSCHECK, 2)
+
+
 def test_sift_batch_sub_batches_and_reuse(oracle):
     """More frames than a sub-batch holds (scratch reused), slots detected in two calls, then the same context reconfigured."""
     import os
