@@ -70,6 +70,7 @@ for (h, w) in ((40, 52), (97, 131), (33, 200)):
     O.sift_detect_and_compute(rng.integers(0, 256, (h, w), dtype=np.uint8))
 O.sift_detect_and_compute(rng.integers(0, 256, (60, 70, 3), dtype=np.uint8), n_layers=4, sigma=1.4)
 O.sift_detect_and_compute(np.full((50, 50), 9, np.uint8)); O.sift_pyramid_image(f[0][:64, :80].copy(), 1, 2, 3)
+O.sift_detect_and_compute(rng.integers(0, 256, (90, 70), dtype=np.uint8), n_layers=1, sigma=2.05)      # > 100 taps: the kernel once lived in a 64-float stack array
 # JPEG decode: valid files of every layout, then 400 corrupted ones (random byte flips, truncations, spliced headers): any
 # result is acceptable except a memory error
 try:
