@@ -199,3 +199,26 @@ def test_solve_pnp_ransac_and_rodrigues(oracle):
     rc, rv, tv, mask, ninl = oracle.solve_pnp_ransac(Xp, uvp, K)
     assert ok and rc == 0
     assert np.abs(rvec.ravel() - rv).max() < 1e-3 and np.abs(tvec.ravel() - tv).max() < 1e-2
+
+
+def test_imdecode_and_sift(oracle):
+    """cv2.imdecode on JPEG files (libjpeg-turbo as cv2 ships it: the far-out-of-range golden file included) and
+    cv2.SIFT_create().detectAndCompute + BFMatcher(NORM_L2, crossCheck=True): the rows SURVEY 8(f) ranks next."""
+    import os
+    buf = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_gray_q1_saturated_329x267.jpg"), "rb").read()
+    assert np.array_equal(oracle.jpeg_decode(buf), cv2.imdecode(np.frombuffer(buf, np.uint8), cv2.IMREAD_COLOR))
+    img = random_image(5, 240, 320)
+    for q, ss in ((90, cv2.IMWRITE_JPEG_SAMPLING_FACTOR_420 if hasattr(cv2, "IMWRITE_JPEG_SAMPLING_FACTOR_420") else None), (35, None)):
+        params = [cv2.IMWRITE_JPEG_QUALITY, q] + ([cv2.IMWRITE_JPEG_SAMPLING_FACTOR, ss] if ss is not None else [])
+        ok, enc = cv2.imencode(".jpg", np.stack([img, np.roll(img, 3, 1), np.roll(img, 5, 0)], -1), params)
+        assert ok and np.array_equal(oracle.jpeg_decode(enc.tobytes()), cv2.imdecode(enc, cv2.IMREAD_COLOR))
+    kps, desc = cv2.SIFT_create().detectAndCompute(img, None)
+    want = oracle.sift_detect_and_compute(img)
+    assert len(kps) == want["n_found"]
+    assert np.array_equal(np.array([k.pt for k in kps], np.float32), want["xy"]) and np.array_equal(desc, want["desc"])
+    assert np.array_equal(np.array([k.octave for k in kps]), want["octave"]) and np.array_equal(np.array([k.angle for k in kps], np.float32), want["angle"])
+    img2 = np.roll(img, 4, 1)
+    d2 = cv2.SIFT_create().detectAndCompute(img2, None)[1]
+    ms = cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match(desc, d2)
+    q, t, d = oracle.match_l2(desc, d2, 2)
+    assert [m.queryIdx for m in ms] == q.tolist() and [m.trainIdx for m in ms] == t.tolist() and np.array_equal(np.array([m.distance for m in ms], np.float32), d)
