@@ -488,15 +488,6 @@ __global__ __launch_bounds__(JPG_NT) void k_jpeg_huffman(JpegImage* imgs, const 
     const uint32_t* rst = rst_all + im.rst_off;
     int16_t* coef = coef_all + (size_t)im.coef_blk * 64;
     const uint32_t nbits = im.clean_len * 8u;
-    // The file's coefficient blocks start out cleared (the writing pass stores only the coefficients the stream names; blocks
-    // behind an early end of the data stay zero).  Cleared here by the file's own workgroup — coalesced 16-byte stores that drain
-    // while the counting passes wait for their table look-ups; the barriers in front of the writing pass order them before its
-    // stores — instead of by a fill of the whole batch's buffer in front of the kernels (0.15 ms per 257 files of 1280 x 720).
-    {
-        uint4* const z = (uint4*)coef;
-        const uint32_t nz = (uint32_t)total_blocks * 8u;      // 128 bytes per block
-        for (uint32_t i = tid; i < nz; i += JPG_NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
     // one subsequence per thread, a whole number of bytes, at least 32 bytes
     uint32_t sub = (im.clean_len + JPG_NT - 1) / JPG_NT; sub = sub < JPG_MIN_SUB ? JPG_MIN_SUB : sub;
     const uint32_t b0 = min(nbits, sub * 8u * (uint32_t)tid), b1 = min(nbits, b0 + sub * 8u);
@@ -813,9 +804,10 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpegImage* imgs, const
 
 // ------------------------------------------------------------------ launchers
 void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
-                        int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h, bool gray, bool packed_tables)
+                        int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h, bool gray, bool packed_tables, hipEvent_t coef_cleared)
 {
     hipLaunchKernelGGL(k_jpeg_unstuff, dim3(F), dim3(JPG_UNS_NT), 0, s, blob, imgs, clean, rst);
+    if (coef_cleared) (void)hipStreamWaitEvent(s, coef_cleared, 0);
     if (packed_tables) hipLaunchKernelGGL(k_jpeg_huffman<4>, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
     else hipLaunchKernelGGL(k_jpeg_huffman<8>, dim3(F), dim3(JPG_NT), 0, s, imgs, tabs, clean, rst, coef);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 255) / 256, F), dim3(256), 0, s, imgs, tabs, coef, planes);

@@ -199,7 +199,8 @@ void launch_match_nn_l2i8(hipStream_t s, const uint8_t* desc_x, const int* norms
 #include "jpeg_host.h"
 void launch_jpeg_decode(hipStream_t s, const uint8_t* blob, JpegImage* imgs, const JpegTables* tabs, int F, uint8_t* clean, uint32_t* rst,
                         int16_t* coef, uint8_t* planes, uint8_t* out, int max_blocks, int max_w, int max_h, bool gray = false,
-                        bool packed_tables = false /* no file of the batch names more than four Huffman tables */);
+                        bool packed_tables = false /* no file of the batch names more than four Huffman tables */,
+                        hipEvent_t coef_cleared = nullptr /* the coefficient buffer is cleared on another stream: k_jpeg_huffman waits for this */);
 
 void launch_pnp_ransac(hipStream_t s, const double* obj, const double* img, const int* offsets, int B, const double* Kd,
                        int iterations, double reproj_err, double confidence, uint64_t seed, const uint32_t* rng_tab, int rng_n,
