@@ -224,3 +224,35 @@ def test_far_out_of_range_samples_saturate(oracle, ctx):
     buf = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_gray_q1_saturated_329x267.jpg"), "rb").read()
     got = ingest.imdecode(buf, ctx)
     assert np.array_equal(got, oracle.jpeg_decode(buf)) and np.array_equal(got, pil_bgr(buf))
+
+
+def test_two_contexts_ingest_concurrently(oracle):
+    """Two contexts on two host threads, each decoding its own files again and again while the other one runs (the coefficient
+    buffer of a context is cleared on a stream of its own, ordered by events behind the previous batch and in front of the entropy
+    decoder): every repetition gives the features of the first, single-threaded pass."""
+    import threading
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    h, w, n = 240, 320, 6
+    sets = [[encode(scene(700 + 10 * c + k, h, w, "boxes"), quality=85, subsampling=2) for k in range(n)] for c in range(2)]
+    fes = [FrontEnd(h, w, max_frames=n, max_pairs=1, nfeatures=300, ctx=_lib.Context(0)) for _ in range(2)]
+    ref = []
+    for c in range(2):
+        fes[c].ingest_jpeg(sets[c]); fes[c].detect(0, n)
+        ref.append([fes[c].features(k) for k in range(n)])
+        o = oracle.orb_detect_and_compute(oracle.jpeg_decode(sets[c][0]), oracle.orb_params(nfeatures=300))
+        assert np.array_equal(ref[c][0]["desc"], o["desc"]) and len(o["xy"]) > 20
+    bad = []
+
+    def work(c):
+        for _ in range(12):
+            fes[c].ingest_jpeg(sets[c]); fes[c].detect(0, n)
+            for k in range(n):
+                f = fes[c].features(k)
+                if not (np.array_equal(f["desc"], ref[c][k]["desc"]) and np.array_equal(f["xy"], ref[c][k]["xy"])): bad.append((c, k))
+
+    th = [threading.Thread(target=work, args=(c,)) for c in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for f in fes: f.ctx.close()
+    assert not bad, bad[:4]
