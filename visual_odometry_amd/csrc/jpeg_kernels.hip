@@ -128,7 +128,9 @@ __device__ __forceinline__ int wave_scan_incl(int v, int lane)
     return v;
 }
 
-#define JPG_UNS_NT 1024                  // sixteen wavefronts per file
+#ifndef JPG_UNS_NT
+#define JPG_UNS_NT 1024                  // sixteen wavefronts per file (512 / 256: no difference in the three-context pipeline)
+#endif
 #define JPG_UNS_CHUNK 1024u              // bytes per wavefront step
 __global__ __launch_bounds__(JPG_UNS_NT) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two files per CU: 257 files are one round, not two
 void k_jpeg_unstuff(const uint8_t* blob, JpegImage* imgs, uint8_t* clean, uint32_t* rst)
