@@ -788,7 +788,8 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
     __shared__ float s_tab[64];
     __shared__ int s_rstart[SD_ROWS + 1];                       // row-major number of a row's first valid sample (chunk-relative rows)
     __shared__ int s_rjlo[SD_ROWS];                             // its column
-    __shared__ unsigned long long s_mask[SD_ACC];               // lanes (samples of the round) that feed an accumulator
+    __shared__ unsigned long long s_mask[SD_D * SD_D * SD_N];   // [cell][o0]: lanes (samples of the round) whose FIRST orientation bin in that cell is o0; the
+                                                                // accumulator (cell, bin) is fed by the lanes of [cell][bin] and of [cell][bin - 1] (their second bin)
     __shared__ int s_base[SD_ACC];                              // start of its queue
     __shared__ __attribute__((aligned(16))) float s_q[SD_QCAP]; // the addends of the round, accumulator by accumulator, in sample order
     __shared__ float s_acc[SD_ACC];
@@ -799,7 +800,12 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
     s_tab[lane] = E.tab[lane];
     // owner role of this lane: accumulators lane, lane + 64 and (lane < 16) lane + 128
     const bool own3 = lane < SD_ACC - 128;
-    for (int k = lane; k < SD_ACC; k += 64) s_mask[k] = 0ull;
+    // accumulator a = cell * 9 + bin is fed by the samples of mask [cell][bin] (bin < 8) and of mask [cell][bin - 1] (bin > 0)
+    auto mask_a = [](int a) { const int cell = a / 9, bin = a - cell * 9; return bin < SD_N ? cell * SD_N + bin : -1; };
+    auto mask_b = [](int a) { const int cell = a / 9, bin = a - cell * 9; return bin > 0 ? cell * SD_N + bin - 1 : -1; };
+    const int pa0 = mask_a(lane), pb0 = mask_b(lane), pa1 = mask_a(lane + 64), pb1 = mask_b(lane + 64);
+    const int pa2 = own3 ? mask_a(lane + 128) : -1, pb2 = own3 ? mask_b(lane + 128) : -1;
+    for (int k = lane; k < SD_D * SD_D * SD_N; k += 64) s_mask[k] = 0ull;
     if (lane < 8) s_q[64 * 8 + lane] = 0.f;
     const int d = SD_D, n = SD_N;
     for (int id = blockIdx.x; id < nkp; id += gridDim.x) {
@@ -909,14 +915,14 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
                             if (a >= 0 && a < SD_D && b >= 0 && b < SD_D) {
                                 const int ac = (a * SD_D + b) * 9 + o0;
                                 acc[dr * 2 + dc] = ac;
-                                atomicOr(&s_mask[ac], bit);
-                                atomicOr(&s_mask[ac + 1], bit);
+                                atomicOr(&s_mask[(a * SD_D + b) * SD_N + o0], bit);      // ONE mark per cell: the second bin's accumulator reads it too
                             }
                         }
                 }
                 SD_SYNC();
                 // (2) counts, queue starts
-                const unsigned long long m0 = s_mask[lane], m1 = s_mask[lane + 64], m2 = own3 ? s_mask[lane + 128] : 0ull;
+                auto rd = [&](int i) { return i >= 0 ? s_mask[i] : 0ull; };
+                const unsigned long long m0 = rd(pa0) | rd(pb0), m1 = rd(pa1) | rd(pb1), m2 = rd(pa2) | rd(pb2);
                 const int c0n = __popcll(m0), c1n = __popcll(m1), c2n = __popcll(m2);
                 const int inc = sd_wave_scan(c0n + c1n + c2n);
                 const int b0 = inc - (c0n + c1n + c2n), b1 = b0 + c0n, b2 = b1 + c1n;
@@ -927,15 +933,16 @@ __global__ __launch_bounds__(64) void k_sb_descriptor(SiftGeom P, const float* g
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (acc[k] >= 0) {                           // position = number of lower lanes that feed the same accumulator (v_mbcnt)
-                        const unsigned long long ma = s_mask[acc[k]], mb = s_mask[acc[k] + 1];
+                        const int cell = acc[k] / 9, ob = acc[k] - cell * 9, pi = cell * SD_N + ob;      // ob = o0 in 0 .. 7
+                        const unsigned long long pm = s_mask[pi];
+                        const unsigned long long ma = pm | (ob > 0 ? s_mask[pi - 1] : 0ull), mb = pm | (ob < SD_N - 1 ? s_mask[pi + 1] : 0ull);
                         s_q[s_base[acc[k]] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] = val[2 * k];
                         s_q[s_base[acc[k] + 1] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = val[2 * k + 1];
                     }
                 SD_SYNC();
                 // (4) the owners add their queues, front to back (four reads in flight; the padding / the next queue's entries
                 // read past the end are discarded by the selects)
-                s_mask[lane] = 0ull; s_mask[lane + 64] = 0ull;
-                if (own3) s_mask[lane + 128] = 0ull;
+                s_mask[lane] = 0ull; s_mask[lane + 64] = 0ull;    // (16 cells x 8 bins = 128 masks)
                 for (int k = 0; k < c0n; k += 4) {
                     const float q0 = s_q[b0 + k], q1 = s_q[b0 + k + 1], q2 = s_q[b0 + k + 2], q3 = s_q[b0 + k + 3];
                     e0 += q0; e0 += k + 1 < c0n ? q1 : 0.f; e0 += k + 2 < c0n ? q2 : 0.f; e0 += k + 3 < c0n ? q3 : 0.f;
