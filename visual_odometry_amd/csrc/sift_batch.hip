@@ -753,9 +753,10 @@ __global__ __launch_bounds__(256) void k_sb_emit(const SiftKp* sorted, int kp_ca
 //  (1) the valid samples are evaluated 64 at a time, one per lane (gradient, fastAtan2, exp32f weight, trilinear split -> 8
 //      values for 8 ACCUMULATORS: bins o0 and o0 + 1 of the 2 x 2 cells of the footprint; 144 accumulators = 16 inner cells x
 //      bins 0..8, bin 8 being the wrap bin that calcSIFTDescriptor folds into bin 0 at the end); every sample sets its lane's
-//      bit in the 64-bit masks of the accumulators it feeds (LDS atomic OR);
+//      bit in ONE 64-bit mask per cell, [cell][o0] (LDS atomic OR): accumulator (cell, bin) is fed by the lanes of [cell][bin]
+//      and by those of [cell][bin - 1], so its mask is the OR of two — four atomics per sample instead of eight;
 //  (2) the accumulators are OWNED by lanes (accumulator & 63: the nine bins of a cell sit in nine lanes): an owner counts the
-//      bits of its masks, a wave scan of the counts gives every accumulator a contiguous queue in LDS;
+//      bits of its (two OR-ed) masks, a wave scan of the counts gives every accumulator a contiguous queue in LDS;
 //  (3) every sample writes its values to the queues: position = queue base + number of lower lanes that feed the same
 //      accumulator (popcount of the mask below its own bit) — i.e. the queue holds the accumulator's addends IN SAMPLE ORDER;
 //  (4) the owners add their queues front to back: one LDS read and one float add per addend, nothing else.
