@@ -15,8 +15,9 @@ Workloads:
   flight --frames N                  BASELINE config 5's shape: an N-frame sequence cut with one halo frame per rank, poses
                                      chained, ATE against the ground truth and against the CPU oracle's chain.
 
-N > 1: one process per GPU (torch.distributed.run may be the launcher: it only sets RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_PORT).  Nothing here needs PyTorch by default: the RCCL id travels through a file (rendezvous.FileRendezvous), the
+N > 1: one process per GPU.  `python3 bench.py --gpus N` alone starts its own N rank processes (launch_ranks: the parent
+never touches the GPU); torch.distributed.run may be the launcher instead: it only sets RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_PORT.  Nothing here needs PyTorch by default: the RCCL id travels through a file (rendezvous.FileRendezvous), the
 barrier, the max-over-ranks of the timing and the record gather go through the library's own communicator
 (vo_comm_allgather_f64 / vo_pairs_gather).  --rendezvous torch keeps the torch.distributed path (gloo: ranks sharing one GPU).
 
@@ -169,6 +170,53 @@ def cpu_baseline(detector, frames, K, nfeatures, nlevels, match_mode, ratio, wid
                       f"{one * n1:.1f} s; cv2 is not importable on this box, so this is NOT a cv2 timing"}
 
 
+def launch_ranks(n, argv):
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and a per-launch rendezvous nonce in the
+    environment), all of them fresh interpreters: the launcher itself never initialises HIP, and nothing is exec'ed from a
+    process that has.  Rank 0's stdout is this process's stdout (the one JSON line); the other ranks' stdout goes to stderr.
+    Returns 0 when every rank did; when one fails the others are ended (by their exact pids) and its code is returned."""
+    import secrets
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:                          # a free port: torch-style launch variables, for whoever reads them
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    key = f"bench_{os.getpid()}_{secrets.token_hex(6)}"
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VO_RENDEZVOUS_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    print(f"bench.py: rank {r} exited with {code}; ending the other ranks", file=sys.stderr, flush=True)
+                    for q in live:
+                        procs[q].send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        deadline = time.time() + 10
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    return rc
+
+
 class TorchCollectives:
     def __init__(self, dist, torch, on_gpu):
         self.dist, self.torch, self.on_gpu = dist, torch, on_gpu
@@ -240,12 +288,14 @@ def main():
                     help="--rendezvous torch only; gloo: rehearse N ranks on a box with fewer GPUs (all ranks share GPU 0, records gathered by torch)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python3 bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU (and
+        # never will): it starts N fresh rank processes of this script and relays rank 0's JSON line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     sift = args.detector == "sift"
     C = args.pairs_per_step or (191 if sift else 256)
@@ -283,6 +333,12 @@ def main():
     from visual_odometry_amd.frontend import (FrontEnd, MATCH_CROSSCHECK, MATCH_CROSSCHECK_LEGACY, MATCH_RATIO, chain_poses)
     from visual_odometry_amd.pipeline import ChunkPipeline
     from visual_odometry_amd.sharding import RECORD_WIDTH, pack_records
+
+    stub = os.environ.get("VO_BENCH_STUB")                  # tests only (tests/test_bench_launcher.py): a module standing in for
+    if stub:                                                # the HIP front end on a box without a GPU; the line is labelled, never a measurement
+        import importlib
+        sb = importlib.import_module(stub)
+        FrontEnd, init_library_comm, LibraryCollectives = sb.FrontEnd, sb.init_library_comm, sb.LibraryCollectives
 
     seq = synth.sequence(D, args.width, args.height, cache_dir="/tmp", trajectory="loop", workers=1)   # the cache rank 0 wrote
     K = seq["K"]
@@ -327,7 +383,7 @@ def main():
     fe = fes[0]
     opts = fe.make_opts(match_mode=match_mode, ratio=args.ratio, want_points=True)
 
-    # The trajectory gather: 128 B per pair.  One RCCL communicator per context, its id from rank 0.
+    # The trajectory gather: 128 B per pair.  ONE RCCL communicator per process (its id from rank 0), shared by the contexts.
     gather, coll = None, NoCollectives()
     if use_dist and rdv is not None:
         init_library_comm(fes, rdv, rank, world)
@@ -335,12 +391,13 @@ def main():
     elif use_dist:
         coll = TorchCollectives(dist, torch, on_gpu)
         if on_gpu:
-            for f in fes:
-                ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    ident.copy_(torch.frombuffer(bytearray(f.ctx.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(ident, 0)
-                f.ctx.comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
+            ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                ident.copy_(torch.frombuffer(bytearray(fe.ctx.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(ident, 0)
+            fe.ctx.comm_init(bytes(ident.cpu().numpy().tobytes()), rank, world)
+            for f in fes[1:]:
+                f.ctx.comm_share(fe.ctx)
             gather = "library"
         else:
             out_t = torch.empty((world * C, RECORD_WIDTH), dtype=torch.float64)
@@ -530,7 +587,7 @@ def main():
             "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f32+f64",
-            "data": "synthetic",
+            "data": "synthetic" if not stub else f"STUB front end {stub}: launcher self-test, NOT a measurement",
             "value_streamed_from_host": round(streamed, 2) if streamed else None,
             "config": {"workload": f"seeded synthetic {args.width}x{args.height} drone flight ({D} distinct rendered views, closed loop), " +
                                    (f"cv2.SIFT_create() defaults (every keypoint kept, ~{int(res['n_kp1'].mean())} per frame) + BFMatcher(NORM_L2, crossCheck) = the "
@@ -547,8 +604,9 @@ def main():
                        "ransac": "5-point, conf 0.99, 1 px, seed 2^64-1, <=1000 iters",
                        "ransac_iters": {"mean": round(float(iters_all.mean()), 1), "max": int(iters_all.max()),
                                         "histogram": {f"{hist_edges[i]}-{hist_edges[i + 1] - 1}": int(hist[i]) for i in range(len(hist))}},
+                       "n_ranks_in_communicator": fe.ctx.comm_info()[0] if gather == "library" else None,
                        "parallelism": (f"pair-sharded x{world}, one all-gather of 128 B/pair per step via " +
-                                       ("vo_pairs_gather (device pack + ncclAllGather on the ctx stream); rendezvous: " +
+                                       ("vo_pairs_gather (device pack + ncclAllGather on the process's one communicator stream); rendezvous: " +
                                         ("a file, no PyTorch in the process" if rdv is not None else "torch.distributed")
                                         if gather == "library" else "torch.distributed.all_gather_into_tensor (gloo)")) if use_dist else "single GPU",
                        "value_is": "HBM-resident inputs (the driver contract); value_streamed_from_host re-runs the same loop with "

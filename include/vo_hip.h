@@ -221,8 +221,15 @@ int vo_pair_matches(vo_ctx* ctx, int pair, int32_t* qidx, int32_t* tidx, float* 
 int vo_comm_unique_id(uint8_t id[VO_COMM_ID_BYTES]);
 int vo_comm_init(vo_ctx* ctx, const uint8_t id[VO_COMM_ID_BYTES], int rank, int world);
 int vo_comm_destroy(vo_ctx* ctx);
+/* One communicator per PROCESS: further contexts of the same GPU (the chunk pipeline alternates over several) join the
+ * one `owner` created instead of creating their own.  All collectives of the process are issued on the communicator's
+ * own stream in host submit order (the same order on every rank) and tied to the calling context's stream with events,
+ * so two collectives are never in flight at once.  vo_comm_destroy drops a context's reference; the last one destroys
+ * the communicator.  vo_comm_info: ncclCommCount and this process's rank (1 and 0 without a communicator). */
+int vo_comm_share(vo_ctx* ctx, vo_ctx* owner);
+int vo_comm_info(vo_ctx* ctx, int32_t* n_ranks, int32_t* rank);
 /* Packs the records of the first B pairs of the most recent vo_pairs_run[_async] on the device and all-gathers them
- * over RCCL on the ctx stream (every rank must pass the same B; pad short blocks).  gathered (host, page-locked for
+ * over RCCL, ordered after the ctx stream's work (every rank must pass the same B; pad short blocks).  gathered (host, page-locked for
  * the asynchronous form, world * B * VO_RECORD_DOUBLES doubles, rank-major) is valid after the call (wait != 0) or
  * after the next vo_sync(ctx).  Without vo_comm_init (single process) it degenerates to the local records. */
 int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait);

@@ -81,6 +81,8 @@ _SIGS = {
     "vo_comm_unique_id": (C.c_int, [_P]),
     "vo_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vo_comm_destroy": (C.c_int, [_P]),
+    "vo_comm_share": (C.c_int, [_P, _P]),
+    "vo_comm_info": (C.c_int, [_P, _P, _P]),
     "vo_pairs_gather": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "vo_comm_allgather_f64": (C.c_int, [_P, _P, C.c_int, _P]),
     "vo_pair_matches": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, _P]),
@@ -165,7 +167,7 @@ class Context:
         the Hamming nearest neighbours (same results).  Choose before detecting."""
         self.check(self.lib.vo_set_matcher_kernel(self.handle, {"mfma": 0, "popcount": 1, "mfma_fp4": 2}[kind]))
 
-    # ---- multi-GPU: the trajectory gather over RCCL (one communicator per context)
+    # ---- multi-GPU: the trajectory gather over RCCL (one communicator per process, shared by its contexts)
     def comm_unique_id(self) -> bytes:
         buf = (C.c_uint8 * VO_COMM_ID_BYTES)()
         if self.lib.vo_comm_unique_id(buf) != 0:
@@ -189,6 +191,16 @@ class Context:
 
     def comm_destroy(self):
         self.check(self.lib.vo_comm_destroy(self.handle))
+
+    def comm_share(self, owner):
+        """Join the communicator `owner` (another Context of this process and GPU) created: one communicator per process."""
+        self.check(self.lib.vo_comm_share(self.handle, owner.handle))
+
+    def comm_info(self):
+        """(ranks in the communicator as ncclCommCount reports them, this process's rank); (1, 0) without a communicator."""
+        n, r = C.c_int32(0), C.c_int32(0)
+        self.check(self.lib.vo_comm_info(self.handle, C.addressof(n), C.addressof(r)))
+        return n.value, r.value
 
     def allgather(self, values, world):
         """Synchronous all-gather of a few float64 per rank over the context's communicator -> [world, n]."""

@@ -3,7 +3,8 @@
 // Frame pairs are independent, so ranks (one process per GPU) share nothing while they detect, match and solve; at the
 // end of a batch every rank contributes its per-pair records ([R|t] + counts, 16 float64 = 128 B per pair) to ONE
 // ncclAllGather over RCCL / xGMI.  The records are packed on the device straight from the batch's result array
-// (vo_pair_result, in HBM) and gathered on the context's own stream — no host bounce, no torch tensors.  RCCL is
+// (vo_pair_result, in HBM) and gathered on the process's ONE communicator stream, ordered against the context's own stream
+// with events — no host bounce, no torch tensors.  RCCL is
 // bound at run time (dlopen: the copy already loaded by the process if there is one), so libvo_hip.so has no link
 // dependency on it and single-GPU users never load it.
 #include "vo_internal.h"
@@ -19,6 +20,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 
 static RcclApi g_rccl;
@@ -38,7 +40,8 @@ const char* rccl_load(void)
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
     a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) return "librccl.so.1 lacks an expected symbol";
+    a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
+    if (!a.GetUniqueId || !a.CommCount || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) return "librccl.so.1 lacks an expected symbol";
     g_rccl = a;
     return nullptr;
 }
@@ -71,6 +74,12 @@ const char* rccl_comm_init(void** comm, const uint8_t* id128, int rank, int worl
 void rccl_comm_destroy(void* comm)
 {
     if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)comm);
+}
+
+const char* rccl_comm_count(void* comm, int* n)
+{
+    ncclResult_t r = g_rccl.CommCount((ncclComm_t)comm, n);
+    return r == ncclSuccess ? nullptr : g_rccl.GetErrorString(r);
 }
 
 const char* rccl_all_gather_f64(void* comm, const double* send, double* recv, size_t count, hipStream_t s)

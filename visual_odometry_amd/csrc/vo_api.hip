@@ -27,6 +27,15 @@ struct SiftState {
     int *rank = nullptr, *counts = nullptr, *fin_count = nullptr, *fin_flags = nullptr;
 };
 
+// The process's RCCL communicator and the stream all of its collectives are issued on.  Every context of the GPU holds a
+// reference; collectives of different contexts therefore run one after the other, in the order the host submitted them
+// (the same on every rank), never two at once.
+struct CommShared {
+    void* comm = nullptr;
+    int rank = 0, world = 1, refs = 0;
+    hipStream_t stream = nullptr;
+};
+
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;         // non-blocking: no implicit ordering with the NULL stream (PyTorch / RCCL use it)
@@ -86,7 +95,8 @@ struct vo_ctx {
     bool ev_det_set = false;
     int descx_fp4 = 0;                    // operand image the resident frames' desc_x currently holds (written at detection)
     int matcher_kernel = 2;               // 2: block-scaled FP4 MFMA (default), 0: int8 MFMA on +127/-127 bytes, 1: XOR + popcount
-    void* comm = nullptr; int comm_rank = 0, comm_world = 1;          // RCCL communicator of the trajectory gather
+    CommShared* cs = nullptr;             // RCCL communicator of the trajectory gather: ONE per process, shared by its contexts (vo_comm_share)
+    hipEvent_t ev_gather[2] = {nullptr, nullptr};                     // ctx stream -> communicator stream -> ctx stream
     double *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0;
     int kp_order = 1;                     // 1 (default): cv2's retainBest order — keypoint / match indices as cv2 numbers them; 0: canonical (octave, y, x)
     Cv2Buf cv2{};
@@ -311,6 +321,7 @@ static void free_config(vo_ctx* c)
 }
 
 static void sift_free(SiftState& S);
+static void comm_release(vo_ctx* ctx);
 static int sift_frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot);
 static int sift_frames_detect_enqueue(vo_ctx* ctx, int first_slot, int F);
 
@@ -378,7 +389,8 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     if (ctx->stream_jpg) { (void)hipStreamSynchronize(ctx->stream_jpg); (void)hipStreamDestroy(ctx->stream_jpg); }
     for (int i = 0; i < 2; i++) if (ctx->ev_jpg[i]) (void)hipEventDestroy(ctx->ev_jpg[i]);
     for (int i = 0; i < 2; i++) if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
-    if (ctx->comm) rccl_comm_destroy(ctx->comm);
+    comm_release(ctx);
+    for (int i = 0; i < 2; i++) if (ctx->ev_gather[i]) (void)hipEventDestroy(ctx->ev_gather[i]);
     if (ctx->rec_send) (void)hipFree(ctx->rec_send);
     if (ctx->rec_recv) (void)hipFree(ctx->rec_recv);
     if (ctx->rng_host) (void)hipHostFree(ctx->rng_host);
@@ -1056,15 +1068,46 @@ extern "C" int vo_comm_unique_id(uint8_t* id)
     return rccl_unique_id(id) ? VO_ERR_HIP : VO_OK;
 }
 
+static void comm_release(vo_ctx* ctx)
+{
+    CommShared* cs = ctx->cs;
+    ctx->cs = nullptr;
+    if (!cs || --cs->refs > 0) return;
+    if (cs->stream) (void)hipStreamSynchronize(cs->stream);
+    if (cs->comm) rccl_comm_destroy(cs->comm);
+    if (cs->stream) (void)hipStreamDestroy(cs->stream);
+    delete cs;
+}
+
 extern "C" int vo_comm_init(vo_ctx* ctx, const uint8_t* id, int rank, int world)
 {
     if (!ctx) return VO_ERR_INVALID;
     if (!id || world < 1 || rank < 0 || rank >= world) FAIL(VO_ERR_INVALID, "bad communicator arguments");
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->comm) { rccl_comm_destroy(ctx->comm); ctx->comm = nullptr; }
-    const char* e = rccl_comm_init(&ctx->comm, id, rank, world);
-    if (e) FAIL(VO_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, e);
-    ctx->comm_rank = rank; ctx->comm_world = world;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    comm_release(ctx);
+    CommShared* cs = new CommShared();
+    if (hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking) != hipSuccess) { delete cs; FAIL(VO_ERR_HIP, "no stream for the communicator"); }
+    const char* e = rccl_comm_init(&cs->comm, id, rank, world);
+    if (e) { (void)hipStreamDestroy(cs->stream); delete cs; FAIL(VO_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, e); }
+    cs->rank = rank; cs->world = world; cs->refs = 1;
+    ctx->cs = cs;
+    return VO_OK;
+}
+
+// ctx joins the communicator `owner` created (same process, same device): one communicator per process however many
+// contexts alternate over the chunks.
+extern "C" int vo_comm_share(vo_ctx* ctx, vo_ctx* owner)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!owner || !owner->cs) FAIL(VO_ERR_INVALID, "the other context has no communicator (vo_comm_init)");
+    if (owner->device != ctx->device) FAIL(VO_ERR_INVALID, "contexts of different devices cannot share a communicator");
+    if (ctx->cs == owner->cs) return VO_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    comm_release(ctx);
+    ctx->cs = owner->cs;
+    ctx->cs->refs++;
     return VO_OK;
 }
 
@@ -1073,8 +1116,40 @@ extern "C" int vo_comm_destroy(vo_ctx* ctx)
     if (!ctx) return VO_ERR_INVALID;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->comm) rccl_comm_destroy(ctx->comm);
-    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_world = 1;
+    comm_release(ctx);
+    return VO_OK;
+}
+
+// ranks the communicator really holds (ncclCommCount) and this process's rank in it; 1 / 0 without a communicator
+extern "C" int vo_comm_info(vo_ctx* ctx, int32_t* n_ranks, int32_t* rank)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    int n = 1, r = 0;
+    if (ctx->cs) {
+        const char* e = rccl_comm_count(ctx->cs->comm, &n);
+        if (e) FAIL(VO_ERR_HIP, "ncclCommCount failed: %s", e);
+        r = ctx->cs->rank;
+    }
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
+    return VO_OK;
+}
+
+// A collective of this context: whatever the ctx stream holds so far happens before it, it runs on the communicator's
+// stream behind every collective submitted earlier by any context of the process, and the ctx stream continues after it.
+static int comm_bracket_begin(vo_ctx* ctx)
+{
+    for (int i = 0; i < 2; i++)
+        if (!ctx->ev_gather[i]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gather[i], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->ev_gather[0], ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->cs->stream, ctx->ev_gather[0], 0));
+    return VO_OK;
+}
+
+static int comm_bracket_end(vo_ctx* ctx)
+{
+    HIPCHK(hipEventRecord(ctx->ev_gather[1], ctx->cs->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_gather[1], 0));
     return VO_OK;
 }
 
@@ -1085,7 +1160,7 @@ extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
     if (B < 0 || B > batch_max_pairs(ctx) || !gathered) FAIL(VO_ERR_INVALID, "bad gather arguments");
     if (B == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    const int world = ctx->comm ? ctx->comm_world : 1;
+    const int world = ctx->cs ? ctx->cs->world : 1;
     const size_t n = (size_t)B * VO_RECORD_DOUBLES;
     if (n * world > ctx->rec_cap) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1101,9 +1176,11 @@ extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
     launch_pack_records(s, ctx->pb.res, B, ctx->last_pairs, ctx->rec_send);
     HIPCHK(hipGetLastError());
     const double* src = ctx->rec_send;
-    if (ctx->comm) {
-        const char* e = rccl_all_gather_f64(ctx->comm, ctx->rec_send, ctx->rec_recv, n, s);
+    if (ctx->cs) {
+        int rc = comm_bracket_begin(ctx); if (rc) return rc;
+        const char* e = rccl_all_gather_f64(ctx->cs->comm, ctx->rec_send, ctx->rec_recv, n, ctx->cs->stream);
         if (e) FAIL(VO_ERR_HIP, "ncclAllGather failed: %s", e);
+        rc = comm_bracket_end(ctx); if (rc) return rc;
         src = ctx->rec_recv;
     }
     HIPCHK(hipMemcpyAsync(gathered, src, n * world * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1118,13 +1195,15 @@ extern "C" int vo_comm_allgather_f64(vo_ctx* ctx, const double* send, int n, dou
     if (!ctx) return VO_ERR_INVALID;
     if (!send || !recv || n < 1 || n > 4096) FAIL(VO_ERR_INVALID, "bad all-gather arguments");
     HIPCHK(hipSetDevice(ctx->device));
-    const int world = ctx->comm ? ctx->comm_world : 1;
-    if (!ctx->comm) { memcpy(recv, send, (size_t)n * sizeof(double)); return VO_OK; }
+    const int world = ctx->cs ? ctx->cs->world : 1;
+    if (!ctx->cs) { memcpy(recv, send, (size_t)n * sizeof(double)); return VO_OK; }
     int rc = ensure_raw_d(ctx, (size_t)n * (world + 1)); if (rc) return rc;
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemcpyAsync(ctx->raw_d, send, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-    const char* e = rccl_all_gather_f64(ctx->comm, ctx->raw_d, ctx->raw_d + n, (size_t)n, s);
+    rc = comm_bracket_begin(ctx); if (rc) return rc;
+    const char* e = rccl_all_gather_f64(ctx->cs->comm, ctx->raw_d, ctx->raw_d + n, (size_t)n, ctx->cs->stream);
     if (e) FAIL(VO_ERR_HIP, "ncclAllGather failed: %s", e);
+    rc = comm_bracket_end(ctx); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(recv, ctx->raw_d + n, (size_t)n * world * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return VO_OK;

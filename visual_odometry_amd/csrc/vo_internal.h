@@ -134,6 +134,7 @@ const char* rccl_load(void);
 const char* rccl_unique_id(uint8_t* id128);
 const char* rccl_comm_init(void** comm, const uint8_t* id128, int rank, int world);
 void rccl_comm_destroy(void* comm);
+const char* rccl_comm_count(void* comm, int* n);
 const char* rccl_all_gather_f64(void* comm, const double* send, double* recv, size_t count, hipStream_t s);
 void launch_pack_records(hipStream_t s, const vo_pair_result* res, int B, int valid, double* rec);
 

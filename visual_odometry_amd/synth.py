@@ -169,13 +169,8 @@ def sequence(n_frames: int, w: int, h: int, step: float = 1.0, yaw_deg: float = 
     """Returns dict(frames u8 [n,h,w], K, R [n,3,3], C [n,3]).  trajectory = "line": the straight flight (step / yaw per
     frame); "loop": the closed circular flight of loop_poses (n distinct views, frame n == frame 0)."""
     k = camera_matrix(w, h)
-    if trajectory == "loop":
-        rs, cs = loop_poses(n_frames, seed=seed)
-        tag = hashlib.sha1(f"loop-{n_frames}-{w}-{h}-{seed}-v1".encode()).hexdigest()[:16]
-    else:
-        rs, cs = poses(n_frames, step, yaw_deg, seed)
-        tag = hashlib.sha1(f"{n_frames}-{w}-{h}-{step}-{yaw_deg}-{seed}-v1".encode()).hexdigest()[:16]
-    path = os.path.join(cache_dir, f"vo_synth_{tag}.npy") if cache_dir else None
+    rs, cs = loop_poses(n_frames, seed=seed) if trajectory == "loop" else poses(n_frames, step, yaw_deg, seed)
+    path = cache_path(n_frames, w, h, cache_dir, trajectory, step, yaw_deg, seed) if cache_dir else None
     if path and os.path.exists(path):
         try:
             frames = np.load(path)
@@ -189,8 +184,12 @@ def sequence(n_frames: int, w: int, h: int, step: float = 1.0, yaw_deg: float = 
     jobs = [(w, h, k, rs[i], cs[i], seed, i) for i in range(n_frames)]
     if workers > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(workers) as pool:
+        pool = mp.get_context("fork").Pool(workers)
+        try:
             frames = np.stack(pool.map(_render_job, jobs, chunksize=2))
+        finally:
+            pool.close()                         # let the workers leave by themselves: Pool.__exit__ is terminate() = SIGTERM,
+            pool.join()                          # which a tool's signal handler inherited by a worker reports as an abort
     else:
         frames = np.stack([_render_job(j) for j in jobs])
     if path:
@@ -203,15 +202,40 @@ def sequence(n_frames: int, w: int, h: int, step: float = 1.0, yaw_deg: float = 
     return dict(frames=frames, K=k, R=rs, C=cs)
 
 
+def cache_path(n_frames: int, w: int, h: int, cache_dir: str, trajectory: str = "line", step: float = 1.0, yaw_deg: float = 0.5,
+               seed: int = _SEED):
+    if trajectory == "loop":
+        tag = hashlib.sha1(f"loop-{n_frames}-{w}-{h}-{seed}-v1".encode()).hexdigest()[:16]
+    else:
+        tag = hashlib.sha1(f"{n_frames}-{w}-{h}-{step}-{yaw_deg}-{seed}-v1".encode()).hexdigest()[:16]
+    return os.path.join(cache_dir, f"vo_synth_{tag}.npy")
+
+
+def _cache_complete(path, shape):
+    try:
+        return np.load(path, mmap_mode="r").shape == tuple(shape)
+    except (OSError, ValueError):
+        return False
+
+
+# what a profiler or sanitizer injects into a process it wraps: the render child is CPU-only numpy and must not carry it
+_TOOL_ENV_PREFIXES = ("LD_PRELOAD", "ROCP", "ROCPROF", "ROCTX", "HSA_TOOLS", "ROCTRACER", "AMD_LOG", "OMPI_", "ASAN_OPTIONS")
+
+
 def prerender(n_frames: int, w: int, h: int, cache_dir: str = "/tmp", trajectory: str = "line"):
     """Fill the cache for sequence(...) in a CHILD process (python -m visual_odometry_amd.synth): the parallel renderer
     forks workers, which a process that holds (or will hold) a GPU context and a process group should not do itself.
-    Call it before anything initialises the GPU; afterwards sequence(..., workers=1) only reads the cache."""
+    Call it before anything initialises the GPU; afterwards sequence(..., workers=1) only reads the cache.
+    Nothing is started when the cache is complete, and the child's environment is stripped of profiler / tool preloads
+    (under `rocprofv3 -- python3 bench.py` the child and its forked workers would otherwise carry the profiler)."""
     import subprocess
     import sys
+    if _cache_complete(cache_path(n_frames, w, h, cache_dir, trajectory), (n_frames, h, w)):
+        return
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith(_TOOL_ENV_PREFIXES)}
     subprocess.check_call([sys.executable, "-m", "visual_odometry_amd.synth", str(n_frames), str(w), str(h), cache_dir, trajectory],
-                          cwd=root, stdout=subprocess.DEVNULL)
+                          cwd=root, stdout=subprocess.DEVNULL, env=env)
 
 
 if __name__ == "__main__":
