@@ -113,6 +113,15 @@ int vo_match_l2(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int
 /* matcher.knnMatch(d1, d2, k=2) + `m.distance < ratio * n.distance` — src/feature_detection.py:20-26. */
 int vo_knn2_ratio_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
                           int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
+/* matcher.knnMatch(d1, d2, k=2) itself — src/feature_detection.py:21 (and :90): BOTH neighbours of every query row, as
+ * batchDistance's K = 2 insertion leaves them (ascending scan of the train rows, strict `<`: equal distances keep their
+ * train order).  idx / dist: nq x 2; a neighbour that does not exist (fewer than two train rows) is -1 / FLT_MAX — cv2
+ * leaves it out of the row's list.  vo_knn2_l2: the same for cv2.BFMatcher(cv2.NORM_L2) on float rows (the script runs its
+ * ratio rule on SIFT descriptors, :7-8); vo_knn2_ratio_l2: knnMatch + the rule of :24-26 in one call. */
+int vo_knn2_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, float* dist);
+int vo_knn2_l2(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, int32_t* idx, float* dist);
+int vo_knn2_ratio_l2(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, double ratio,
+                     int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
 
 /* cv2.findEssentialMat(p1, p2, K, cv2.FM_RANSAC, prob, thresh) — src/image_pair.py:280-286.
  * p1, p2: M x 2 float64 pixel coordinates; K: 3x3 row-major; seed: OpenCV's RNG seed 2^64-1.

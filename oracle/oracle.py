@@ -189,6 +189,27 @@ def knn2_ratio_hamming(q, t, ratio):
     return qi[:n.value].copy(), ti[:n.value].copy(), d[:n.value].copy()
 
 
+def knn2_hamming(q, t):
+    """matcher.knnMatch(q, t, k=2) for NORM_HAMMING: (idx [nq, 2], dist [nq, 2]); missing neighbours -1 / FLT_MAX."""
+    q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
+    idx = np.zeros((max(len(q), 1), 2), np.int32); d = np.zeros((max(len(q), 1), 2), np.float32)
+    f = lib().voo_knn2_hamming
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    assert f(q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data, d.ctypes.data) == 0
+    return idx[:len(q)], d[:len(q)]
+
+
+def knn2_l2(q, t):
+    """matcher.knnMatch(q, t, k=2) for NORM_L2 on float32 rows."""
+    q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+    dim = q.shape[1] if len(q) else (t.shape[1] if len(t) else 1)
+    idx = np.zeros((max(len(q), 1), 2), np.int32); d = np.zeros((max(len(q), 1), 2), np.float32)
+    f = lib().voo_knn2_l2
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert f(q.ctypes.data, len(q), t.ctypes.data, len(t), int(dim), idx.ctypes.data, d.ctypes.data) == 0
+    return idx[:len(q)], d[:len(q)]
+
+
 def set_dk_early_exit(on):
     """False (default): cv::solvePoly's fixed 300 sweeps; True: the noise-floor exit of the kernel's throughput mode."""
     lib().voo_set_dk_early_exit(int(bool(on)))

@@ -71,6 +71,9 @@ int voo_knn2_ratio_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, d
 
 /* cv2.BFMatcher(cv2.NORM_L2, crossCheck).match on float descriptors (the reference's live SIFT matcher,
  * visual_slam.py:19): same cross_check values as voo_match_hamming, distances = sqrt(sum of squared differences) */
+/* knnMatch(k=2): both neighbours of every query row, nq x 2 (feature_detection.py:21); missing entries -1 / FLT_MAX */
+int voo_knn2_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, float* dist);
+int voo_knn2_l2(const float* q, int nq, const float* t, int nt, int dim, int32_t* idx, float* dist);
 int voo_match_l2(const float* q, int nq, const float* t, int nt, int dim, int cross_check,
                  int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out);
 

@@ -167,3 +167,45 @@ int voo_match_l2(const float* q, int nq, const float* t, int nt, int dim, int cr
     free(fi); free(fd);
     return 0;
 }
+
+/* ---------------------------------------------------------------- matcher.knnMatch(d1, d2, k=2) itself
+ * (/root/reference/src/feature_detection.py:21,90).  batchDistance with K = 2 (core/batch_distance.cpp BatchDistInvoker):
+ * the train rows are scanned in ascending order; a distance enters the sorted two-entry list only if it is strictly smaller
+ * than the entry it displaces (`d < dist[K-1]`, then shifted past every entry with `dist[k] > d`), so equal distances keep
+ * their train order.  idx / dist: nq x 2; an entry that was never filled (fewer than two train rows) stays -1 / FLT_MAX —
+ * BFMatcher::knnMatchImpl leaves such entries out of the row's DMatch list. */
+int voo_knn2_hamming(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, float* dist)
+{
+    if (nq < 0 || nt < 0) return -1;
+    for (int i = 0; i < nq; i++) {
+        int d0 = INT_MAX, d1 = INT_MAX, i0 = -1, i1 = -1;
+        for (int j = 0; j < nt; j++) {
+            int d = hamming256(q + (size_t)32 * i, t + (size_t)32 * j);
+            if (d < d1) {
+                if (d0 > d) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                else { d1 = d; i1 = j; }
+            }
+        }
+        idx[2 * i] = i0; dist[2 * i] = i0 >= 0 ? (float)d0 : FLT_MAX;
+        idx[2 * i + 1] = i1; dist[2 * i + 1] = i1 >= 0 ? (float)d1 : FLT_MAX;
+    }
+    return 0;
+}
+
+int voo_knn2_l2(const float* q, int nq, const float* t, int nt, int dim, int32_t* idx, float* dist)
+{
+    if (nq < 0 || nt < 0 || dim < 1) return -1;
+    for (int i = 0; i < nq; i++) {
+        float d0 = FLT_MAX, d1 = FLT_MAX; int i0 = -1, i1 = -1;
+        for (int j = 0; j < nt; j++) {
+            float d = sqrtf(l2sqr(q + (size_t)dim * i, t + (size_t)dim * j, dim));
+            if (d < d1) {
+                if (d0 > d) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                else { d1 = d; i1 = j; }
+            }
+        }
+        idx[2 * i] = i0; dist[2 * i] = d0;
+        idx[2 * i + 1] = i1; dist[2 * i + 1] = d1;
+    }
+    return 0;
+}

@@ -204,3 +204,82 @@ def test_matcher_kernel_switch_after_detection_stays_consistent(oracle, seq_smal
             assert np.array_equal(qi, want[0]) and np.array_equal(ti, want[1]) and np.array_equal(dd, want[2]), (first, then)
     finally:
         c.close()
+
+
+def _script_ratio_loop(matches, ratio):
+    """/root/reference/src/feature_detection.py:21-26 (and :90-96), re-typed: the loop the script runs on knnMatch's result."""
+    good = []
+    for m, n in matches:
+        if m.distance < ratio * n.distance:
+            good.append(m)
+    return good
+
+
+@pytest.mark.parametrize("kernel", ["mfma_fp4", "mfma", "popcount"])
+def test_knn_match_k2_hamming(oracle, kernel):
+    """matcher.knnMatch(d1, d2, k=2) returns [DMatch, DMatch] rows — both neighbours, index and distance, as batchDistance's
+    K = 2 insertion orders them (ties keep their train order) — in every Hamming kernel; the script's own loop over that
+    result gives ratio_match's list."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.matcher import HammingMatcher
+    c = _lib.Context(0)
+    try:
+        c.set_matcher_kernel(kernel)
+        m = HammingMatcher(ctx=c)
+        rng = np.random.default_rng(11)
+        base = rng.integers(0, 256, (12, 32), dtype=np.uint8)
+        cases = [(_descs(3, 700, dup_from=_descs(4, 900), flip_bits=40), _descs(4, 900)),
+                 (base[rng.integers(0, 12, 200)], base[rng.integers(0, 12, 150)]),         # exact duplicates: ties in both entries
+                 (_descs(5, 2100), _descs(6, 2300)), (_descs(7, 33), _descs(8, 2)), (_descs(9, 1), _descs(10, 300))]
+        for q, t in cases:
+            gi, gd = m.knn2_arrays(q, t)
+            oi, od = oracle.knn2_hamming(q, t)
+            assert np.array_equal(gi, oi) and np.array_equal(gd, od), (kernel, len(q), len(t))
+            D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2) if len(q) * len(t) <= 200 * 150 else None
+            if D is not None:                                                              # an independent statement of the rule
+                o2 = np.argsort(D, axis=1, kind="stable")[:, :2]
+                assert np.array_equal(gi, o2) and np.array_equal(gd, np.take_along_axis(D, o2, 1).astype(np.float32))
+            rows = m.knnMatch(q, t, k=2)
+            assert len(rows) == len(q) and all(len(r) == 2 for r in rows)
+            assert all(r[0].queryIdx == i and r[1].queryIdx == i for i, r in enumerate(rows))
+            for ratio in (0.3, 0.8):                                                       # the script's literal is 0.3
+                good = _script_ratio_loop(rows, ratio)
+                want = m.ratio_match(q, t, ratio)
+                assert [(g.queryIdx, g.trainIdx, g.distance) for g in good] == [(w.queryIdx, w.trainIdx, w.distance) for w in want]
+        # one train row: cv2 returns one-entry lists (and the script's `for m, n in` would raise on them)
+        rows = m.knnMatch(_descs(1, 5), _descs(2, 1), k=2)
+        assert [len(r) for r in rows] == [1] * 5 and all(r[0].trainIdx == 0 for r in rows)
+        assert m.knnMatch(_descs(1, 5), np.zeros((0, 32), np.uint8), k=2) == [[]] * 5
+        assert [len(r) for r in m.knnMatch(_descs(1, 5), _descs(2, 9), k=1)] == [1] * 5
+        with pytest.raises(ValueError):
+            HammingMatcher(crossCheck=True, ctx=c).knnMatch(_descs(1, 5), _descs(2, 9), k=2)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("dim,nq,nt", [(128, 700, 900), (128, 2100, 2300), (128, 65, 64), (61, 130, 70), (3, 10, 200), (128, 40, 1)])
+def test_knn_match_k2_l2(oracle, ctx, dim, nq, nt):
+    """cv2.BFMatcher(cv2.NORM_L2).knnMatch(d1, d2, k=2) on float rows — what src/feature_detection.py:7-8,21 runs on SIFT
+    descriptors: both neighbours and their float distances equal the oracle's, ties included; the script's loop over the
+    rows = L2Matcher.ratio_match (vo_knn2_ratio_l2)."""
+    from visual_odometry_amd.matcher import L2Matcher
+    rng = np.random.default_rng(dim * 77 + nq)
+    t = np.floor(rng.random((nt, dim), dtype=np.float32) * 255).astype(np.float32)       # SIFT rows hold integers 0..255
+    q = np.clip(t[rng.integers(0, nt, nq)] + np.rint(rng.normal(0, 6, (nq, dim))), 0, 255).astype(np.float32)
+    if nt > 8:
+        t[nt // 2:nt // 2 + 4] = t[0]                                                      # duplicated train rows: ties
+        q[:3] = t[0]
+    m = L2Matcher(ctx=ctx)
+    gi, gd = m.knn2_arrays(q, t)
+    oi, od = oracle.knn2_l2(q, t)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    rows = m.knnMatch(q, t, k=2)
+    assert len(rows) == nq and all(len(r) == min(2, nt) for r in rows)
+    if nt >= 2:
+        assert rows[0][0].trainIdx == 0 or nt <= 8
+        for ratio in (0.3, 0.8):
+            good = _script_ratio_loop(rows, ratio)
+            want = m.ratio_match(q, t, ratio)
+            assert [(g.queryIdx, g.trainIdx, g.distance) for g in good] == [(w.queryIdx, w.trainIdx, w.distance) for w in want]
+    else:
+        assert m.ratio_match(q, t, 0.8) == []

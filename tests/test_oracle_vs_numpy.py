@@ -465,3 +465,31 @@ def test_p3p_branch_recovers_the_pose(oracle):
         assert np.abs(rep[:3] - uv[:3]).max() < 1e-2             # the three points P3P solves with
         good += np.abs(Rg - R).max() < 1e-4 and np.abs(tv - t).max() < 1e-3
     assert good >= 95
+
+
+def test_knn2_oracle_is_the_stable_two_smallest(oracle):
+    """voo_knn2_hamming / voo_knn2_l2 (knnMatch(k=2), feature_detection.py:21) = the first two entries of a stable sort of every
+    row of the distance matrix: batchDistance's insertion (ascending scan, strict <) stated another way."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (10, 32), dtype=np.uint8)
+    for q, t in ((rng.integers(0, 256, (90, 32), dtype=np.uint8), rng.integers(0, 256, (120, 32), dtype=np.uint8)),
+                 (base[rng.integers(0, 10, 60)], base[rng.integers(0, 10, 40)])):
+        D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+        o2 = np.argsort(D, axis=1, kind="stable")[:, :2]
+        idx, dist = oracle.knn2_hamming(q, t)
+        assert np.array_equal(idx, o2) and np.array_equal(dist, np.take_along_axis(D, o2, 1).astype(np.float32))
+        for ratio in (0.3, 0.8, 1.0):                                    # and the ratio oracle is knn2 + the script's rule
+            qi, ti, d = oracle.knn2_ratio_hamming(q, t, ratio)
+            keep = dist[:, 0].astype(np.float64) < ratio * dist[:, 1].astype(np.float64)
+            assert np.array_equal(qi, np.nonzero(keep)[0]) and np.array_equal(ti, idx[keep, 0]) and np.array_equal(d, dist[keep, 0])
+    a = np.floor(rng.random((40, 128)) * 255).astype(np.float32); b = np.floor(rng.random((55, 128)) * 255).astype(np.float32)
+    b[20:23] = b[0]; a[:2] = b[0]
+    idx, dist = oracle.knn2_l2(a, b)
+    D = np.sqrt(((a[:, None, :].astype(np.float64) - b[None, :, :]) ** 2).sum(2)).astype(np.float32)   # integer rows: the sums are exact
+    o2 = np.argsort(D, axis=1, kind="stable")[:, :2]
+    assert np.array_equal(idx, o2) and np.array_equal(dist, np.take_along_axis(D, o2, 1))
+    assert idx[0].tolist() == [0, 20] and dist[0].tolist() == [0.0, 0.0]
+    qi, ti, d = oracle.match_l2(a, b, 0)
+    assert np.array_equal(ti, idx[:, 0]) and np.array_equal(d, dist[:, 0])
+    i1, d1 = oracle.knn2_l2(a, b[:1])
+    assert np.all(i1[:, 1] == -1) and np.all(i1[:, 0] == 0)

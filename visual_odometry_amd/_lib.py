@@ -78,6 +78,9 @@ _SIGS = {
     "vo_set_keypoint_order": (C.c_int, [_P, C.c_int]),
     "vo_stage_retain_best": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "vo_detect_after": (C.c_int, [_P, _P]),
+    "vo_knn2_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P]),
+    "vo_knn2_l2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    "vo_knn2_ratio_l2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
     "vo_comm_unique_id": (C.c_int, [_P]),
     "vo_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vo_comm_destroy": (C.c_int, [_P]),

@@ -721,7 +721,11 @@ void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count,
 // matrix cores would change the rounding of every distance, and with it the winner of near-ties.
 // One lane per query row (its elements stay in registers for DIM = 128), train rows broadcast from LDS tiles.
 #define L2_TILE 32
-template <int DIM>
+// KNN2: the two nearest train rows of every query (knnMatch(k = 2): batchDistance's K = 2 insertion, strict `<`, so equal
+// distances keep their ascending train order).  Every share of the train rows then leaves its own best two keys in
+// part[share][row][2]; k_nn_l2_merge2 takes the two smallest of all shares — keys are unique (the index is part of them), so
+// that is exactly the order the single ascending scan produces.
+template <int DIM, bool KNN2>
 __global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const float* B, int nb, int dim, unsigned long long* key, int split_rows)
 {
     extern __shared__ float s_t[];                       // [L2_TILE][dim]
@@ -733,8 +737,8 @@ __global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const floa
 #pragma unroll
         for (int k = 0; k < DIM; k++) areg[k] = a[k];
     }
-    float best = FLT_MAX;
-    int bi = -1;
+    float best = FLT_MAX, best2 = FLT_MAX;
+    int bi = -1, bi2 = -1;
     // blockIdx.y: this workgroup's share of the train rows; the shares meet in a 64-bit atomic minimum of
     // (distance bits << 32 | train index) — non-negative floats order like their bit patterns, so the minimum is the
     // smallest distance and, among equals, the lowest index: the ascending scan with strict `<`
@@ -773,10 +777,35 @@ __global__ __launch_bounds__(64) void k_nn_l2(const float* A, int na, const floa
             float d = (s[0] + s[2]) + (s[1] + s[3]);
             for (; j < dim; j++) { const float t = (DIM > 0 ? areg[DIM > 0 ? min(j, DIM - 1) : 0] : a[j]) - b[j]; const float p = t * t; d = d + p; }
             d = sqrtf(d);
-            if (d < best) { best = d; bi = base + r; }
+            if (KNN2) {
+                if (d < best2) {
+                    if (best > d) { best2 = best; bi2 = bi; best = d; bi = base + r; }
+                    else { best2 = d; bi2 = base + r; }
+                }
+            } else if (d < best) { best = d; bi = base + r; }
         }
     }
-    if (live && bi >= 0) atomicMin(&key[row], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi);
+    if (KNN2) {
+        if (live) {
+            unsigned long long* o = key + ((size_t)blockIdx.y * na + row) * 2;
+            o[0] = bi >= 0 ? ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi : ~0ULL;
+            o[1] = bi2 >= 0 ? ((unsigned long long)__float_as_uint(best2) << 32) | (unsigned)bi2 : ~0ULL;
+        }
+    } else if (live && bi >= 0) atomicMin(&key[row], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi);
+}
+
+__global__ void k_nn_l2_merge2(const unsigned long long* part, int nsplit, int na, int* idx, float* dist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= na) return;
+    unsigned long long k0 = ~0ULL, k1 = ~0ULL;
+    for (int sp = 0; sp < nsplit; sp++)
+        for (int j = 0; j < 2; j++) {
+            const unsigned long long k = part[((size_t)sp * na + i) * 2 + j];
+            if (k < k0) { k1 = k0; k0 = k; } else if (k < k1) k1 = k;
+        }
+    idx[2 * i] = k0 == ~0ULL ? -1 : (int)(k0 & 0xffffffffu);     dist[2 * i] = k0 == ~0ULL ? FLT_MAX : __uint_as_float((unsigned)(k0 >> 32));
+    idx[2 * i + 1] = k1 == ~0ULL ? -1 : (int)(k1 & 0xffffffffu); dist[2 * i + 1] = k1 == ~0ULL ? FLT_MAX : __uint_as_float((unsigned)(k1 >> 32));
 }
 
 __global__ void k_nn_l2_decode(const unsigned long long* key, int na, int* idx, float* dist)
@@ -786,6 +815,40 @@ __global__ void k_nn_l2_decode(const unsigned long long* key, int na, int* idx, 
     const unsigned long long k = key[i];
     idx[i] = k == ~0ULL ? -1 : (int)(k & 0xffffffffu);
     dist[i] = k == ~0ULL ? FLT_MAX : __uint_as_float((unsigned)(k >> 32));
+}
+
+static void nn_l2_shares(int na, int nb, int* gx_out, int* nsplit_out, int* split_rows_out)
+{
+    const int gx = (na + 63) / 64;
+    // enough workgroups to fill the chip: the train rows are cut into shares of whole LDS tiles
+    int nsplit = (2048 + gx - 1) / gx;
+    const int max_split = (nb + 4 * L2_TILE - 1) / (4 * L2_TILE);
+    nsplit = nsplit < 1 ? 1 : nsplit > max_split ? max_split : nsplit;
+    if (nsplit < 1) nsplit = 1;
+    int split_rows = (nb + nsplit - 1) / nsplit;
+    split_rows = (split_rows + L2_TILE - 1) / L2_TILE * L2_TILE;
+    nsplit = nb > 0 ? (nb + split_rows - 1) / split_rows : 1;
+    *gx_out = gx; *nsplit_out = nsplit; *split_rows_out = split_rows;
+}
+
+// keys the two-neighbour search needs: [shares][na][2]
+size_t nn_l2_knn2_keys(int na, int nb)
+{
+    int gx, nsplit, split_rows;
+    nn_l2_shares(na, nb, &gx, &nsplit, &split_rows);
+    return (size_t)nsplit * (na > 0 ? na : 1) * 2;
+}
+
+// idx / dist: [na][2] (second neighbour -1 / FLT_MAX when the train set has a single row)
+void launch_nn_l2_knn2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist, unsigned long long* part)
+{
+    if (na <= 0) return;
+    int gx, nsplit, split_rows;
+    nn_l2_shares(na, nb, &gx, &nsplit, &split_rows);
+    const size_t shmem = (size_t)L2_TILE * dim * sizeof(float);
+    if (dim == 128) hipLaunchKernelGGL((k_nn_l2<128, true>), dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, part, split_rows);
+    else hipLaunchKernelGGL((k_nn_l2<0, true>), dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, part, split_rows);
+    hipLaunchKernelGGL(k_nn_l2_merge2, dim3((na + 255) / 256), dim3(256), 0, s, part, nsplit, na, idx, dist);
 }
 
 void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist, unsigned long long* key)
@@ -802,7 +865,7 @@ void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb,
     split_rows = (split_rows + L2_TILE - 1) / L2_TILE * L2_TILE;
     nsplit = nb > 0 ? (nb + split_rows - 1) / split_rows : 1;
     (void)hipMemsetAsync(key, 0xFF, (size_t)na * sizeof(unsigned long long), s);
-    if (dim == 128) hipLaunchKernelGGL(k_nn_l2<128>, dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, key, split_rows);
-    else hipLaunchKernelGGL(k_nn_l2<0>, dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, key, split_rows);
+    if (dim == 128) hipLaunchKernelGGL((k_nn_l2<128, false>), dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, key, split_rows);
+    else hipLaunchKernelGGL((k_nn_l2<0, false>), dim3(gx, nsplit), dim3(64), shmem, s, A, na, B, nb, dim, key, split_rows);
     hipLaunchKernelGGL(k_nn_l2_decode, dim3((na + 255) / 256), dim3(256), 0, s, key, na, idx, dist);
 }

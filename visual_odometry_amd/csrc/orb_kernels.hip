@@ -107,6 +107,36 @@ void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride
     hipLaunchKernelGGL(k_gray, grid, dim3(64), 0, s, src, channels, row_stride, frame_stride, pyr, g);
 }
 
+// the same conversion into a plain image stack (any row pitch, no padding written): the SIFT slots' gray frames
+__global__ void k_gray_plain(const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
+                             uint8_t* dst, int w, int dstride, int64_t dframe)
+{
+    const int f = blockIdx.z;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= w) return;
+    const uint8_t* s = src + (size_t)f * frame_stride + (size_t)y * row_stride;
+    uint8_t* d = dst + (size_t)f * dframe + (size_t)y * dstride + x4;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int x = x4 + b;
+        if (x < w) {
+            const uint8_t* px = s + (size_t)x * channels;
+            const int v = channels == 1 ? px[0] : (px[0] * 3735 + px[1] * 19235 + px[2] * 9798 + (1 << 14)) >> 15;
+            out |= (uint32_t)v << (8 * b);
+        }
+    }
+    if (x4 + 4 <= w && ((dstride | (int)(dframe & 3)) & 3) == 0) *(uint32_t*)d = out;      // rows and frames start on dword boundaries
+    else for (int b = 0; b < 4 && x4 + b < w; b++) d[b] = (uint8_t)(out >> (8 * b));
+}
+
+void launch_gray_plain(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
+                       uint8_t* dst, int w, int h, int dstride, int64_t dframe, int F)
+{
+    dim3 grid(((w + 3) / 4 + 63) / 64, h, F);
+    hipLaunchKernelGGL(k_gray_plain, grid, dim3(64), 0, s, src, channels, row_stride, frame_stride, dst, w, dstride, dframe);
+}
+
 // ------------------------------------------------------------------ INTER_LINEAR_EXACT (resize.cpp resize_bitExact, u8)
 // 8.8 fixed-point horizontal pass (exact), 16.16 vertical pass rounded half-up; edge columns / rows
 // replicate. One thread = 4 destination pixels (one dword store).

@@ -528,6 +528,30 @@ extern "C" int vo_batch_configure(vo_ctx* ctx, int h, int w, const vo_orb_params
     return VO_OK;
 }
 
+// ---- the resident gray frames of the batched path, whichever detector is configured: level 0 of the ORB pyramid slots, or the
+// SIFT slots' dense gray images
+static bool batch_ready(const vo_ctx* ctx);
+static int batch_w(const vo_ctx* ctx) { return ctx->detector == 1 ? ctx->sift.w : ctx->w; }
+static int batch_h(const vo_ctx* ctx) { return ctx->detector == 1 ? ctx->sift.h : ctx->h; }
+static int batch_max_frames(const vo_ctx* ctx) { return ctx->detector == 1 ? ctx->sift.max_frames : ctx->max_frames; }
+struct GraySlots { uint8_t* base; int stride; size_t frame; };          // slot k's image at base + k * frame, rows of `stride` bytes
+static GraySlots batch_gray_slots(const vo_ctx* ctx, int first_slot)
+{
+    if (ctx->detector == 1) {
+        const size_t fb = (size_t)ctx->sift.fstride * ctx->sift.h;
+        return {ctx->sift.frames + (size_t)first_slot * fb, ctx->sift.fstride, fb};
+    }
+    return {ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes + ctx->g.lv[0].off, ctx->g.lv[0].stride, (size_t)ctx->g.frame_bytes};
+}
+// cvtColor(BGR2GRAY) (or a copy of gray input) of n device frames into slots first_slot..
+static void gray_into_slots(vo_ctx* ctx, hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride, int first_slot, int n)
+{
+    if (ctx->detector == 1) {
+        const GraySlots d = batch_gray_slots(ctx, first_slot);
+        launch_gray_plain(s, src, channels, row_stride, frame_stride, d.base, ctx->sift.w, ctx->sift.h, d.stride, (int64_t)d.frame, n);
+    } else launch_gray(s, src, channels, row_stride, frame_stride, ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes, ctx->g, n);
+}
+
 static int frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot)
 {
     if (ctx->detector == 1) return sift_frames_upload_enqueue(ctx, frames, F, row_stride, frame_stride, first_slot);
@@ -583,30 +607,27 @@ extern "C" int vo_frames_upload_color(vo_ctx* ctx, const uint8_t* frames, int F,
 {
     if (!ctx) return VO_ERR_INVALID;
     if (channels == 1) return vo_frames_upload(ctx, frames, F, row_stride, frame_stride, first_slot);
-    if (ctx->detector == 1) FAIL(VO_ERR_UNSUPPORTED, "the batched SIFT path takes gray frames (vo_frames_upload)");
-    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!batch_ready(ctx)) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (channels != 3 && channels != 4) FAIL(VO_ERR_INVALID, "channels must be 1, 3 or 4");
-    if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
-    if (row_stride < ctx->w * channels || frame_stride < (int64_t)row_stride * ctx->h) FAIL(VO_ERR_INVALID, "strides too small");
+    if (!frames || F < 0 || first_slot < 0 || first_slot + F > batch_max_frames(ctx)) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (row_stride < batch_w(ctx) * channels || frame_stride < (int64_t)row_stride * batch_h(ctx)) FAIL(VO_ERR_INVALID, "strides too small");
+    if (F == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t per = (size_t)frame_stride;
-    // stage in chunks of at most 64 frames
+    // B G R (A) frames pass through a staging buffer (at most 64 frames of it, grown once: the first call of a size pays for it);
+    // the chunks follow one another in stream order — the next chunk's copy waits for the previous chunk's conversion by
+    // itself — and the call returns when the last conversion has finished
     const int chunk = F < 64 ? F : 64;
-    if (per * chunk > ctx->staging_bytes) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (ctx->staging) (void)hipFree(ctx->staging);
-        ctx->staging = nullptr; ctx->staging_bytes = 0;
-        HIPCHK(hipMalloc((void**)&ctx->staging, per * chunk));
-        ctx->staging_bytes = per * chunk;
-    }
+    int rc = ensure_bytes(ctx, &ctx->staging, &ctx->staging_bytes, per * chunk); if (rc) return rc;
     for (int f0 = 0; f0 < F; f0 += chunk) {
         const int n = F - f0 < chunk ? F - f0 : chunk;
         HIPCHK(hipMemcpyAsync(ctx->staging, frames + (size_t)f0 * per, per * n, hipMemcpyHostToDevice, ctx->stream));
         StageTimer t(ctx, ST_GRAY);
-        launch_gray(ctx->stream, ctx->staging, channels, row_stride, frame_stride,
-                    ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes, ctx->g, n);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        gray_into_slots(ctx, ctx->stream, ctx->staging, channels, row_stride, frame_stride, first_slot + f0, n);
     }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_collect(ctx);
     return VO_OK;
 }
 
@@ -1334,6 +1355,92 @@ extern "C" int vo_knn2_ratio_hamming(vo_ctx* ctx, const uint8_t* q, int nq, cons
     return match_raw(ctx, q, nq, t, nt, 3, ratio, qidx, tidx, dist, n_out);
 }
 
+// matcher.knnMatch(d1, d2, k=2) itself: both neighbours of every query row (src/feature_detection.py:21,90)
+extern "C" int vo_knn2_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, float* dist)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) FAIL(VO_ERR_INVALID, "bad matcher arguments");
+    if (nq == 0) return VO_OK;
+    if (nt == 0) { for (int i = 0; i < 2 * nq; i++) { idx[i] = -1; dist[i] = FLT_MAX; } return VO_OK; }
+    if (nq > 65535 || nt > 65535) FAIL(VO_ERR_INVALID, "at most 65535 descriptors per set");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_raw(ctx, nq > nt ? nq : nt);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    const int cap = ctx->raw_cap, cx = desc_x_rows(cap), fp4 = matcher_fp4(ctx, cap);
+    const int counts[2] = {nq, nt}, slots[2] = {0, 1};
+    HIPCHK(hipMemcpyAsync(ctx->raw_desc, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->raw_desc + (size_t)cap * 32, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->raw_count, counts, sizeof(counts), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ctx->raw_pb.slots, slots, sizeof(slots), hipMemcpyHostToDevice, s));
+    {
+        StageTimer tm(ctx, ST_MATCH_NN);
+        if (ctx->matcher_kernel == 1 || cap >= 16129) launch_match_nn_popcount(s, ctx->raw_desc, ctx->raw_count, cap, ctx->raw_pb, 1, 1, 1);
+        else {
+            launch_desc_expand(s, ctx->raw_desc, ctx->raw_count, cap, cx, ctx->raw_desc_x, 2, fp4);
+            launch_match_nn(s, ctx->raw_desc_x, ctx->raw_count, cap, cx, ctx->raw_pb, 1, 1, 1, fp4);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<int> i0(nq), d0(nq), i1(nq), d1(nq);
+    HIPCHK(hipMemcpyAsync(i0.data(), ctx->raw_pb.nn_idx, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(d0.data(), ctx->raw_pb.nn_dist, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(i1.data(), ctx->raw_pb.nn_idx2, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(d1.data(), ctx->raw_pb.nn_dist2, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    for (int i = 0; i < nq; i++) {
+        idx[2 * i] = i0[i]; dist[2 * i] = i0[i] >= 0 ? (float)d0[i] : FLT_MAX;
+        const bool two = nt >= 2 && i1[i] >= 0;
+        idx[2 * i + 1] = two ? i1[i] : -1; dist[2 * i + 1] = two ? (float)d1[i] : FLT_MAX;
+    }
+    return VO_OK;
+}
+
+// ... on float rows (cv2.BFMatcher(cv2.NORM_L2).knnMatch(q, t, k=2): the script applies its ratio rule to SIFT descriptors)
+extern "C" int vo_knn2_l2(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, int32_t* idx, float* dist)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || dim < 1 || dim > 1024 || (nq > 0 && (!q || !idx || !dist)) || (nt > 0 && !t)) FAIL(VO_ERR_INVALID, "bad matcher arguments");
+    if (nq == 0) return VO_OK;
+    if (nt == 0) { for (int i = 0; i < 2 * nq; i++) { idx[i] = -1; dist[i] = FLT_MAX; } return VO_OK; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nf = (size_t)(nq + nt) * dim, no = (size_t)4 * nq, nk = nn_l2_knn2_keys(nq, nt);
+    int rc = ensure_raw_d(ctx, (nf + no) / 2 + 64 + nk);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    float* dq = (float*)ctx->raw_d; float* dt = dq + (size_t)nq * dim;
+    int* di = (int*)(dt + (size_t)nt * dim); float* dd = (float*)(di + 2 * nq);
+    unsigned long long* part = (unsigned long long*)((double*)ctx->raw_d + (nf + no) / 2 + 32);
+    HIPCHK(hipMemcpyAsync(dq, q, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)nt * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    { StageTimer tm(ctx, ST_MATCH_NN); launch_nn_l2_knn2(s, dq, nq, dt, nt, dim, di, dd, part); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(idx, di, (size_t)2 * nq * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(dist, dd, (size_t)2 * nq * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
+// knnMatch(k=2) + `m.distance < ratio * n.distance` on float rows (src/feature_detection.py:20-26 as the script runs it: on SIFT)
+extern "C" int vo_knn2_ratio_l2(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, double ratio,
+                                int32_t* qidx, int32_t* tidx, float* dist, int32_t* n_out)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!n_out || nq < 0 || (nq > 0 && (!qidx || !tidx || !dist))) FAIL(VO_ERR_INVALID, "bad matcher arguments");
+    *n_out = 0;
+    if (nq == 0 || nt < 2) return nt < 0 ? VO_ERR_INVALID : VO_OK;      // fewer than two neighbours: the script's `for m, n in` has nothing to unpack
+    std::vector<int32_t> i2((size_t)2 * nq); std::vector<float> d2((size_t)2 * nq);
+    const int rc = vo_knn2_l2(ctx, q, nq, t, nt, dim, i2.data(), d2.data());
+    if (rc) return rc;
+    int n = 0;
+    for (int i = 0; i < nq; i++)
+        if (i2[2 * i] >= 0 && i2[2 * i + 1] >= 0 && (double)d2[2 * i] < ratio * (double)d2[2 * i + 1]) { qidx[n] = i; tidx[n] = i2[2 * i]; dist[n] = d2[2 * i]; n++; }
+    *n_out = n;
+    return VO_OK;
+}
+
 __global__ void k_prepare_points(PairBuf pb, int M, const double* Kd, int fill_mask)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1773,12 +1880,12 @@ extern "C" int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, i
 static int ingest_from_device(vo_ctx* ctx, const uint8_t* src, int n, int sh, int sw, int channels, int row_stride, int64_t frame_stride,
                               int first_slot, uint8_t* resized_out)
 {
-    const int dw = ctx->w, dh = ctx->h;
+    const int dw = batch_w(ctx), dh = batch_h(ctx);
     const size_t dper = (size_t)dw * dh * channels;
     hipStream_t s = ctx->stream;
     if (sw == dw && sh == dh && (!resized_out || (row_stride == dw * channels && frame_stride == (int64_t)dper))) {
         // cv::resize to the source's own size is a copy: gray straight from the source frames
-        { StageTimer t(ctx, ST_GRAY); launch_gray(s, src, channels, row_stride, frame_stride, ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes, ctx->g, n); }
+        { StageTimer t(ctx, ST_GRAY); gray_into_slots(ctx, s, src, channels, row_stride, frame_stride, first_slot, n); }
         if (resized_out) HIPCHK(hipMemcpyAsync(resized_out, src, dper * n, hipMemcpyDeviceToHost, s));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
@@ -1787,12 +1894,11 @@ static int ingest_from_device(vo_ctx* ctx, const uint8_t* src, int n, int sh, in
     int rc = ensure_bytes(ctx, &ctx->ingest_out, &ctx->ingest_out_bytes, dper * n); if (rc) return rc;
     const int* xofs; const void* xa; const int* yofs; const void* yb;
     rc = ingest_tables(ctx, sw, sh, dw, dh, &xofs, &xa, &yofs, &yb); if (rc) return rc;
-    const LevelGeom& lv = ctx->g.lv[0];
-    uint8_t* lvl0 = ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes + lv.off;
+    const GraySlots g0 = batch_gray_slots(ctx, first_slot);
     {
         StageTimer t(ctx, ST_MISC);
-        if (channels == 1 && !resized_out)                   // gray input: straight into level 0
-            launch_resize_linear(s, src, sw, sh, 1, row_stride, frame_stride, lvl0, dw, dh, lv.stride, ctx->g.frame_bytes,
+        if (channels == 1 && !resized_out)                   // gray input: straight into the slots' gray frames
+            launch_resize_linear(s, src, sw, sh, 1, row_stride, frame_stride, g0.base, dw, dh, g0.stride, (int64_t)g0.frame,
                                  xofs, xa, yofs, yb, sw == 2 * dw && sh == 2 * dh, n);
         else
             launch_resize_linear(s, src, sw, sh, channels, row_stride, frame_stride, ctx->ingest_out, dw, dh, dw * channels,
@@ -1800,8 +1906,7 @@ static int ingest_from_device(vo_ctx* ctx, const uint8_t* src, int n, int sh, in
     }
     if (!(channels == 1 && !resized_out)) {
         StageTimer t(ctx, ST_GRAY);
-        launch_gray(s, ctx->ingest_out, channels, dw * channels, (int64_t)dper,
-                    ctx->pyr + (size_t)first_slot * ctx->g.frame_bytes, ctx->g, n);
+        gray_into_slots(ctx, s, ctx->ingest_out, channels, dw * channels, (int64_t)dper, first_slot, n);
         if (resized_out) HIPCHK(hipMemcpyAsync(resized_out, ctx->ingest_out, dper * n, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipGetLastError());
@@ -1816,13 +1921,13 @@ extern "C" int vo_frames_ingest(vo_ctx* ctx, const uint8_t* frames, int F, int s
                                 int64_t frame_stride, int first_slot, uint8_t* resized_out)
 {
     if (!ctx) return VO_ERR_INVALID;
-    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
-    if (!frames || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (!batch_ready(ctx)) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!frames || F < 0 || first_slot < 0 || first_slot + F > batch_max_frames(ctx)) FAIL(VO_ERR_INVALID, "slot range out of bounds");
     if (sh < 1 || sw < 1 || (channels != 1 && channels != 3 && channels != 4) || row_stride < sw * channels ||
         frame_stride < (int64_t)row_stride * sh) FAIL(VO_ERR_INVALID, "bad source geometry");
     if (F == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    const int dw = ctx->w, dh = ctx->h;
+    const int dw = batch_w(ctx), dh = batch_h(ctx);
     const size_t per = (size_t)frame_stride, dper = (size_t)dw * dh * channels;
     size_t chunk = (size_t)512 * 1024 * 1024 / per; if (chunk < 1) chunk = 1; if (chunk > (size_t)F) chunk = F;
     int rc = ensure_bytes(ctx, &ctx->staging, &ctx->staging_bytes, per * chunk); if (rc) return rc;
@@ -2311,8 +2416,8 @@ extern "C" int vo_jpeg_decode(vo_ctx* ctx, const uint8_t* data, size_t nbytes, u
 extern "C" int vo_frames_ingest_jpeg(vo_ctx* ctx, const uint8_t* blob, const int64_t* offsets, int F, int first_slot, uint8_t* resized_out)
 {
     if (!ctx) return VO_ERR_INVALID;
-    if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
-    if (!blob || !offsets || F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
+    if (!batch_ready(ctx)) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (!blob || !offsets || F < 0 || first_slot < 0 || first_slot + F > batch_max_frames(ctx)) FAIL(VO_ERR_INVALID, "slot range out of bounds");
     for (int f = 0; f < F; f++) if (offsets[f + 1] < offsets[f] + 4) FAIL(VO_ERR_INVALID, "file %d is empty", f);
     if (F == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
@@ -2320,15 +2425,15 @@ extern "C" int vo_frames_ingest_jpeg(vo_ctx* ctx, const uint8_t* blob, const int
     const int irc = jpeg_info(blob + offsets[0], (size_t)(offsets[1] - offsets[0]), &sh, &sw, &nc, &sa, &orr);
     if (irc) FAIL(irc, "file 0 is not a baseline JPEG");
     const int chunk = jpeg_chunk(sh, sw, F);
-    const size_t dper = (size_t)ctx->w * ctx->h * 3;
+    const int dw = batch_w(ctx), dh = batch_h(ctx);
+    const size_t dper = (size_t)dw * dh * 3;
     for (int f0 = 0; f0 < F; f0 += chunk) {
         const int n = F - f0 < chunk ? F - f0 : chunk;
-        if (sw == ctx->w && sh == ctx->h && !resized_out) {
+        const GraySlots g0 = batch_gray_slots(ctx, first_slot + f0);
+        if (sw == dw && sh == dh && !resized_out && g0.stride >= align_up(dw, 4)) {
             // files of the configured size and nobody wants the colour frames: cv::resize is a copy, so the decoder's colour
-            // conversion writes the gray level 0 of the slots itself (no B G R frames in memory, no k_gray pass)
-            const LevelGeom& lv = ctx->g.lv[0];
-            const int rc = jpeg_decode_device(ctx, blob, offsets, f0, n, sh, sw, ctx->pyr + (size_t)(first_slot + f0) * ctx->g.frame_bytes + lv.off,
-                                              ctx->g.frame_bytes, lv.stride);
+            // conversion writes the gray frames of the slots itself (no B G R frames in memory, no k_gray pass)
+            const int rc = jpeg_decode_device(ctx, blob, offsets, f0, n, sh, sw, g0.base, g0.frame, g0.stride);
             if (rc) return rc;
             continue;
         }

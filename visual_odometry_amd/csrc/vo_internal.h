@@ -141,6 +141,8 @@ void launch_pack_records(hipStream_t s, const vo_pair_result* res, int B, int va
 // ---- launchers (defined in the .hip files) --------------------------------------------------
 void launch_gray(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
                  uint8_t* pyr, const PyrGeom& g, int F);
+void launch_gray_plain(hipStream_t s, const uint8_t* src, int channels, int row_stride, int64_t frame_stride,
+                       uint8_t* dst, int w, int h, int dstride, int64_t dframe, int F);
 void launch_resize(hipStream_t s, uint8_t* pyr, const PyrGeom& g, int level, const ResizeTab& tab, int F);
 void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F,
                  uint32_t* tile_list, int* tile_count);      // tile_list == nullptr: dense score map instead of winner lists
@@ -230,6 +232,8 @@ void launch_match_nn_popcount(hipStream_t s, const uint8_t* desc, const int* kp_
 void launch_match_select(hipStream_t s, const float* kp_xy, const int* kp_count, int kp_cap, PairBuf pb, int P,
                          int mode, double ratio, const double* K, int l2 = 0);   // l2: nn_dist holds squared L2 distances, reported as sqrtf
 
+size_t nn_l2_knn2_keys(int na, int nb);
+void launch_nn_l2_knn2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist, unsigned long long* part);
 void launch_nn_l2(hipStream_t s, const float* A, int na, const float* B, int nb, int dim, int* idx, float* dist, unsigned long long* key);
 
 void launch_ransac(hipStream_t s, PairBuf pb, int kp_cap, int P, RansacParams rp, const uint32_t* rng_tab, int rng_n);
