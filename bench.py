@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_T = 78.6        # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz, lane-operations per second (one wave-instruction per 2 clk)
-PROFILE_TAG = "r03"       # profiles/<tag>_pmc_traffic[_sift].json hold this round's rocprofv3 PMC passes
+PROFILE_TAG = "r04"       # profiles/<tag>_pmc_traffic[_sift].json hold this round's rocprofv3 PMC passes
 
 # live kernels of every stage (name as rocprofv3 prints it, launches per step) and what bounds the stage
 STAGE_KERNELS = {"fast_score_nms": [("k_fast<false>", 1)], "gaussian_blur": [("k_blur_direct", 1)],
@@ -63,14 +63,29 @@ STAGE_BOUND = {"gray": "hbm", "pyramid_resize": "hbm", "fast_score_nms": "hbm", 
                "cv2_keypoint_order": "latency", "trajectory_gather": "latency"}
 
 
+_PMC_CACHE = {}
+
+
 def _pmc(detector):
-    names = [f"{PROFILE_TAG}_pmc_traffic{'_sift' if detector == 'sift' else ''}.json"] + ([] if detector == "sift" else ["r02_pmc_traffic.json"])
-    for n in names:
-        try:
-            return json.load(open(os.path.join(ROOT, "profiles", n))), n
-        except (OSError, ValueError):
-            continue
-    return None, None
+    """The committed rocprofv3 PMC pass of this round for `detector` — ONLY if it was collected on the sources this library
+    was built from (tools/collect_traffic.py stamps the file with tools/source_hash.py's hash and vo_version()): counters of
+    an older kernel are not replayed, the fields that would quote them become null."""
+    if detector in _PMC_CACHE:
+        return _PMC_CACHE[detector]
+    n = f"{PROFILE_TAG}_pmc_traffic{'_sift' if detector == 'sift' else ''}.json"
+    out = (None, None)
+    try:
+        from tools.source_hash import source_hash
+        t = json.load(open(os.path.join(ROOT, "profiles", n)))
+        if t.get("_meta", {}).get("source_hash") == source_hash():
+            out = (t, n)
+        else:
+            print(f"bench.py: profiles/{n} was collected on other sources (hash {t.get('_meta', {}).get('source_hash')}): "
+                  f"roofline.traffic / valu are reported as null; re-run tools/collect_profiles.sh", file=sys.stderr)
+    except (OSError, ValueError):
+        pass
+    _PMC_CACHE[detector] = out
+    return out
 
 
 def pmc_sum(detector, stage, field, nframes=None):
@@ -268,6 +283,7 @@ def main():
     ap.add_argument("--no-stream-pass", action="store_true", help="skip the frames-streamed-from-host measurement")
     ap.add_argument("--no-sustain", action="store_true", help="skip the >= 5 s x 3 sustained passes")
     ap.add_argument("--no-faithful-pass", action="store_true", help="ORB: skip the cv2-order + 300-sweep pass")
+    ap.add_argument("--no-extras", action="store_true", help="skip the widened rows' passes (config.sift, config.jpeg_pipeline, config.pnp)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0)
     ap.add_argument("--sustain-repeats", type=int, default=3)
     ap.add_argument("--workload", choices=["sequence", "independent", "batch", "flight"], default="sequence",
@@ -309,8 +325,12 @@ def main():
     from visual_odometry_amd import synth
     from visual_odometry_amd.rendezvous import FileRendezvous, LibraryCollectives, init_library_comm
     D = args.distinct_frames
+    extras = (not args.no_extras and world == 1 and args.gpus == 1 and args.detector == "orb" and args.workload == "sequence" and
+              not args.force_dist and (args.width, args.height) == (1280, 720))
     if rank == 0:
         synth.prerender(D, args.width, args.height, "/tmp", "loop")     # child process: this one never forks
+        if extras:
+            synth.prerender(D, 1152, 648, "/tmp", "loop")               # the SIFT pass runs at the reference's working size
     rdv = dist = torch = None
     on_gpu = True
     if use_dist and args.rendezvous == "file":
@@ -576,6 +596,21 @@ def main():
                             "tests/test_gpu_faithful.py); the headline value differs only in the root finder's exit rule"}
         del pipe2, fes2
 
+    # The rows either side of the pair path, under the same clock (tools/bench_passes.py): the reference's live SIFT + L2
+    # configuration at its working size, files in -> poses out, and solvePnPRansac.  Each runs on contexts of its own after the
+    # timed region, like config.faithful.
+    extra = {}
+    if extras and not stub:
+        from tools import bench_passes as BP
+        try:
+            seq_s = synth.sequence(D, 1152, 648, cache_dir="/tmp", trajectory="loop", workers=1)
+            extra["sift"] = BP.sift_pass(seq_s["frames"][(start + np.arange(192)) % D], seq_s["K"], device=device, hbm_peak_gbs=HBM_PEAK_GBS)
+            files = BP.jpeg_files(seq["frames"][:64])
+            extra["jpeg_pipeline"] = BP.jpeg_pipeline_pass(files, args.width, args.height, K, nfeatures=args.nfeatures, device=device)
+            extra["pnp"] = BP.pnp_pass(_lib.Context(device))[0]
+        except Exception as e:                            # noqa: BLE001 — an extra never takes the headline line down
+            extra["error"] = f"{type(e).__name__}: {e}"
+
     ok = int((res["status"] == 0).sum())
     if rank == 0:
         value = world * C * args.steps / dt
@@ -606,12 +641,12 @@ def main():
                                         "histogram": {f"{hist_edges[i]}-{hist_edges[i + 1] - 1}": int(hist[i]) for i in range(len(hist))}},
                        "n_ranks_in_communicator": fe.ctx.comm_info()[0] if gather == "library" else None,
                        "parallelism": (f"pair-sharded x{world}, one all-gather of 128 B/pair per step via " +
-                                       ("vo_pairs_gather (device pack + ncclAllGather on the process's one communicator stream); rendezvous: " +
+                                       ("vo_pairs_gather (device pack + ncclAllGather over the process's one communicator, collectives chained in submit order); rendezvous: " +
                                         ("a file, no PyTorch in the process" if rdv is not None else "torch.distributed")
                                         if gather == "library" else "torch.distributed.all_gather_into_tensor (gloo)")) if use_dist else "single GPU",
                        "value_is": "HBM-resident inputs (the driver contract); value_streamed_from_host re-runs the same loop with "
                                    "every chunk's frames DMAed from page-locked host memory",
-                       "sustained": sustained, "faithful": faithful,
+                       "sustained": sustained, "faithful": faithful, **extra,
                        "unoverlapped_pageable_upload_ms_per_chunk": round(1000 * upload_s, 2),
                        "pairs_ok_last_step": ok,
                        "mean_keypoints_last_step": round(float(res["n_kp1"].mean()), 1),
@@ -634,6 +669,15 @@ def main():
                         "measured": f"HIP events on the library's stream, {prof_steps} single-context steps right after the timed region "
                                     f"(the timed region overlaps {n_ctx} contexts); all launches of the stage in one step count as one "
                                     f"launch; traffic from profiles/{pmc_file}"}
+            # algorithmic bytes of one frame pair (its own accounting, from the level sizes) x pairs/s / peak
+            Ppx = fe.stage_bytes("fast_score_nms", 1) if not sift else 0.0
+            e2e = None
+            if Ppx:
+                N = float(args.nfeatures)
+                frame_b = fe.stage_bytes("pyramid_resize", 1) + 3.0 * Ppx + (2 * N * 49 + N * 749 + N * 961) + N * 60
+                pair_b = (frame_b if args.workload == "sequence" else 2 * frame_b) + (2 * N * 32 + 16 * N) + 65 * N
+                e2e = {"algorithmic_bytes_per_pair": int(pair_b), "mode": "streaming sequence (frame + matcher + geometry)" if args.workload == "sequence" else "independent pairs (2 x frame + matcher + geometry)",
+                       "achieved": round(pair_b * value / 1e9, 1), "unit": "GB/s", "frac": round(pair_b * value / (HBM_PEAK_GBS * 1e9), 4)}
             dom = max((k for k in per_step if k != "misc"), key=lambda k: per_step[k])
             hbm_dom = max((k for k in per_step if STAGE_BOUND.get(k) == "hbm"), key=lambda k: per_step[k], default=None)
             if STAGE_BOUND.get(dom) == "hbm":
@@ -647,7 +691,9 @@ def main():
                                             "for the dominant streaming kernel and DESIGN.md section 6"}
                 if hbm_dom:
                     line["roofline_hbm"] = hbm_entry(hbm_dom)
-            insts = pmc_sum(args.detector, dom, "valu_wave_insts_per_launch")
+            if e2e:
+                line["roofline"]["achieved_end_to_end"] = e2e
+            insts = pmc_sum(args.detector, dom, "valu_wave_insts_per_launch", NF)
             if insts:
                 # issue bound: tools/ubench/valu_rates.hip (asm volatile) measures ~4.3 clk per wave-instruction and SIMD for the
                 # packed-16 / perm / min-max / shift / 3-operand class and ~2.5 clk for add / xor / mov / f32; `mix_weighted` prices
@@ -658,8 +704,11 @@ def main():
                         "measured_class_rates_Tlaneops": {"pk16_perm_minmax_shift_dot_3op": 36.6, "add_xor_mov_f32": 60.0},
                         "frac_of_physical_peak": round(rate / VALU_PEAK_T, 3),
                         "note": "SQ_INSTS_VALU (committed PMC pass) x 64 lanes / event time"}
-                if dom == "fast_score_nms":
-                    mix_ms = (0.855 * insts * 64 / 36.6e12 + 0.145 * insts * 64 / 60.0e12) * 1e3
+                mix = (_pmc(args.detector)[0] or {}).get("_meta", {}).get("isa_mix", {}).get(STAGE_KERNELS[dom][0][0]) if dom in STAGE_KERNELS else None
+                if mix:                                   # the kernel's own opcode classes (tools/isa_mix.py --json on the build's ISA, stored with the counters)
+                    hr, fr = mix["half_rate_class_frac"], mix["full_rate_class_frac"]
+                    mix_ms = (hr * insts * 64 / 36.6e12 + fr * insts * 64 / 60.0e12) * 1e3
+                    valu["isa_class_mix"] = {"pk16_perm_minmax_shift_dot_3op": hr, "add_xor_mov_f32": fr, "source": "tools/isa_mix.py (static, per opcode of the kernel body)"}
                     valu["mix_weighted_issue_bound_ms"] = round(mix_ms, 4)
                     valu["frac_of_mix_weighted_bound"] = round(mix_ms / per_step[dom], 3)
                 line["roofline"]["valu"] = valu

@@ -212,6 +212,10 @@ int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K,
  * latency-bound RANSAC / pose kernels. */
 int vo_pairs_run_async(vo_ctx* ctx, const int32_t* pair_slots, int B, const double* K, const vo_pair_opts* opts,
                        vo_pair_result* results, double* X, int32_t x_cap);
+/* The synchronous forms (vo_frames_detect, vo_pairs_run) return VO_WARN_CAPACITY (> 0, results valid) when a keypoint list of an
+ * involved slot hit its capacity: the batched SIFT path cuts such a frame at kp_cap in cv2's list order — x ascending, i.e. the
+ * right edge of the image goes first — so E-RANSAC would run on a one-sided set; raise kp_cap.  The asynchronous forms cannot
+ * know: vo_frame_features[_sift] reports the flag per slot. */
 int vo_sync(vo_ctx* ctx);
 /* Orders ctx's next enqueued work after `other`'s most recent vo_frames_detect_async (same device).  Chaining the
  * detections of two contexts keeps them out of phase: one's RANSAC / pose always runs beside the other's ORB. */
@@ -231,9 +235,9 @@ int vo_comm_unique_id(uint8_t id[VO_COMM_ID_BYTES]);
 int vo_comm_init(vo_ctx* ctx, const uint8_t id[VO_COMM_ID_BYTES], int rank, int world);
 int vo_comm_destroy(vo_ctx* ctx);
 /* One communicator per PROCESS: further contexts of the same GPU (the chunk pipeline alternates over several) join the
- * one `owner` created instead of creating their own.  All collectives of the process are issued on the communicator's
- * own stream in host submit order (the same order on every rank) and tied to the calling context's stream with events,
- * so two collectives are never in flight at once.  vo_comm_destroy drops a context's reference; the last one destroys
+ * one `owner` created instead of creating their own.  A collective runs on the calling context's stream, after an event wait
+ * for the collective submitted before it (by whichever context): the process's collectives execute one at a time in host
+ * submit order (the same order on every rank).  vo_comm_destroy drops a context's reference; the last one destroys
  * the communicator.  vo_comm_info: ncclCommCount and this process's rank (1 and 0 without a communicator). */
 int vo_comm_share(vo_ctx* ctx, vo_ctx* owner);
 int vo_comm_info(vo_ctx* ctx, int32_t* n_ranks, int32_t* rank);

@@ -12,7 +12,7 @@ infrastructure (uses the oracle's pyramid); writes the table that profiles/r04_k
 """
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/scripts/ -> repo root
 sys.path.insert(0, ROOT)
 from oracle import oracle as O                       # noqa: E402
 from visual_odometry_amd import synth                # noqa: E402

@@ -168,8 +168,13 @@ def test_sift_capacity_is_flagged(oracle):
     img = random_image(3, 240, 320)
     want = oracle.sift_detect_and_compute(img)
     assert want["n_found"] > 300
-    fe = F.FrontEnd(240, 320, max_frames=1, max_pairs=1, detector="sift", kp_cap=256)
-    fe.upload(img[None]); fe.detect(0, 1)
+    fe = F.FrontEnd(240, 320, max_frames=2, max_pairs=1, detector="sift", kp_cap=256)
+    fe.upload(np.stack([img, img]))
+    with pytest.warns(RuntimeWarning, match="capacity"):                 # vo_frames_detect returns VO_WARN_CAPACITY ...
+        fe.detect(0, 2)
+    with pytest.warns(RuntimeWarning, match="capacity"):                 # ... and so does vo_pairs_run for a pair that involves the slot
+        res, _ = fe.run_pairs([[0, 1]], np.array([[300.0, 0, 160], [0, 300.0, 120], [0, 0, 1]]))
+    assert res["n_kp1"][0] == 256 and res["n_kp2"][0] == 256            # the kept count, not the uncapped one
     got = fe.features(0)
     assert got["truncated"] and len(got["xy"]) == 256
     for k in KEYS:                                                       # truncated in cv2's list order: a prefix of the full list

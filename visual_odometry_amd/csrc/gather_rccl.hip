@@ -3,8 +3,8 @@
 // Frame pairs are independent, so ranks (one process per GPU) share nothing while they detect, match and solve; at the
 // end of a batch every rank contributes its per-pair records ([R|t] + counts, 16 float64 = 128 B per pair) to ONE
 // ncclAllGather over RCCL / xGMI.  The records are packed on the device straight from the batch's result array
-// (vo_pair_result, in HBM) and gathered on the process's ONE communicator stream, ordered against the context's own stream
-// with events — no host bounce, no torch tensors.  RCCL is
+// (vo_pair_result, in HBM) and gathered over the process's ONE communicator on the context's own stream, each collective
+// ordered behind the previous one with an event — no host bounce, no torch tensors.  RCCL is
 // bound at run time (dlopen: the copy already loaded by the process if there is one), so libvo_hip.so has no link
 // dependency on it and single-GPU users never load it.
 #include "vo_internal.h"

@@ -545,6 +545,22 @@ __device__ __forceinline__ int fast_score_or_zero(const uint8_t* c, int t)      
 // DENSE = true writes the score map (the stage API / tests); false (the pipeline) writes, per tile, the list of NMS
 // winners inside the border as (score << 16 | row in tile << 8 | column in tile) and their number: retainBest then
 // works on a few thousand entries per frame instead of scanning 2.9 M score bytes twice.
+#ifdef FT_STATS
+// Diagnostic build only (tools/experiments/fast_stats.sh, never the product library): how many groups / pixels reach each phase.
+// [0] tiles, [1] groups with a pre-test survivor, [2] pre-test survivors (pixel queue), [3] FAST corners, [4] listed NMS winners,
+// [5] phase-C iterations (128 candidates each), [6] tiles that overflowed the queue
+__device__ unsigned long long g_ft_stats[8];
+extern "C" int vo_debug_fast_stats(unsigned long long* out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ft_stats), sizeof(g_ft_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ft_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define FT_STAT(i, v) do { if (lane == 0) atomicAdd(&g_ft_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define FT_STAT(i, v) do { } while (0)
+#endif
+
 template <bool DENSE>
 __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score, uint32_t* hist, PyrGeom g,
                                              uint32_t* tile_list, int* tile_count)
@@ -712,6 +728,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
 
     int nw = 0;                                       // wave-uniform number of listed winners
     uint32_t* my_list = DENSE ? nullptr : tile_list + ((size_t)f * g.ftiles_total + bid) * FT_LISTCAP;
+    FT_STAT(0, 1); FT_STAT(1, gn); FT_STAT(2, qn); FT_STAT(5, (qn + 127) / 128); FT_STAT(6, qn > FT_QCAP);
     if (qn <= FT_QCAP) {
         // C. cornerScore for the queued candidates, two per lane (two independent chains of LDS reads in flight);
         //    the real corners (about 40 % of the candidates) are compacted in place at the front of the queue
@@ -735,6 +752,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
             nc += na + (int)__popcll(mb);
         }
         __syncthreads();
+        FT_STAT(3, nc);
 #if defined(FT_STOP_AFTER) && FT_STOP_AFTER == 4
         if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = nc + s_q[0]; return;
 #endif
@@ -803,6 +821,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         __syncthreads();
     }
     if (!DENSE) {
+        FT_STAT(4, nw);
         if (lane == 0) tile_count[(size_t)f * g.ftiles_total + bid] = nw;
         return;
     }

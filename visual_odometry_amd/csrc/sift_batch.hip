@@ -185,7 +185,10 @@ __device__ __forceinline__ float4 sb_base_finish(const SiftBaseSrc& B, uint2 raw
                        (float)__builtin_amdgcn_udot4(p1, We, 0u, false) * s, (float)__builtin_amdgcn_udot4(p3, W3, 0u, false) * s);
 }
 
-// ------------------------------------------------------------------ one scale-space layer: Gaussian blur + DoG, one sweep
+// ------------------------------------------------------------------ one scale-space layer: Gaussian blur, one sweep
+// (The DoG planes are never stored: D[i] = G[i + 1] - G[i] is ONE IEEE subtraction of two stored values, so the extrema search
+//  and the refinement subtract where they read — bit-identical to buildDoGPyramid's stored planes, 3 of 19 plane transfers per
+//  octave less, 40 % less scratch per frame.)
 #define SW_TW 128                      // columns of a strip
 #define SW_RS 8                        // source rows per step
 #define SW_THREADS 256
@@ -193,14 +196,8 @@ struct SiftTaps { int n; float k[SIFT_MAX_TAPS]; };
 
 // N > 0: tap count known at compile time (windows in registers); N == 0: any odd tap count <= SW_NMAX, taken from t.n
 #define SW_NMAX 63
-#ifndef SW_CTR_MAXN
-#define SW_CTR_MAXN 63                 // tap counts above this read the centre again from L2 instead (frees LDS: more workgroups per CU)
-#endif
 #ifndef SW_VGPR_TAPS
 #define SW_VGPR_TAPS 21
-#endif
-#ifndef SW_CTR_LDS
-#define SW_CTR_LDS 1                   // (measured: 7.87 vs 8.64 ms per 64 frames) 1: the source rows' centre columns wait in an LDS ring for the DoG; 0: they are read again (L2) when the row is written
 #endif
 template <int N>
 struct SweepDims {
@@ -210,13 +207,11 @@ struct SweepDims {
     static constexpr int INW = SW_TW + 2 * R4;                  // floats of a source row segment (starts 16-byte aligned)
     static constexpr int INP = INW + 4;                          // LDS pitch of s_in
     static constexpr int RING = (NN + SW_RS - 1 + 7) & ~7;       // row-filtered rows kept
-    static constexpr int CRING = (R + SW_RS + 7) & ~7;           // source centre rows kept (for the DoG)
-    static constexpr bool CTR = SW_CTR_LDS && NN <= SW_CTR_MAXN;
-    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW + (CTR ? CRING * SW_TW : 0);
+    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW;
 };
 
 template <int N, bool BASE>
-__global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs,
+__global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_t src_fs, float* dstG, size_t g_fs,
                                                          int w, int h, int stride, int seg, SiftTaps t, float* dstH, size_t h_fs, int hstride, int hw, int hh,
                                                          SiftBaseSrc B)
 {
@@ -237,17 +232,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     const int R4 = N > 0 ? DM::R4 : ((r + 3) & ~3);
     const int INW = SW_TW + 2 * R4, INP = INW + 4;
     const int RING = N > 0 ? DM::RING : ((n + SW_RS - 1 + 7) & ~7);
-    const int CRING = N > 0 ? DM::CRING : ((r + SW_RS + 7) & ~7);
     float* s_in = s_dyn;                                   // [SW_RS][INP]
     float* s_ring = s_in + SW_RS * INP;                    // [RING][SW_TW]
-    float* s_ctr = s_ring + RING * SW_TW;                  // [CRING][SW_TW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * SW_TW, Y0 = blockIdx.y * seg, Y1 = min(h, Y0 + seg);
     if (Y0 >= h) return;
     if (!BASE) src += (size_t)blockIdx.z * src_fs;
     const uint8_t* bimg = BASE ? B.img + (size_t)blockIdx.z * B.frame_stride : nullptr;    // BASE: the source is the 2 x up-sampled input image, made here
-    if (dstG) dstG += (size_t)blockIdx.z * g_fs;
-    if (dstD) dstD += (size_t)blockIdx.z * d_fs;
+    dstG += (size_t)blockIdx.z * g_fs;
     if (dstH) dstH += (size_t)blockIdx.z * h_fs;      // the next octave's first image: this layer at half size (INTER_NEAREST: every other pixel of every other row)
     const int xa = x0 - R4;                                // first source column of a segment (multiple of 4)
     const bool interior = xa >= 0 && xa + INW <= w;        // whole segments inside the image: aligned 16-byte loads, no reflection
@@ -298,7 +290,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
         }
         if (k + 1 < nsteps) issue(k + 1);                  // in flight during this step's arithmetic
         __syncthreads();
-        // ---- row pass: s_in row rrow -> ring row (k * 8 + rrow); the source centre values go to their own ring
+        // ---- row pass: s_in row rrow -> ring row (k * 8 + rrow)
         {
             const int seq = k * SW_RS + rrow;
             const float* in = s_in + rrow * INP + rx4;
@@ -315,7 +307,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[q] += tk[i] * win[WO + i + q];
                 }
-                if (DM::CTR) *(float4*)(s_ctr + (seq % DM::CRING) * SW_TW + rx4) = make_float4(win[DM::R4], win[DM::R4 + 1], win[DM::R4 + 2], win[DM::R4 + 3]);
                 *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             } else {
 #pragma unroll
@@ -324,7 +315,6 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[q] += t.k[i] * in[woff + i + q];
                 }
-                if (DM::CTR) *(float4*)(s_ctr + (seq % CRING) * SW_TW + rx4) = make_float4(in[R4], in[R4 + 1], in[R4 + 2], in[R4 + 3]);
                 *(float4*)(s_ring + (seq % RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
@@ -359,20 +349,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
                             acc[q] += t.k[r + i] * (*(const v2f*)(s_ring + ((rb0 + r + q + i) % RING) * SW_TW + cc) + *(const v2f*)(s_ring + ((rb0 + r + q - i) % RING) * SW_TW + cc));
                     }
                 }
-                const int cb0 = (m0 + r + 4 * CRING) % CRING;
                 const bool two = x + 1 < w;
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int m = m0 + q, y = Y0 + m;
                     if (m >= 0 && y < Y1) {
                         const size_t o = (size_t)y * stride + x;
-                        v2f dg;
-                        if (dstD) {
-                            if (DM::CTR) { int ci = cb0 + q; ci = ci >= CRING ? ci - CRING : ci; dg = acc[q] - *(const v2f*)(s_ctr + ci * SW_TW + cc); }
-                            else { dg.x = acc[q].x - src[o]; dg.y = two ? acc[q].y - src[o + 1] : 0.f; }     // this workgroup streamed the row through a moment ago: an L2 hit
-                        }
-                        if (two) { if (dstG) *(v2f*)(dstG + o) = acc[q]; if (dstD) *(v2f*)(dstD + o) = dg; }
-                        else { if (dstG) dstG[o] = acc[q].x; if (dstD) dstD[o] = dg.x; }
+                        if (two) *(v2f*)(dstG + o) = acc[q];
+                        else dstG[o] = acc[q].x;
                         // (row y of q = 0 and column x are even: steps, segments and a thread's column pair start at even indices)
                         if (dstH && q == 0 && (y >> 1) < hh && (x >> 1) < hw) dstH[(size_t)(y >> 1) * hstride + (x >> 1)] = acc[0].x;
                     }
@@ -395,8 +379,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #define EX_SEG 256                    // rows per wavefront sweep (32 / 64 / 128 / 256 / 512: 2.74 / 2.25 / 1.99 / 1.77 / 1.95 ms per 64 frames: fewer halo rows, longer streams; then too few waves)
 #endif
 #define EX_MAXP 10                     // DoG planes of an octave (nOctaveLayers + 2 <= 10)
+// NP = DoG planes of the octave; the kernel reads the NP + 1 Gaussian planes and forms D[pl] = G[pl + 1] - G[pl] in registers.
 template <int NP>
-__global__ __launch_bounds__(256) void k_sb_extrema(const float* dog, size_t d_fs, size_t plane, int w, int h, int stride, int o,
+__global__ __launch_bounds__(256) void k_sb_extrema(const float* gauss, size_t g_fs, size_t plane, int w, int h, int stride, int o,
                                                     float threshold, SiftCand* cand, int* counts /*[F][4]*/, int cap)
 {
     const int f = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -404,13 +389,16 @@ __global__ __launch_bounds__(256) void k_sb_extrema(const float* dog, size_t d_f
     const int c = SIFT_IMG_BORDER + strip * EX_COLS + lane - 1;       // this lane's column (lane 0 / 63: halo)
     if (SIFT_IMG_BORDER + strip * EX_COLS >= w - SIFT_IMG_BORDER) return;
     const int ys = SIFT_IMG_BORDER + blockIdx.y * EX_SEG, ye = min(ys + EX_SEG, h - SIFT_IMG_BORDER);      // output rows [ys, ye)
-    const float* D = dog + (size_t)f * d_fs + min(c, w - 1);
+    const float* D = gauss + (size_t)f * g_fs + min(c, w - 1);
     const bool out_lane = lane >= 1 && lane <= EX_COLS && c < w - SIFT_IMG_BORDER;
     float hmx[3][NP], hmn[3][NP], ctr[3][NP], nxt[NP];
     auto load = [&](int y) {
         const float* p = D + (size_t)min(y, h - 1) * stride;
+        float gv[NP + 1];
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) nxt[pl] = p[(size_t)pl * plane];
+        for (int pl = 0; pl <= NP; pl++) gv[pl] = p[(size_t)pl * plane];
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) nxt[pl] = gv[pl + 1] - gv[pl];
     };
     auto rowext = [&](int slot) {                         // nxt -> slot: the 3-wide extremes of the row just loaded
 #pragma unroll
@@ -448,7 +436,7 @@ __global__ __launch_bounds__(256) void k_sb_extrema(const float* dog, size_t d_f
 }
 
 // ------------------------------------------------------------------ refinement
-__global__ __launch_bounds__(64) void k_sb_refine(SiftGeom P, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr, float edgeThr,
+__global__ __launch_bounds__(64) void k_sb_refine(SiftGeom P, const float* gauss, const SiftCand* cand, int cand_cap, float contrastThr, float edgeThr,
                                                   float sigma, SiftSurv* surv, int surv_cap, int* counts)
 {
     const int f = blockIdx.y, id = blockIdx.x * 64 + threadIdx.x;
@@ -458,11 +446,12 @@ __global__ __launch_bounds__(64) void k_sb_refine(SiftGeom P, const float* dog, 
     const int o = cd.o, nLayers = P.nLayers, w = P.w[o], h = P.h[o], st = P.stride[o];
     int layer = cd.layer, r = cd.r, c = cd.c;
     const size_t plane = P.plane[o];
-    const float* dbase = dog + (size_t)f * P.dframe + P.doff[o];
+    const float* gbase = gauss + (size_t)f * P.gframe + P.goff[o];
     const float img_scale = 1.f / 255.f, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
     float xi = 0, xr = 0, xc = 0;
     int i = 0;
-#define D(L, rr, cc) dbase[(size_t)(L) * plane + (size_t)(rr) * st + (cc)]
+    // DoG sample = the one subtraction buildDoGPyramid stores (G[L + 1] - G[L]), made where it is read
+#define D(L, rr, cc) (gbase[(size_t)((L) + 1) * plane + (size_t)(rr) * st + (cc)] - gbase[(size_t)(L) * plane + (size_t)(rr) * st + (cc)])
     for (; i < SIFT_MAX_INTERP_STEPS; i++) {
         const float dD0 = (D(layer, r, c + 1) - D(layer, r, c - 1)) * deriv_scale, dD1 = (D(layer, r + 1, c) - D(layer, r - 1, c)) * deriv_scale,
                     dD2 = (D(layer + 1, r, c) - D(layer - 1, r, c)) * deriv_scale;
@@ -1026,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_sb_unpack(const SiftKp* kps, int kp_cap
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     const int nk = min(counts[4 * f + 3], kp_cap);
     const size_t slot = (size_t)(first_slot + f);
-    if (i == 0) { kp_count[slot] = fin_count[f]; flags[slot] = fin_flags[f]; }
+    if (i == 0) { kp_count[slot] = min(fin_count[f], kp_cap); flags[slot] = fin_flags[f]; }      // the kept count: overflow is flags bit 0
     if (i >= nk) return;
     const SiftKp k = kps[(size_t)f * kp_cap + i];
     const size_t o = slot * kp_cap + i;
@@ -1035,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_sb_unpack(const SiftKp* kps, int kp_cap
 
 // ------------------------------------------------------------------ launchers
 template <int N, bool BASE>
-static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F, const SiftTaps& t,
+static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, int w, int h, int stride, int F, const SiftTaps& t,
                     float* dstH, size_t h_fs, int hstride, int hw, int hh, const SiftBaseSrc& B)
 {
     // segments: tall enough that the 2 r halo rows stay a small fraction, short enough that a small batch still fills the chip
@@ -1044,11 +1033,11 @@ static void sweep_n(hipStream_t s, const float* src, size_t src_fs, float* dstG,
     while (seg > 64 && (long long)strips * ((h + seg - 1) / seg) * F < 2048) seg >>= 1;
     const int n = N > 0 ? N : t.n, r = n / 2, R4 = (r + 3) & ~3;
     const size_t lds = N > 0 ? (size_t)SweepDims<N>::LDS_FLOATS * 4
-                             : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + (((n + SW_RS - 1 + 7) & ~7) + (SweepDims<0>::CTR ? ((r + SW_RS + 7) & ~7) : 0)) * SW_TW) * 4;
-    hipLaunchKernelGGL((k_sb_sweep<N, BASE>), dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, seg, t, dstH, h_fs, hstride, hw, hh, B);
+                             : (size_t)(SW_RS * (SW_TW + 2 * R4 + 4) + ((n + SW_RS - 1 + 7) & ~7) * SW_TW) * 4;
+    hipLaunchKernelGGL((k_sb_sweep<N, BASE>), dim3(strips, (h + seg - 1) / seg, F), dim3(SW_THREADS), lds, s, src, src_fs, dstG, g_fs, w, h, stride, seg, t, dstH, h_fs, hstride, hw, hh, B);
 }
 
-int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
+int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, int w, int h, int stride, int F,
                     const float* taps, int ntaps, float* dstH, size_t h_fs, int hstride, int hw, int hh)
 {
     if (ntaps < 1 || ntaps > SW_NMAX || !(ntaps & 1)) return -1;
@@ -1056,10 +1045,10 @@ int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG,
     for (int i = 0; i < SIFT_MAX_TAPS; i++) t.k[i] = i < ntaps ? taps[i] : 0.f;
     const SiftBaseSrc none = {nullptr, 0, 0, 0, 0, 0};
     switch (ntaps) {                                        // the sizes cv2's defaults produce are 11, 13, 17, 21, 27
-#define SW_CASE(N) case N: sweep_n<N, false>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh, none); break;
+#define SW_CASE(N) case N: sweep_n<N, false>(s, src, src_fs, dstG, g_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh, none); break;
         SW_CASE(11) SW_CASE(13) SW_CASE(17) SW_CASE(21) SW_CASE(27)
 #undef SW_CASE
-        default: sweep_n<0, false>(s, src, src_fs, dstG, g_fs, dstD, d_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh, none);
+        default: sweep_n<0, false>(s, src, src_fs, dstG, g_fs, w, h, stride, F, t, dstH, h_fs, hstride, hw, hh, none);
     }
     return 0;
 }
@@ -1072,28 +1061,28 @@ int launch_sb_sweep_base(hipStream_t s, const uint8_t* img, int channels, int ro
     SiftTaps t; t.n = ntaps;
     for (int i = 0; i < SIFT_MAX_TAPS; i++) t.k[i] = i < ntaps ? taps[i] : 0.f;
     const SiftBaseSrc B = {img, channels, row_stride, sw, sh, (long long)frame_stride};
-    if (ntaps == 11) sweep_n<11, true>(s, nullptr, 0, dstG, g_fs, nullptr, 0, 2 * sw, 2 * sh, stride, F, t, nullptr, 0, 0, 0, 0, B);
-    else sweep_n<0, true>(s, nullptr, 0, dstG, g_fs, nullptr, 0, 2 * sw, 2 * sh, stride, F, t, nullptr, 0, 0, 0, 0, B);
+    if (ntaps == 11) sweep_n<11, true>(s, nullptr, 0, dstG, g_fs, 2 * sw, 2 * sh, stride, F, t, nullptr, 0, 0, 0, 0, B);
+    else sweep_n<0, true>(s, nullptr, 0, dstG, g_fs, 2 * sw, 2 * sh, stride, F, t, nullptr, 0, 0, 0, 0, B);
     return 0;
 }
 
-void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o, float threshold, SiftCand* cand, int* counts, int cap, int F)
+void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* gauss, int o, float threshold, SiftCand* cand, int* counts, int cap, int F)
 {
     const int w = P.w[o], h = P.h[o];
     if (w <= 2 * SIFT_IMG_BORDER || h <= 2 * SIFT_IMG_BORDER) return;
     const int strips = (w - 2 * SIFT_IMG_BORDER + EX_COLS - 1) / EX_COLS;
     const dim3 grid((strips + 3) / 4, (h - 2 * SIFT_IMG_BORDER + EX_SEG - 1) / EX_SEG, F);
     switch (P.nLayers + 2) {
-#define EX_CASE(NP) case NP: hipLaunchKernelGGL(k_sb_extrema<NP>, grid, dim3(256), 0, s, dog + P.doff[o], P.dframe, P.plane[o], w, h, P.stride[o], o, threshold, cand, counts, cap); break;
+#define EX_CASE(NP) case NP: hipLaunchKernelGGL(k_sb_extrema<NP>, grid, dim3(256), 0, s, gauss + P.goff[o], P.gframe, P.plane[o], w, h, P.stride[o], o, threshold, cand, counts, cap); break;
         EX_CASE(3) EX_CASE(4) EX_CASE(5) EX_CASE(6) EX_CASE(7) EX_CASE(8) EX_CASE(9) EX_CASE(10)
 #undef EX_CASE
     }
 }
 
-void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr,
+void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const SiftCand* cand, int cand_cap, float contrastThr,
                              float edgeThr, float sigma, const SiftExpTab& E, SiftSurv* surv, int surv_cap, SiftKp* kps, int kp_cap, int* counts, int F, int waves)
 {
-    hipLaunchKernelGGL(k_sb_refine, dim3((cand_cap + 63) / 64, F), dim3(64), 0, s, P, dog, cand, cand_cap, contrastThr, edgeThr, sigma, surv, surv_cap, counts);
+    hipLaunchKernelGGL(k_sb_refine, dim3((cand_cap + 63) / 64, F), dim3(64), 0, s, P, gauss, cand, cand_cap, contrastThr, edgeThr, sigma, surv, surv_cap, counts);
     hipLaunchKernelGGL(k_sb_orient, dim3(waves, F), dim3(64), 0, s, P, gauss, surv, surv_cap, E, kps, kp_cap, counts);
 }
 

@@ -22,18 +22,21 @@ struct SiftState {
     uint8_t* frames = nullptr;                                    // [slot][h][fstride] gray
     float *kp_xy = nullptr, *kp_size = nullptr, *kp_angle = nullptr, *kp_resp = nullptr; int *kp_oct = nullptr, *kp_count = nullptr, *flags = nullptr;
     uint8_t *desc = nullptr, *desc_x = nullptr; int* norms = nullptr;   // [slot][kp_cap][128] u8; int8 operand image + |v - 128|^2 for the matrix-core matcher
-    float *G = nullptr, *D = nullptr, *up = nullptr;              // sub-batch scratch: Gaussian / DoG pyramids, the up-sampled base image
+    float *G = nullptr, *up = nullptr;                            // sub-batch scratch: the Gaussian pyramids (the DoG planes are never stored)
     SiftCand* cand = nullptr; SiftSurv* surv = nullptr; SiftKp *kraw = nullptr, *ksorted = nullptr, *kfin = nullptr;
     int *rank = nullptr, *counts = nullptr, *fin_count = nullptr, *fin_flags = nullptr;
 };
 
-// The process's RCCL communicator and the stream all of its collectives are issued on.  Every context of the GPU holds a
-// reference; collectives of different contexts therefore run one after the other, in the order the host submitted them
-// (the same on every rank), never two at once.
+// The process's ONE RCCL communicator.  Every context of the GPU holds a reference and issues its collectives on its own
+// stream, but each collective first waits (event) for the one submitted before it, whichever context that was: collectives
+// run one after the other in the order the host submitted them (the same on every rank), never two at once.
+// (A dedicated communicator stream was tried first: with 3 context streams it shares a hardware queue with one of them and
+//  cost 9 % of the single-GPU rate — 76.4 k vs 83.7 k pairs/s — through false serialisation.)
 struct CommShared {
     void* comm = nullptr;
     int rank = 0, world = 1, refs = 0;
-    hipStream_t stream = nullptr;
+    hipEvent_t last = nullptr;            // end of the most recently submitted collective
+    bool last_set = false;
 };
 
 struct vo_ctx {
@@ -96,7 +99,6 @@ struct vo_ctx {
     int descx_fp4 = 0;                    // operand image the resident frames' desc_x currently holds (written at detection)
     int matcher_kernel = 2;               // 2: block-scaled FP4 MFMA (default), 0: int8 MFMA on +127/-127 bytes, 1: XOR + popcount
     CommShared* cs = nullptr;             // RCCL communicator of the trajectory gather: ONE per process, shared by its contexts (vo_comm_share)
-    hipEvent_t ev_gather[2] = {nullptr, nullptr};                     // ctx stream -> communicator stream -> ctx stream
     double *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0;
     int kp_order = 1;                     // 1 (default): cv2's retainBest order — keypoint / match indices as cv2 numbers them; 0: canonical (octave, y, x)
     Cv2Buf cv2{};
@@ -325,7 +327,7 @@ static void comm_release(vo_ctx* ctx);
 static int sift_frames_upload_enqueue(vo_ctx* ctx, const uint8_t* frames, int F, int row_stride, int64_t frame_stride, int first_slot);
 static int sift_frames_detect_enqueue(vo_ctx* ctx, int first_slot, int F);
 
-extern "C" int vo_version(void) { return 110; }
+extern "C" int vo_version(void) { return 120; }
 
 extern "C" int vo_create(int device_id, vo_ctx** out)
 {
@@ -390,7 +392,6 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     for (int i = 0; i < 2; i++) if (ctx->ev_jpg[i]) (void)hipEventDestroy(ctx->ev_jpg[i]);
     for (int i = 0; i < 2; i++) if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
     comm_release(ctx);
-    for (int i = 0; i < 2; i++) if (ctx->ev_gather[i]) (void)hipEventDestroy(ctx->ev_gather[i]);
     if (ctx->rec_send) (void)hipFree(ctx->rec_send);
     if (ctx->rec_recv) (void)hipFree(ctx->rec_recv);
     if (ctx->rng_host) (void)hipHostFree(ctx->rng_host);
@@ -749,6 +750,21 @@ extern "C" int vo_detect_after(vo_ctx* ctx, vo_ctx* other)
     return VO_OK;
 }
 
+// VO_WARN_CAPACITY if a keypoint / candidate list of one of the given slots overflowed (flags bit 0) — after a stream sync.
+// SIFT cuts an over-full frame at kp_cap in cv2's list order (x ascending after removeDuplicatedSorted): the keypoints at the
+// right edge of the image are the ones lost, so a caller should know before it trusts the pose of such a pair.
+static int capacity_warning(vo_ctx* ctx, const int32_t* slots, int n, int first_slot, int F)
+{
+    const int* dflags = ctx->detector == 1 ? ctx->sift.flags : ctx->ff.flags;
+    const int mf = batch_max_frames(ctx);
+    if (!dflags || mf <= 0) return VO_OK;
+    std::vector<int> fl((size_t)mf);
+    HIPCHK(hipMemcpy(fl.data(), dflags, (size_t)mf * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < F; i++) if (fl[(size_t)first_slot + i] & 1) return VO_WARN_CAPACITY;
+    for (int i = 0; i < n; i++) if (fl[(size_t)slots[i]] & 1) return VO_WARN_CAPACITY;
+    return VO_OK;
+}
+
 extern "C" int vo_frames_detect(vo_ctx* ctx, int first_slot, int F)
 {
     if (!ctx) return VO_ERR_INVALID;
@@ -757,7 +773,7 @@ extern "C" int vo_frames_detect(vo_ctx* ctx, int first_slot, int F)
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (ctx->prof) prof_collect(ctx);
-        return VO_OK;
+        return capacity_warning(ctx, nullptr, 0, first_slot, F);
     }
     if (!ctx->configured) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
     if (F < 0 || first_slot < 0 || first_slot + F > ctx->max_frames) FAIL(VO_ERR_INVALID, "slot range out of bounds");
@@ -768,7 +784,7 @@ extern "C" int vo_frames_detect(vo_ctx* ctx, int first_slot, int F)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) prof_collect(ctx);
-    return VO_OK;
+    return capacity_warning(ctx, nullptr, 0, first_slot, F);
 }
 
 extern "C" int vo_frame_features(vo_ctx* ctx, int slot, float* kp_xy, float* kp_size, float* kp_angle, float* kp_response,
@@ -1035,7 +1051,7 @@ extern "C" int vo_pairs_run(vo_ctx* ctx, const int32_t* pair_slots, int B, const
                                (size_t)n * sizeof(double), 4, hipMemcpyDeviceToHost));
         }
     }
-    return VO_OK;
+    return capacity_warning(ctx, pair_slots, 2 * B, 0, 0);
 }
 
 // Enqueue only: results (and X, which must use x_cap == vo_batch_kp_capacity) have to be page-locked
@@ -1094,9 +1110,8 @@ static void comm_release(vo_ctx* ctx)
     CommShared* cs = ctx->cs;
     ctx->cs = nullptr;
     if (!cs || --cs->refs > 0) return;
-    if (cs->stream) (void)hipStreamSynchronize(cs->stream);
+    if (cs->last) { if (cs->last_set) (void)hipEventSynchronize(cs->last); (void)hipEventDestroy(cs->last); }
     if (cs->comm) rccl_comm_destroy(cs->comm);
-    if (cs->stream) (void)hipStreamDestroy(cs->stream);
     delete cs;
 }
 
@@ -1108,9 +1123,9 @@ extern "C" int vo_comm_init(vo_ctx* ctx, const uint8_t* id, int rank, int world)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     comm_release(ctx);
     CommShared* cs = new CommShared();
-    if (hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking) != hipSuccess) { delete cs; FAIL(VO_ERR_HIP, "no stream for the communicator"); }
+    if (hipEventCreateWithFlags(&cs->last, hipEventDisableTiming) != hipSuccess) { delete cs; FAIL(VO_ERR_HIP, "no event for the communicator"); }
     const char* e = rccl_comm_init(&cs->comm, id, rank, world);
-    if (e) { (void)hipStreamDestroy(cs->stream); delete cs; FAIL(VO_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, e); }
+    if (e) { (void)hipEventDestroy(cs->last); delete cs; FAIL(VO_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, e); }
     cs->rank = rank; cs->world = world; cs->refs = 1;
     ctx->cs = cs;
     return VO_OK;
@@ -1156,21 +1171,18 @@ extern "C" int vo_comm_info(vo_ctx* ctx, int32_t* n_ranks, int32_t* rank)
     return VO_OK;
 }
 
-// A collective of this context: whatever the ctx stream holds so far happens before it, it runs on the communicator's
-// stream behind every collective submitted earlier by any context of the process, and the ctx stream continues after it.
+// A collective of this context, on its own stream: it starts after the collective submitted before it (by any context of the
+// process) has finished, and leaves its own end behind for the next one.
 static int comm_bracket_begin(vo_ctx* ctx)
 {
-    for (int i = 0; i < 2; i++)
-        if (!ctx->ev_gather[i]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_gather[i], hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ctx->ev_gather[0], ctx->stream));
-    HIPCHK(hipStreamWaitEvent(ctx->cs->stream, ctx->ev_gather[0], 0));
+    if (ctx->cs->last_set) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->cs->last, 0));
     return VO_OK;
 }
 
 static int comm_bracket_end(vo_ctx* ctx)
 {
-    HIPCHK(hipEventRecord(ctx->ev_gather[1], ctx->cs->stream));
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_gather[1], 0));
+    HIPCHK(hipEventRecord(ctx->cs->last, ctx->stream));
+    ctx->cs->last_set = true;
     return VO_OK;
 }
 
@@ -1199,7 +1211,7 @@ extern "C" int vo_pairs_gather(vo_ctx* ctx, int B, double* gathered, int wait)
     const double* src = ctx->rec_send;
     if (ctx->cs) {
         int rc = comm_bracket_begin(ctx); if (rc) return rc;
-        const char* e = rccl_all_gather_f64(ctx->cs->comm, ctx->rec_send, ctx->rec_recv, n, ctx->cs->stream);
+        const char* e = rccl_all_gather_f64(ctx->cs->comm, ctx->rec_send, ctx->rec_recv, n, s);
         if (e) FAIL(VO_ERR_HIP, "ncclAllGather failed: %s", e);
         rc = comm_bracket_end(ctx); if (rc) return rc;
         src = ctx->rec_recv;
@@ -1222,7 +1234,7 @@ extern "C" int vo_comm_allgather_f64(vo_ctx* ctx, const double* send, int n, dou
     hipStream_t s = ctx->stream;
     HIPCHK(hipMemcpyAsync(ctx->raw_d, send, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
     rc = comm_bracket_begin(ctx); if (rc) return rc;
-    const char* e = rccl_all_gather_f64(ctx->cs->comm, ctx->raw_d, ctx->raw_d + n, (size_t)n, ctx->cs->stream);
+    const char* e = rccl_all_gather_f64(ctx->cs->comm, ctx->raw_d, ctx->raw_d + n, (size_t)n, s);
     if (e) FAIL(VO_ERR_HIP, "ncclAllGather failed: %s", e);
     rc = comm_bracket_end(ctx); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(recv, ctx->raw_d + n, (size_t)n * world * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1961,7 +1973,7 @@ static int sift_gauss_taps(double sigma, float* k)
 static void sift_free(SiftState& S)
 {
     void* ptrs[] = {S.frames, S.kp_xy, S.kp_size, S.kp_angle, S.kp_resp, S.kp_oct, S.kp_count, S.flags, S.desc, S.desc_x, S.norms,
-                    S.G, S.D, S.up, S.cand, S.surv, S.kraw, S.ksorted, S.kfin, S.rank, S.counts, S.fin_count, S.fin_flags};
+                    S.G, S.up, S.cand, S.surv, S.kraw, S.ksorted, S.kfin, S.rank, S.counts, S.fin_count, S.fin_flags};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     S = SiftState();
 }
@@ -1987,16 +1999,16 @@ static int sift_setup(vo_ctx* ctx, SiftState& S, int h, int w, const vo_sift_par
     int nOct = (int)lrint(log((double)(2 * (w < h ? w : h))) / log(2.) - 2) + 1;
     if (nOct < 1) nOct = 1;
     if (nOct > SIFT_MAX_OCT) nOct = SIFT_MAX_OCT;
-    size_t gtot = 0, dtot = 0;
+    size_t gtot = 0;
     for (int o = 0; o < nOct; o++) {
         P.w[o] = o ? P.w[o - 1] / 2 : 2 * w; P.h[o] = o ? P.h[o - 1] / 2 : 2 * h;
         if (P.w[o] < 1 || P.h[o] < 1) { nOct = o; break; }
         P.stride[o] = align_up(P.w[o], 16);
         P.plane[o] = (size_t)P.stride[o] * P.h[o];
-        P.goff[o] = gtot; P.doff[o] = dtot;
-        gtot += (size_t)(L + 2) * P.plane[o]; dtot += (size_t)(L + 2) * P.plane[o];
+        P.goff[o] = gtot;
+        gtot += (size_t)(L + 3) * P.plane[o];
     }
-    P.nOct = nOct; P.gframe = gtot; P.dframe = dtot;
+    P.nOct = nOct; P.gframe = gtot;
     // Gaussian taps of the base image (createInitialImage) and of the incremental blurs (buildGaussianPyramid)
     {
         const double k = pow(2., 1. / L);
@@ -2020,7 +2032,7 @@ static int sift_setup(vo_ctx* ctx, SiftState& S, int h, int w, const vo_sift_par
         HIPCHK(dmalloc(&S.desc_x, F * (size_t)S.cap_x * 128)); HIPCHK(dmalloc(&S.norms, F * (size_t)S.cap_x));
         HIPCHK(hipMemset(S.desc_x, 0, F * (size_t)S.cap_x * 128)); HIPCHK(hipMemset(S.norms, 0, F * (size_t)S.cap_x * sizeof(int)));
     }
-    HIPCHK(dmalloc(&S.G, B * gtot)); HIPCHK(dmalloc(&S.D, B * dtot));     // (the up-sampled base image is never stored: S.up stays null)
+    HIPCHK(dmalloc(&S.G, B * gtot));                                       // (the up-sampled base image is never stored: S.up stays null)
     HIPCHK(dmalloc(&S.cand, B * cand_cap)); HIPCHK(dmalloc(&S.surv, B * surv_cap));
     HIPCHK(dmalloc(&S.kraw, B * raw_cap)); HIPCHK(dmalloc(&S.ksorted, B * raw_cap)); HIPCHK(dmalloc(&S.kfin, B * kp_cap));
     HIPCHK(dmalloc(&S.rank, B * 4097)); HIPCHK(dmalloc(&S.counts, B * 4)); HIPCHK(dmalloc(&S.fin_count, B)); HIPCHK(dmalloc(&S.fin_flags, B));
@@ -2049,21 +2061,20 @@ static int sift_detect_enqueue(vo_ctx* ctx, SiftState& S, const uint8_t* src, in
             StageTimer t(ctx, ST_SIFT_SCALE);
             float* g0 = S.G + P.goff[o];
             for (int i = 1; i < L + 3; i++) {
-                // G[i] = blur(G[i-1]) and D[i-1] = G[i] - G[i-1] in one pass; the last Gaussian of the octave is not stored; the sweep
-                // that makes layer L also writes it at half size: the first image of the next octave (cv::resize INTER_NEAREST)
-                float* gi = i < L + 2 ? g0 + (size_t)i * P.plane[o] : nullptr;
+                // G[i] = blur(G[i-1]); the sweep that makes layer L also writes it at half size: the first image of the next
+                // octave (cv::resize INTER_NEAREST)
                 const bool seed = i == L && o + 1 < P.nOct;
-                launch_sb_sweep(s, g0 + (size_t)(i - 1) * P.plane[o], P.gframe, gi, P.gframe, S.D + P.doff[o] + (size_t)(i - 1) * P.plane[o], P.dframe,
+                launch_sb_sweep(s, g0 + (size_t)(i - 1) * P.plane[o], P.gframe, g0 + (size_t)i * P.plane[o], P.gframe,
                                 P.w[o], P.h[o], P.stride[o], F, S.taps[i], S.ntaps[i],
                                 seed ? S.G + P.goff[o + 1] : nullptr, P.gframe, seed ? P.stride[o + 1] : 0, seed ? P.w[o + 1] : 0, seed ? P.h[o + 1] : 0);
             }
         }
-        { StageTimer t(ctx, ST_SIFT_EXTREMA); launch_sb_extrema(s, P, S.D, o, threshold, S.cand, S.counts, S.cand_cap, F); }
+        { StageTimer t(ctx, ST_SIFT_EXTREMA); launch_sb_extrema(s, P, S.G, o, threshold, S.cand, S.counts, S.cand_cap, F); }
     }
     const int waves = 2048 / (F < 8 ? F : 8) > 64 ? 2048 / (F < 8 ? F : 8) : 64;        // persistent wavefronts per frame for the wave-per-item kernels
     {
         StageTimer t(ctx, ST_SIFT_ORIENT);
-        launch_sb_refine_orient(s, P, S.G, S.D, S.cand, S.cand_cap, (float)S.prm.contrast_threshold, (float)S.prm.edge_threshold, (float)S.prm.sigma, S.E,
+        launch_sb_refine_orient(s, P, S.G, S.cand, S.cand_cap, (float)S.prm.contrast_threshold, (float)S.prm.edge_threshold, (float)S.prm.sigma, S.E,
                                 S.surv, S.surv_cap, S.kraw, S.raw_cap, S.counts, F, waves);
     }
     {
@@ -2181,9 +2192,9 @@ extern "C" int vo_batch_configure_sift(vo_ctx* ctx, int h, int w, const vo_sift_
     const char* ev = getenv("VO_SIFT_SUBBATCH");
     int fb = ev ? atoi(ev) : 0;
     if (fb < 1) {
-        size_t px = 0;                                         // floats of one frame's Gaussian + DoG planes (the geometry of sift_setup)
+        size_t px = 0;                                         // floats of one plane per octave (the geometry of sift_setup)
         for (int ww = 2 * w, hh = 2 * h; ww >= 1 && hh >= 1; ww /= 2, hh /= 2) px += (size_t)align_up(ww, 16) * hh;
-        const size_t per_frame = px * 2 * (size_t)(params->n_octave_layers + 2) * sizeof(float);
+        const size_t per_frame = px * (size_t)(params->n_octave_layers + 3) * sizeof(float);
         const size_t fit = ((size_t)48 << 30) / (per_frame ? per_frame : 1);
         fb = (int)(fit < 192 ? fit : 192);
         if (fb < 1) fb = 1;
@@ -2536,16 +2547,17 @@ extern "C" const char* vo_stage_name(int stage)
 extern "C" double vo_stage_bytes(vo_ctx* ctx, int stage, int F)
 {
     if (ctx && ctx->detector == 1 && ctx->sift.configured) {
-        // SIFT: float planes.  One layer sweep reads its source plane and writes a Gaussian and a DoG plane; per octave
-        // nLayers + 2 sweeps (the last one writes no Gaussian); the base image: u8 in, float out, one blur; next-octave seeds.
+        // SIFT: float planes.  One layer sweep reads its source plane and writes a Gaussian plane; per octave nLayers + 2
+        // sweeps; the base image: u8 in, float out, one blur; next-octave seeds.  The extrema search reads the octave's nLayers + 3
+        // Gaussian planes (the DoG planes are differences made in registers, never stored).
         const SiftState& S = ctx->sift;
         const int L = S.P.nLayers;
         double px = 0;
         for (int o = 0; o < S.P.nOct; o++) px += (double)S.P.w[o] * S.P.h[o];
         const double p0 = (double)S.P.w[0] * S.P.h[0];
         double b = 0;
-        if (stage == ST_SIFT_SCALE) b = (double)S.w * S.h + 4.0 * p0 * 3 + 4.0 * px * ((L + 2) + (L + 1) + (L + 2)) + 4.0 * (px - p0) * 1.25;
-        else if (stage == ST_SIFT_EXTREMA) b = 4.0 * px * (L + 2);
+        if (stage == ST_SIFT_SCALE) b = (double)S.w * S.h + 4.0 * p0 * 3 + 4.0 * px * ((L + 2) + (L + 2)) + 4.0 * (px - p0) * 1.25;
+        else if (stage == ST_SIFT_EXTREMA) b = 4.0 * px * (L + 3);
         else if (stage == ST_MATCH_NN) b = 2.0 * S.kp_cap * 128;
         return b * F;
     }

@@ -166,15 +166,15 @@ void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride,
 #define SIFT_MAX_INTERP_STEPS 5
 #define SIFT_MAX_OCT 16
 #define SIFT_MAX_TAPS 64
-// One frame's Gaussian and DoG pyramids (floats): octave o holds nLayers + 2 Gaussian and nLayers + 2 DoG planes of w[o] x h[o]
-// with a row pitch of stride[o] floats (a multiple of 16: every row starts on a 64-byte boundary).  The (nLayers + 3)rd
-// Gaussian image of an octave is never stored: it only feeds the last DoG plane, inside the kernel that computes it.
+// One frame's Gaussian pyramid (floats): octave o holds its nLayers + 3 Gaussian planes of w[o] x h[o] with a row pitch of
+// stride[o] floats (a multiple of 16: every row starts on a 64-byte boundary).  The DoG planes are not stored: a DoG sample is
+// one subtraction of two stored Gaussian samples, made by the kernels that read it (k_sb_extrema, k_sb_refine).
 struct SiftGeom {
     int nOct, nLayers;
     int w[SIFT_MAX_OCT], h[SIFT_MAX_OCT], stride[SIFT_MAX_OCT];
     size_t plane[SIFT_MAX_OCT];                         // stride * h
-    size_t goff[SIFT_MAX_OCT], doff[SIFT_MAX_OCT];      // float offset of the octave's first plane inside a frame's block
-    size_t gframe, dframe;                              // floats per frame
+    size_t goff[SIFT_MAX_OCT];                          // float offset of the octave's first plane inside a frame's block
+    size_t gframe;                                      // floats per frame
 };
 struct SiftCand { int o, layer, r, c; };
 struct SiftKp { float x, y, size, angle, response; int octave; };
@@ -183,10 +183,10 @@ struct SiftExpTab { float tab[64]; };                   // 2^(i/64), the table o
 // per-frame counters of a sub-batch: counts[f][4] = {extrema candidates, refined extrema, oriented keypoints, final keypoints}
 int launch_sb_sweep_base(hipStream_t s, const uint8_t* img, int channels, int row_stride, int64_t frame_stride, int sw, int sh,
                          float* dstG, size_t g_fs, int stride, int F, const float* taps, int ntaps);
-int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, float* dstD, size_t d_fs, int w, int h, int stride, int F,
+int launch_sb_sweep(hipStream_t s, const float* src, size_t src_fs, float* dstG, size_t g_fs, int w, int h, int stride, int F,
                     const float* taps, int ntaps, float* dstH = nullptr, size_t h_fs = 0, int hstride = 0, int hw = 0, int hh = 0);
-void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* dog, int o, float threshold, SiftCand* cand, int* counts, int cap, int F);
-void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const float* dog, const SiftCand* cand, int cand_cap, float contrastThr,
+void launch_sb_extrema(hipStream_t s, const SiftGeom& P, const float* gauss, int o, float threshold, SiftCand* cand, int* counts, int cap, int F);
+void launch_sb_refine_orient(hipStream_t s, const SiftGeom& P, const float* gauss, const SiftCand* cand, int cand_cap, float contrastThr,
                              float edgeThr, float sigma, const SiftExpTab& E, SiftSurv* surv, int surv_cap, SiftKp* kps, int kp_cap, int* counts, int F, int waves);
 void launch_sb_sort_emit(hipStream_t s, const SiftKp* kps, int kp_cap, int* counts, int* rank /*[F][4097]*/, void* rank_tmp /*[F][kp_cap] records*/, SiftKp* sorted,
                          SiftKp* out, int out_cap, int* out_count, int* out_flags, int cand_cap, int surv_cap, int F);

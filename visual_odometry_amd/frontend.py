@@ -111,7 +111,7 @@ class FrontEnd:
         if after is not None and after is not self:
             c.check(c.lib.vo_detect_after(c.handle, after.ctx.handle))
         fn = c.lib.vo_frames_detect if wait else c.lib.vo_frames_detect_async
-        c.check(fn(c.handle, int(first_slot), int(count)))
+        self._warn_capacity(c.check(fn(c.handle, int(first_slot), int(count))))
 
     def features(self, slot):
         """Keypoints and descriptors of a detected slot.  ORB: desc [n, 32] uint8; SIFT: desc [n, 128] float32 (the integer bin
@@ -154,8 +154,14 @@ class FrontEnd:
         c = self.ctx
         fn = c.lib.vo_pairs_run if wait else c.lib.vo_pairs_run_async
         self._keep = (ps, K, opts)                  # keep the argument buffers alive until the work has been consumed
-        c.check(fn(c.handle, ps.ctypes.data, B, K.ctypes.data, C.addressof(opts), res.ctypes.data, _lib.ptr(X), self.kp_cap))
+        self._warn_capacity(c.check(fn(c.handle, ps.ctypes.data, B, K.ctypes.data, C.addressof(opts), res.ctypes.data, _lib.ptr(X), self.kp_cap)))
         return res, X
+
+    def _warn_capacity(self, rc):
+        if rc == _lib.VO_WARN_CAPACITY:
+            import warnings
+            warnings.warn("a frame's keypoint list hit its capacity and was cut (SIFT: in x order, the right edge of the image first): "
+                          "raise kp_cap; features(slot)['truncated'] names the slots", RuntimeWarning, stacklevel=3)
 
     def wait(self):
         c = self.ctx

@@ -143,9 +143,8 @@ class LibraryCollectives:
 
 def init_library_comm(front_ends, rdv, rank, world):
     """ONE RCCL communicator per process: the first context creates it (its id travels from rank 0 through the file
-    rendezvous), the other contexts of the GPU share it (vo_comm_share).  Their all-gathers are issued on the
-    communicator's own stream in submit order — the same order on every rank — so no two collectives of a process are ever
-    in flight at once."""
+    rendezvous), the other contexts of the GPU share it (vo_comm_share).  Every all-gather waits (event) for the one
+    submitted before it — the same order on every rank — so no two collectives of a process are ever in flight at once."""
     first = front_ends[0].ctx
     ident = rdv.broadcast(first.comm_unique_id() if rank == 0 else b"", name="rccl_id")
     first.comm_init(ident, rank, world)
