@@ -350,6 +350,27 @@ int vo_frames_ingest(vo_ctx* ctx, const uint8_t* frames, int F, int sh, int sw, 
 int vo_feature_tracks(vo_ctx* ctx, int F, int cap, const int32_t* pair_frames, const int32_t* match_off,
                       const int32_t* mq, const int32_t* mt, int P, int32_t* root_frame, int32_t* root_idx, int32_t* hops);
 
+/* The step after the pair path ON RESIDENT DATA — VisualSlam.update_feature_mapper / estimate_current_camera_position /
+ * add_information_to_map, src/visual_slam.py:183-266 and :153-180, without the bundle adjustment (src/map.py:104-186).
+ * Consumes what the most recent vo_pairs_run (want_points = 1) left in HBM — the pairs' inlier lists, inlier pixel
+ * coordinates and triangulated points — for ALL its B pairs, which must form a chain of distinct frames (a0, b0), (b0, b1), ...
+ * (the order the reference walks a sequence in), and runs on the context's stream without a host round trip:
+ *   pair 0: initialize_map (:43-92) — the two cameras and one map point per E inlier, keyed by featureid1.  [deviation] the
+ *     reference stores camera 1 = (I, 0), camera 2 = (R, t) but the points in camera-2 coordinates and leaves the
+ *     reconciliation to g2o; here camera 2 = (I, 0), camera 1 = (R^T, -R^T t): consistent with the points.
+ *   pair p >= 1: feature_mapper links of every inlier (:183-188); for every inlier in match order the track is traced back
+ *     (:94-99) and, if its root owns a map point, (map point, keypoint2) joins the correspondences (:201-227);
+ *     cv2.solvePnPRansac(map, image, K, zeros(4)) with `iterations`, `reproj_err`, `confidence` (cv2's defaults 100, 8.0,
+ *     0.99; :231-235); the camera (Rodrigues(rvec), tvec) (:243-251); reconstruct_3d_points with K pose(frame2), K pose(frame1)
+ *     (:164-172); points within max_point_norm (50, :177) whose root is not in the map become map points under featureid1.
+ * poses: (B + 1) x 12 — world -> camera [R | t] of pair 0's first frame, then of every pair's second frame (zeros from a
+ * pair that could not be localised on).  status[p]: VO_OK; VO_ERR_TOO_FEW (fewer than 4 correspondences: cv2 raises) or
+ * VO_ERR_NO_MODEL (retval False) at the pair where the reference stops adding cameras; VO_ERR_NOT_CONFIGURED for the pairs
+ * after it; a pair's own failure status if vo_pairs_run could not solve it.  n_corr / n_inl: correspondences and PnP
+ * inliers of the pair; n_map: map points after it. */
+int vo_tracks_pnp_batch(vo_ctx* ctx, int B, const double* K, int iterations, double reproj_err, double confidence, uint64_t seed,
+                        double max_point_norm, double* poses, int32_t* n_corr, int32_t* n_inl, int32_t* status, int32_t* n_map);
+
 /* ------------------------------------------------------------------ measurement
  * With profiling on, every kernel family of the batched path is bracketed by hipEvents on the
  * ctx stream; vo_profile_read returns accumulated milliseconds and launch counts per stage since

@@ -13,7 +13,7 @@ if [ $DET = sift ]; then SUF=_sift; DARGS="--detector sift"; FR=192; else SUF=""
 O=$R/gpurun_out/prof_$TAG$SUF
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --contexts 1 --no-cpu-baseline --no-stream-pass --no-sustain --no-faithful-pass $DARGS"
+B="python3 $R/bench.py --contexts 1 --no-cpu-baseline --no-stream-pass --no-sustain --no-faithful-pass --no-extras $DARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 8 --warmup 2 --no-profile > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 3 --warmup 1 --no-profile > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 3 --warmup 1 --no-profile > $O/write.log 2>&1

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/sift_trace; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --detector sift --contexts 1 --steps 2 --warmup 1 --no-cpu-baseline --no-stream-pass --no-sustain --no-faithful-pass --no-profile > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --detector sift --contexts 1 --steps 2 --warmup 1 --no-cpu-baseline --no-stream-pass --no-sustain --no-faithful-pass --no-extras --no-profile > $O/log.txt 2>&1
 cd $R
 python3 - "$O" <<'PY' > gpurun_out/sift_launches.txt
 import csv, glob, sys

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/_t_$TAG -- python3 $R/bench.py --no-cpu-baseline --no-stream-pass --no-sustain --no-profile --no-faithful-pass --steps 3 --warmup 1 "$@" > $O/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/_t_$TAG -- python3 $R/bench.py --no-cpu-baseline --no-stream-pass --no-sustain --no-profile --no-faithful-pass --no-extras --steps 3 --warmup 1 "$@" > $O/${TAG}_trace.log 2>&1
 find $O/_t_$TAG -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats.csv \;
 rm -rf $O/_t_$TAG
 python3 - <<PY

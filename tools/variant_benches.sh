@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/variants; rm -rf $O; mkdir -p $O
 cd $R
-run() { name=$1; shift; timeout -k 10 300 python bench.py --no-sustain --no-cpu-baseline "$@" > $O/$name.json 2> $O/$name.err || { echo "$name FAILED"; tail -3 $O/$name.err; return; }
+run() { name=$1; shift; timeout -k 10 300 python bench.py --no-sustain --no-cpu-baseline --no-extras "$@" > $O/$name.json 2> $O/$name.err || { echo "$name FAILED"; tail -3 $O/$name.err; return; }
   python - "$O/$name.json" "$name" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

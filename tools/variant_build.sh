@@ -16,6 +16,6 @@ for fl in "$@"; do
   hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/libvo_var$i.so $objs -ldl || exit 1
   echo "== $src $fl"
   if [ -n "$RUN" ]; then ( cd $R; VO_HIP_LIBRARY=/tmp/libvo_var$i.so $RUN ); continue; fi
-  ( cd $R; VO_HIP_LIBRARY=/tmp/libvo_var$i.so python3 bench.py --no-cpu-baseline --no-stream-pass --no-sustain --no-faithful-pass $BENCH_ARGS | python3 -c "
+  ( cd $R; VO_HIP_LIBRARY=/tmp/libvo_var$i.so python3 bench.py --no-cpu-baseline --no-stream-pass --no-sustain --no-faithful-pass --no-extras $BENCH_ARGS | python3 -c "
 import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('  ',d['value'],d['ms_per_step'],'$st',round(d['stages']['$st']['ms_total']/5,4))" )
 done

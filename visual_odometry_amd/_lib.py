@@ -81,6 +81,7 @@ _SIGS = {
     "vo_knn2_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P]),
     "vo_knn2_l2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "vo_knn2_ratio_l2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P]),
+    "vo_tracks_pnp_batch": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_double, _P, _P, _P, _P, _P]),
     "vo_comm_unique_id": (C.c_int, [_P]),
     "vo_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vo_comm_destroy": (C.c_int, [_P]),

@@ -1198,3 +1198,213 @@ void launch_tracks(hipStream_t s, const int* pair_frames, const int* match_off, 
         hipLaunchKernelGGL(k_track_link, dim3((max_m + 255) / 256, P), dim3(256), 0, s, pair_frames, match_off, mq, mt, P, cap, parent);
     hipLaunchKernelGGL(k_track_roots, dim3((cap + 255) / 256, F), dim3(256), 0, s, parent, F, cap, root_frame, root_idx, hops, bad);
 }
+
+
+// ------------------------------------------------------------------ the localisation chain on resident pair results
+// VisualSlam's steady state (src/visual_slam.py:183-266, 153-180) for the pairs vo_pairs_run left in HBM, in their order,
+// without a host round trip and without the bundle adjustment (src/map.py:104-186, out of scope):
+//   update_feature_mapper (:183-188)            -> k_chain_link, all pairs at once (a feature id is a key of one pair only)
+//   initialize_map (:43-92)                     -> k_chain_init: cameras of pair 0, one map point per inlier keyed by featureid1
+//   estimate_current_camera_position (:190-235) -> k_chain_gather: matches whose track root is in the map -> (map, image) coordinates
+//                                                  k_pnp_ransac on them (pnp_kernels.hip), k_chain_pose: Rodrigues, the camera
+//   add_information_to_map (:153-180)           -> k_chain_triangulate with K pose(frame2), K pose(frame1); k_chain_insert:
+//                                                  points beyond 50 units dropped, a point whose root is unmapped is added under
+//                                                  featureid1 (as add_new_match_to_map does)
+__device__ __forceinline__ size_t chain_key(int f, int i, int cap) { return (size_t)f * cap + i; }
+
+__device__ __forceinline__ void chain_root(const unsigned long long* parent, int cap, int F, int& f, int& i)
+{
+    for (int n = 0; n <= F; n++) {                      // track_feature_back_in_time (:94-99)
+        const unsigned long long v = parent[chain_key(f, i, cap)];
+        if (v == 0) return;
+        f = (int)((v >> 20) & 0xfffffu); i = (int)(v & 0xfffffu);
+    }
+}
+
+__global__ void k_chain_link(PairBuf pb, int kp_cap, ChainBuf cb)
+{
+    const int p = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pb.res[p].status != VO_OK || i >= pb.m_count[p] || !pb.mask[(size_t)p * kp_cap + i]) return;
+    const int f1 = pb.slots[2 * p], f2 = pb.slots[2 * p + 1];
+    const int q = pb.m_q[(size_t)p * kp_cap + i], t = pb.m_t[(size_t)p * kp_cap + i];
+    const unsigned long long v = ((unsigned long long)(p + 1) << 40) | ((unsigned long long)(unsigned)f1 << 20) | (unsigned)q;
+    atomicMax(&cb.parent[chain_key(f2, t, kp_cap)], v);
+}
+
+void launch_chain_link(hipStream_t s, PairBuf pb, int kp_cap, int P, ChainBuf cb)
+{
+    hipLaunchKernelGGL(k_chain_link, dim3((kp_cap + 255) / 256, P), dim3(256), 0, s, pb, kp_cap, cb);
+}
+
+// the j-th inlier's match index: inliers are numbered in match order, as k_pose compacts them (and as X's columns run)
+template <typename F>
+__device__ __forceinline__ void chain_for_each_inlier(const PairBuf& pb, int kp_cap, int p, int* s_w, F&& body)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = pb.m_count[p];
+    const uint8_t* mask = pb.mask + (size_t)p * kp_cap;
+    int base = 0;
+    for (int b = 0; b < M; b += 256) {
+        const int i = b + tid;
+        const bool f = i < M && mask[i] != 0;
+        const unsigned long long bal = __ballot(f);
+        __syncthreads();
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < 4; w++) { const int c = s_w[w]; if (w < wave) off += c; tot += c; }
+        body(f, i, base + off + (int)__popcll(bal & ((1ULL << lane) - 1)));
+        base += tot;
+    }
+}
+
+// [deviation, documented in DESIGN.md] the reference stores camera 1 = (I, 0) and camera 2 = (R, t) but its first points in
+// camera-2 coordinates (reconstruct_3d_points' default matrices) and lets the bundle adjustment reconcile them; without BA the
+// cameras are stored consistently with the points: camera 2 = (I, 0), camera 1 = (R^T, -R^T t).
+__global__ __launch_bounds__(256) void k_chain_init(PairBuf pb, int kp_cap, ChainBuf cb)
+{
+    __shared__ int s_w[4];
+    const int tid = threadIdx.x;
+    const vo_pair_result& r = pb.res[0];
+    const int f1 = pb.slots[0], f2 = pb.slots[1];
+    if (r.status != VO_OK) {
+        if (tid == 0) { cb.alive[0] = 0; cb.status[0] = r.status; cb.n_corr[0] = 0; cb.n_inl[0] = 0; cb.n_map[0] = 0; }
+        return;
+    }
+    if (tid < 12) {
+        const int rr = tid / 4, c = tid % 4;
+        const double a = c < 3 ? r.R[c * 3 + rr] : -(r.R[0 * 3 + rr] * r.t[0] + r.R[1 * 3 + rr] * r.t[1] + r.R[2 * 3 + rr] * r.t[2]);
+        const double b = c < 3 ? (rr == c ? 1.0 : 0.0) : 0.0;
+        cb.cam[(size_t)f1 * 12 + tid] = a; cb.cam[(size_t)f2 * 12 + tid] = b;
+        cb.poses[tid] = a; cb.poses[12 + tid] = b;
+    }
+    if (tid == 0) { cb.cam_ok[f1] = 1; cb.cam_ok[f2] = 1; cb.alive[0] = 1; cb.status[0] = VO_OK; cb.n_corr[0] = 0; cb.n_inl[0] = 0; }
+    const double* X = pb.X;                                  // pair 0: [4][kp_cap], w = 1
+    __shared__ int s_added;
+    if (tid == 0) s_added = 0;
+    int added = 0;
+    chain_for_each_inlier(pb, kp_cap, 0, s_w, [&](bool f, int i, int pos) {
+        if (!f) return;
+        const size_t k = chain_key(f1, pb.m_q[i], kp_cap);   // TrackedPoint(match.point, ..., match.featureid1)  (:70-75)
+        cb.in_map[k] = 1;
+        for (int d = 0; d < 3; d++) cb.map_pt[3 * k + d] = X[(size_t)d * kp_cap + pos];
+        added++;
+    });
+    __syncthreads();
+    atomicAdd(&s_added, added);
+    __syncthreads();
+    if (tid == 0) { cb.map_count[0] = s_added; cb.n_map[0] = s_added; }
+}
+
+void launch_chain_init(hipStream_t s, PairBuf pb, int kp_cap, ChainBuf cb)
+{
+    hipLaunchKernelGGL(k_chain_init, dim3(1), dim3(256), 0, s, pb, kp_cap, cb);
+}
+
+// matches_with_map (:201-218): for every match with 3-D information of the current pair, in order — trace featureid2 back, keep
+// the match if the root feature owns a map point: (imagecoord = keypoint2, mapcoord = the point)
+__global__ __launch_bounds__(256) void k_chain_gather(PairBuf pb, int kp_cap, int p, int F, ChainBuf cb)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const vo_pair_result& r = pb.res[p];
+    const int f1 = pb.slots[2 * p], f2 = pb.slots[2 * p + 1];
+    const bool ok = cb.alive[0] && r.status == VO_OK && cb.cam_ok[f1];
+    if (!ok) {
+        if (tid == 0) {
+            cb.off[0] = 0; cb.off[1] = 0; cb.n_corr[p] = 0;
+            cb.status[p] = !cb.alive[0] ? VO_ERR_NOT_CONFIGURED : r.status != VO_OK ? r.status : VO_ERR_INVALID;   // the chain broke earlier / this pair failed / no camera for frame 1
+            cb.alive[0] = 0;
+        }
+        return;
+    }
+    if (tid == 0) s_base = 0;
+    const int M = pb.m_count[p];
+    const uint8_t* mask = pb.mask + (size_t)p * kp_cap;
+    const double* px2 = pb.px2 + (size_t)p * kp_cap * 2;
+    for (int b = 0; b < M; b += 256) {
+        const int i = b + tid;
+        bool take = false; size_t key = 0;
+        if (i < M && mask[i]) {
+            int rf = f2, ri = pb.m_t[(size_t)p * kp_cap + i];
+            chain_root(cb.parent, kp_cap, F, rf, ri);
+            key = chain_key(rf, ri, kp_cap);
+            take = cb.in_map[key] != 0;
+        }
+        const unsigned long long bal = __ballot(take);
+        __syncthreads();
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int w = 0; w < 4; w++) { const int c = s_w[w]; if (w < wave) off += c; tot += c; }
+        if (take) {
+            const int pos = s_base + off + (int)__popcll(bal & ((1ULL << lane) - 1));
+            for (int d = 0; d < 3; d++) cb.obj[3 * pos + d] = cb.map_pt[3 * key + d];
+            cb.img[2 * pos] = px2[2 * i]; cb.img[2 * pos + 1] = px2[2 * i + 1];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { cb.off[0] = 0; cb.off[1] = s_base; cb.n_corr[p] = s_base; }
+}
+
+void launch_chain_gather(hipStream_t s, PairBuf pb, int kp_cap, int p, int F, ChainBuf cb)
+{
+    hipLaunchKernelGGL(k_chain_gather, dim3(1), dim3(256), 0, s, pb, kp_cap, p, F, cb);
+}
+
+// add_information_to_map's reconstruct_3d_points(essential_matches, pose(frame2)[0:3], pose(frame1)[0:3]) (:164-172):
+// cv2.triangulatePoints(K pose(frame1), K pose(frame2), pts1, pts2), X /= w, for every E inlier of the pair
+__global__ void k_chain_triangulate(PairBuf pb, int kp_cap, int p, ChainBuf cb)
+{
+    if (!cb.alive[0]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pb.res[p].n_inl) return;
+    double P1[12], P2[12], q[4];
+    for (int k = 0; k < 12; k++) { P1[k] = cb.P1[k]; P2[k] = cb.P2[k]; }
+    const double* a = pb.ipx1 + ((size_t)p * kp_cap + i) * 2;
+    const double* b = pb.ipx2 + ((size_t)p * kp_cap + i) * 2;
+    triangulate_one(P1, P2, a[0], a[1], b[0], b[1], q);
+    const double w = q[3];
+    for (int k = 0; k < 4; k++) cb.Xw[4 * (size_t)i + k] = q[k] / w;
+}
+
+void launch_chain_triangulate(hipStream_t s, PairBuf pb, int kp_cap, int p, ChainBuf cb)
+{
+    hipLaunchKernelGGL(k_chain_triangulate, dim3((kp_cap + 63) / 64), dim3(64), 0, s, pb, kp_cap, p, cb);
+}
+
+// the loop of :174-178 with add_point_observation_to_map (:138-151): skip points farther than max_norm; a match whose track root
+// already owns a map point only adds an observation (nothing to store without BA); otherwise a new point under featureid1
+__global__ __launch_bounds__(256) void k_chain_insert(PairBuf pb, int kp_cap, int p, int F, double max_norm, ChainBuf cb)
+{
+    __shared__ int s_w[4];
+    __shared__ int s_added;
+    if (!cb.alive[0]) { if (threadIdx.x == 0) cb.n_map[p] = cb.map_count[0]; return; }
+    const int f1 = pb.slots[2 * p], f2 = pb.slots[2 * p + 1];
+    if (threadIdx.x == 0) s_added = 0;
+    int added = 0;
+    chain_for_each_inlier(pb, kp_cap, p, s_w, [&](bool f, int i, int pos) {
+        if (!f) return;
+        const double x = cb.Xw[4 * (size_t)pos], y = cb.Xw[4 * (size_t)pos + 1], z = cb.Xw[4 * (size_t)pos + 2];
+        if (!(sqrt(x * x + y * y + z * z) <= max_norm)) return;                  // np.linalg.norm(match.point) > 50: continue (NaN: kept out)
+        int rf = f2, ri = pb.m_t[(size_t)p * kp_cap + i];
+        chain_root(cb.parent, kp_cap, F, rf, ri);
+        if (cb.in_map[chain_key(rf, ri, kp_cap)]) return;                        // add_new_observation_of_existing_point
+        const size_t k = chain_key(f1, pb.m_q[(size_t)p * kp_cap + i], kp_cap);  // add_new_match_to_map: keyed by featureid1
+        cb.in_map[k] = 1;
+        cb.map_pt[3 * k] = x; cb.map_pt[3 * k + 1] = y; cb.map_pt[3 * k + 2] = z;
+        added++;
+    });
+    __syncthreads();
+    atomicAdd(&s_added, added);
+    __syncthreads();
+    if (threadIdx.x == 0) { cb.map_count[0] += s_added; cb.n_map[p] = cb.map_count[0]; }
+}
+
+void launch_chain_insert(hipStream_t s, PairBuf pb, int kp_cap, int p, int F, double max_norm, ChainBuf cb)
+{
+    hipLaunchKernelGGL(k_chain_insert, dim3(1), dim3(256), 0, s, pb, kp_cap, p, F, max_norm, cb);
+}

@@ -1850,3 +1850,39 @@ void launch_rodrigues(hipStream_t s, const double* in, int in_is_matrix, double*
 {
     hipLaunchKernelGGL(k_rodrigues, dim3(1), dim3(64), 0, s, in, in_is_matrix, out);
 }
+
+
+// ------------------------------------------------------------------ the localisation chain: the camera of a localised frame
+// src/visual_slam.py:237-251: retval -> R, _ = cv2.Rodrigues(rvec); TrackedCamera(R, tvec, ...).  Also the two projection
+// matrices add_information_to_map hands to reconstruct_3d_points (:166-172): K pose(frame1)[0:3] and K pose(frame2)[0:3].
+__global__ void k_chain_pose(PairBuf pb, int p, const double* Kd, ChainBuf cb)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    if (!cb.alive[0]) { cb.n_inl[p] = 0; for (int k = 0; k < 12; k++) cb.poses[(size_t)(p + 1) * 12 + k] = 0.0; return; }   // (status set by k_chain_gather)
+    const int st = cb.pstatus[0];
+    cb.n_inl[p] = cb.pninl[0];
+    if (st != VO_OK) {                 // fewer than 4 correspondences (cv2 raises) or no model (retval False): the reference adds no camera
+        cb.status[p] = st; cb.alive[0] = 0;
+        for (int k = 0; k < 12; k++) cb.poses[(size_t)(p + 1) * 12 + k] = 0.0;
+        return;
+    }
+    cb.status[p] = VO_OK;
+    const int f1 = pb.slots[2 * p], f2 = pb.slots[2 * p + 1];
+    double R[9], r[3] = {cb.rvec[0], cb.rvec[1], cb.rvec[2]};
+    dp_rodrigues_to_mat(r, R);
+    double* c2 = cb.cam + (size_t)f2 * 12;
+    for (int rr = 0; rr < 3; rr++) { for (int c = 0; c < 3; c++) c2[rr * 4 + c] = R[rr * 3 + c]; c2[rr * 4 + 3] = cb.tvec[rr]; }
+    cb.cam_ok[f2] = 1;
+    for (int k = 0; k < 12; k++) cb.poses[(size_t)(p + 1) * 12 + k] = c2[k];
+    const double* c1 = cb.cam + (size_t)f1 * 12;
+    for (int rr = 0; rr < 3; rr++)
+        for (int c = 0; c < 4; c++) {
+            cb.P1[rr * 4 + c] = Kd[rr * 3] * c1[c] + Kd[rr * 3 + 1] * c1[4 + c] + Kd[rr * 3 + 2] * c1[8 + c];
+            cb.P2[rr * 4 + c] = Kd[rr * 3] * c2[c] + Kd[rr * 3 + 1] * c2[4 + c] + Kd[rr * 3 + 2] * c2[8 + c];
+        }
+}
+
+void launch_chain_pose(hipStream_t s, PairBuf pb, int p, const double* Kd, ChainBuf cb)
+{
+    hipLaunchKernelGGL(k_chain_pose, dim3(1), dim3(64), 0, s, pb, p, Kd, cb);
+}

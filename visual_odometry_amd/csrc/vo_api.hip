@@ -105,6 +105,9 @@ struct vo_ctx {
     bool cv2_ready = false;
     int pnp_refine = 1;                   // solvePnPRansac's final pose: 1 = cv2's solvePnP(ITERATIVE) (default), 0 = fast minimiser
     int dk_early = 1;                     // five-point polynomial roots: 1 = noise-floor exit (default), 0 = fixed 300 sweeps
+    std::vector<int32_t> last_slots;      // pair slots of the most recent vo_pairs_run[_async] (host copy)
+    int last_points = 0;                  // ... and whether it triangulated (want_points)
+    uint8_t* chain_mem = nullptr; size_t chain_bytes = 0;             // the localisation chain's tables (vo_tracks_pnp_batch)
 };
 
 static const char* k_stage_names[VO_STAGE_COUNT] = {
@@ -380,7 +383,7 @@ extern "C" void vo_destroy(vo_ctx* ctx)
     free_pairbuf(ctx->raw_pb);
     sift_free(ctx->sift); sift_free(ctx->sift1);
     void* ptrs[] = {ctx->staging, ctx->dK, ctx->raw_desc, ctx->raw_xy, ctx->raw_count, ctx->raw_d, ctx->raw_i, ctx->rng_tab, ctx->raw_desc_x,
-                    ctx->ingest_out, ctx->ingest_tab, ctx->sift_img, ctx->jpg_blob, ctx->jpg_clean, ctx->jpg_rst, ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out,
+                    ctx->chain_mem, ctx->ingest_out, ctx->ingest_tab, ctx->sift_img, ctx->jpg_blob, ctx->jpg_clean, ctx->jpg_rst, ctx->jpg_coef, ctx->jpg_planes, ctx->jpg_out,
                     ctx->jpg_img, ctx->jpg_tab};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev_ready) for (int i = 0; i < MAX_EVENTS; i++) { (void)hipEventDestroy(ctx->ev[i][0]); (void)hipEventDestroy(ctx->ev[i][1]); }
@@ -1006,6 +1009,8 @@ static int pairs_enqueue(vo_ctx* ctx, const int32_t* pair_slots, int B, const do
         if (pair_slots[i] < 0 || pair_slots[i] >= max_frames) FAIL(VO_ERR_INVALID, "pair slot %d out of range", pair_slots[i]);
     *whole_x_out = false;
     ctx->last_pairs = B;
+    ctx->last_slots.assign(pair_slots, pair_slots + 2 * (size_t)B);
+    ctx->last_points = opts->want_points != 0;
     if (B == 0) return VO_OK;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -2512,6 +2517,77 @@ extern "C" int vo_feature_tracks(vo_ctx* ctx, int F, int cap, const int32_t* pai
 }
 
 // ------------------------------------------------------------------ measurement
+// ------------------------------------------------------------------ the step after the pair path, on resident data
+// VisualSlam.estimate_current_camera_position + add_information_to_map (src/visual_slam.py:183-266, 153-180) for the pairs the
+// most recent vo_pairs_run (want_points) left in HBM: feature tracks -> (map, image) coordinates -> solvePnPRansac -> camera ->
+// new map points, pair after pair on the context's stream with no host round trip (the kernels: geom_kernels.hip k_chain_*,
+// pnp_kernels.hip k_pnp_ransac / k_chain_pose).
+extern "C" int vo_tracks_pnp_batch(vo_ctx* ctx, int B, const double* K, int iterations, double reproj_err, double confidence, uint64_t seed,
+                                   double max_point_norm, double* poses, int32_t* n_corr, int32_t* n_inl, int32_t* status, int32_t* n_map)
+{
+    if (!ctx) return VO_ERR_INVALID;
+    if (!batch_ready(ctx)) FAIL(VO_ERR_NOT_CONFIGURED, "vo_batch_configure has not been called");
+    if (B < 1 || B != ctx->last_pairs || !K || !poses || !n_corr || !n_inl || !status || !n_map)
+        FAIL(VO_ERR_INVALID, "vo_tracks_pnp_batch takes all %d pairs of the most recent vo_pairs_run", ctx->last_pairs);
+    if (!ctx->last_points) FAIL(VO_ERR_INVALID, "the most recent vo_pairs_run did not triangulate (want_points)");
+    const int F = batch_max_frames(ctx), cap = batch_cap(ctx);
+    {   // the pairs must be a chain of distinct frames (a0, b0), (b0, b1), ...: the order the reference processes a sequence in
+        std::vector<char> seen((size_t)F, 0);
+        const int32_t* sl = ctx->last_slots.data();
+        seen[(size_t)sl[0]] = 1;
+        for (int p = 0; p < B; p++) {
+            if ((p > 0 && sl[2 * p] != sl[2 * p - 1]) || seen[(size_t)sl[2 * p + 1]])
+                FAIL(VO_ERR_INVALID, "pair %d (%d, %d) does not continue a chain of distinct frames", p, sl[2 * p], sl[2 * p + 1]);
+            seen[(size_t)sl[2 * p + 1]] = 1;
+        }
+    }
+    if (F >= (1 << 20) || cap >= (1 << 20)) FAIL(VO_ERR_INVALID, "too many frames or keypoints for the packed track table");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure_rng(ctx, seed); if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    // one allocation, carved up (8-byte quantities first)
+    const size_t fc = (size_t)F * cap;
+    size_t need = 0;
+    auto take = [&](size_t bytes) { const size_t o = need; need += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_parent = take(fc * 8), o_pt = take(fc * 24), o_cam = take((size_t)F * 96), o_obj = take((size_t)cap * 24), o_img = take((size_t)cap * 16),
+                 o_rv = take(24), o_tv = take(24), o_P1 = take(96), o_P2 = take(96), o_Xw = take((size_t)cap * 32), o_poses = take((size_t)(B + 1) * 96), o_K = take(72),
+                 o_inmap = take(fc), o_camok = take((size_t)F * 4), o_off = take(8), o_pmask = take((size_t)cap), o_pninl = take(4), o_pst = take(4),
+                 o_alive = take(4), o_ncorr = take((size_t)B * 4), o_ninl = take((size_t)B * 4), o_st = take((size_t)B * 4), o_nmap = take((size_t)B * 4), o_mc = take(4);
+    rc = ensure_bytes(ctx, &ctx->chain_mem, &ctx->chain_bytes, need); if (rc) return rc;
+    uint8_t* m = ctx->chain_mem;
+    ChainBuf cb;
+    cb.parent = (unsigned long long*)(m + o_parent); cb.map_pt = (double*)(m + o_pt); cb.cam = (double*)(m + o_cam); cb.obj = (double*)(m + o_obj);
+    cb.img = (double*)(m + o_img); cb.rvec = (double*)(m + o_rv); cb.tvec = (double*)(m + o_tv); cb.P1 = (double*)(m + o_P1); cb.P2 = (double*)(m + o_P2);
+    cb.Xw = (double*)(m + o_Xw); cb.poses = (double*)(m + o_poses); double* dK = (double*)(m + o_K);
+    cb.in_map = m + o_inmap; cb.cam_ok = (int*)(m + o_camok); cb.off = (int*)(m + o_off); cb.pmask = m + o_pmask; cb.pninl = (int*)(m + o_pninl);
+    cb.pstatus = (int*)(m + o_pst); cb.alive = (int*)(m + o_alive); cb.n_corr = (int*)(m + o_ncorr); cb.n_inl = (int*)(m + o_ninl);
+    cb.status = (int*)(m + o_st); cb.n_map = (int*)(m + o_nmap); cb.map_count = (int*)(m + o_mc);
+    HIPCHK(hipMemsetAsync(m, 0, need, s));                           // empty feature_mapper, empty map, no cameras
+    HIPCHK(hipMemcpyAsync(dK, K, 72, hipMemcpyHostToDevice, s));
+    {
+        StageTimer t(ctx, ST_MISC);
+        launch_chain_link(s, ctx->pb, cap, B, cb);
+        launch_chain_init(s, ctx->pb, cap, cb);
+        for (int p = 1; p < B; p++) {
+            launch_chain_gather(s, ctx->pb, cap, p, F, cb);
+            launch_pnp_ransac(s, cb.obj, cb.img, cb.off, 1, dK, iterations, reproj_err, confidence, seed, ctx->rng_tab, RNG_TAB_N, ctx->pnp_refine,
+                              cb.rvec, cb.tvec, cb.pmask, cb.pninl, cb.pstatus);
+            launch_chain_pose(s, ctx->pb, p, dK, cb);
+            launch_chain_triangulate(s, ctx->pb, cap, p, cb);
+            launch_chain_insert(s, ctx->pb, cap, p, F, max_point_norm, cb);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(poses, cb.poses, (size_t)(B + 1) * 96, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(n_corr, cb.n_corr, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(n_inl, cb.n_inl, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(status, cb.status, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(n_map, cb.n_map, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ctx->prof) prof_collect(ctx);
+    return VO_OK;
+}
+
 extern "C" int vo_profile_enable(vo_ctx* ctx, int on)
 {
     if (!ctx) return VO_ERR_INVALID;

@@ -245,5 +245,31 @@ void launch_five_point_raw(hipStream_t s, const double* x1, const double* x2, do
 void launch_reprojection(hipStream_t s, const double* poses, int ncam, const double* points, int npt, const int* obs_cam,
                          const int* obs_pt, const double* obs_xy, int nobs, const double* Kd, double threshold,
                          double* sqerr, uint8_t* keep, int* bad);
+// ---- the localisation chain on resident pair results (geom_kernels.hip / pnp_kernels.hip): src/visual_slam.py:183-266
+struct ChainBuf {
+    unsigned long long* parent;   // [F][cap] packed feature_mapper entry (k_track_link's format), 0 = no entry
+    uint8_t* in_map;              // [F][cap] 1: a map point is keyed by this feature id (mappointdict)
+    double*  map_pt;              // [F][cap][3] world coordinates
+    double*  cam;                 // [F][12] world -> camera [R | t] of a slot's camera (TrackedCamera.pose()[0:3])
+    int*     cam_ok;              // [F]
+    double*  obj;                 // [cap][3] the current problem's map coordinates
+    double*  img;                 // [cap][2] ... image coordinates
+    int*     off;                 // [2] {0, n}: the offsets k_pnp_ransac reads
+    double*  rvec; double* tvec;  // [3] each: solvePnPRansac's result for the current pair
+    uint8_t* pmask;               // [cap]
+    int*     pninl; int* pstatus; // [1] each
+    double*  P1; double* P2;      // [12] each: K pose(frame1)[0:3], K pose(frame2)[0:3] of the current pair
+    double*  Xw;                  // [cap][4] the current pair's inliers triangulated in world coordinates
+    int*     alive;               // [1] 1 while every pair so far was localised
+    int*     n_corr; int* n_inl; int* status; int* n_map;   // [P] per-pair outputs
+    double*  poses;               // [P + 1][12]: camera of pair 0's first frame, then of every pair's second frame
+    int*     map_count;           // [1]
+};
+void launch_chain_link(hipStream_t s, PairBuf pb, int kp_cap, int P, ChainBuf cb);
+void launch_chain_init(hipStream_t s, PairBuf pb, int kp_cap, ChainBuf cb);
+void launch_chain_gather(hipStream_t s, PairBuf pb, int kp_cap, int p, int F, ChainBuf cb);
+void launch_chain_pose(hipStream_t s, PairBuf pb, int p, const double* Kd, ChainBuf cb);
+void launch_chain_triangulate(hipStream_t s, PairBuf pb, int kp_cap, int p, ChainBuf cb);
+void launch_chain_insert(hipStream_t s, PairBuf pb, int kp_cap, int p, int F, double max_norm, ChainBuf cb);
 void launch_tracks(hipStream_t s, const int* pair_frames, const int* match_off, const int* mq, const int* mt, int P, int max_m,
                    int F, int cap, unsigned long long* parent, int* root_frame, int* root_idx, int* hops, int* bad);

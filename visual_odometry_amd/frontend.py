@@ -167,6 +167,19 @@ class FrontEnd:
         c = self.ctx
         c.check(c.lib.vo_sync(c.handle))
 
+    def localize_chain(self, n_pairs, K, iterations=100, reproj_err=8.0, confidence=0.99, seed=OPENCV_RNG_SEED, max_point_norm=50.0):
+        """The step after the pair path on resident data (vo_tracks_pnp_batch; src/visual_slam.py:183-266 without the bundle
+        adjustment): the `n_pairs` pairs of the latest run_pairs(..., want_points=True) — a chain (f0, f1), (f1, f2), ... — are
+        walked in order: feature tracks -> map / image coordinates -> solvePnPRansac -> camera -> new map points.
+        Returns dict(poses [n_pairs + 1, 3, 4] world -> camera, n_corr, n_inl, status, n_map, each [n_pairs])."""
+        B = int(n_pairs)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        poses = np.zeros((B + 1, 12)); nc = np.zeros(B, np.int32); ni = np.zeros(B, np.int32); st = np.zeros(B, np.int32); nm = np.zeros(B, np.int32)
+        c = self.ctx
+        c.check(c.lib.vo_tracks_pnp_batch(c.handle, B, K.ctypes.data, int(iterations), float(reproj_err), float(confidence), int(seed),
+                                          float(max_point_norm), poses.ctypes.data, nc.ctypes.data, ni.ctypes.data, st.ctypes.data, nm.ctypes.data))
+        return dict(poses=poses.reshape(B + 1, 3, 4), n_corr=nc, n_inl=ni, status=st, n_map=nm)
+
     def gather_records(self, B, world=1, wait=True):
         """All-gather the [R|t] + counts records (16 float64 per pair) of the first B pairs of the latest run_pairs
         over the context's RCCL communicator (ctx.comm_init; without one: the local records).  Returns a
