@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--no-stream-pass", action="store_true", help="skip the frames-streamed-from-host measurement")
     ap.add_argument("--no-sustain", action="store_true", help="skip the >= 5 s x 3 sustained passes")
     ap.add_argument("--no-faithful-pass", action="store_true", help="ORB: skip the cv2-order + 300-sweep pass")
-    ap.add_argument("--no-extras", action="store_true", help="skip the widened rows' passes (config.sift, config.jpeg_pipeline, config.pnp)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the widened rows' passes (config.sift, config.jpeg_pipeline, config.pnp, config.tracks_pnp_chain)")
     ap.add_argument("--sustain-seconds", type=float, default=5.0)
     ap.add_argument("--sustain-repeats", type=int, default=3)
     ap.add_argument("--workload", choices=["sequence", "independent", "batch", "flight"], default="sequence",
@@ -608,6 +608,7 @@ def main():
             files = BP.jpeg_files(seq["frames"][:64])
             extra["jpeg_pipeline"] = BP.jpeg_pipeline_pass(files, args.width, args.height, K, nfeatures=args.nfeatures, device=device)
             extra["pnp"] = BP.pnp_pass(_lib.Context(device))[0]
+            extra["tracks_pnp_chain"] = BP.chain_pass(seq["frames"][:65], K, nfeatures=args.nfeatures, device=device)
         except Exception as e:                            # noqa: BLE001 — an extra never takes the headline line down
             extra["error"] = f"{type(e).__name__}: {e}"
 

@@ -142,6 +142,33 @@ def sift_pass(frames, K, contexts=2, steps=4, device=0, kp_cap=0, hbm_peak_gbs=8
     return out
 
 
+def chain_pass(frames, K, nfeatures=2000, device=0, repeats=3):
+    """frames [n, h, w] -> ORB pairs (k, k + 1) with triangulation -> vo_tracks_pnp_batch: the reference's per-frame localisation
+    (tracks -> map / image coordinates -> solvePnPRansac -> camera -> new map points, src/visual_slam.py:183-266 without BA) walked
+    over the resident results.  The walk is sequential by nature (frame k + 1 is localised against the map frame k extended): five
+    small launches per pair on one stream; sequences, not pairs, are what runs in parallel (contexts / GPUs)."""
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    n, h, w = frames.shape
+    pairs = np.stack([np.arange(n - 1), np.arange(n - 1) + 1], 1).astype(np.int32)
+    fe = FrontEnd(h, w, max_frames=n, max_pairs=n - 1, nfeatures=nfeatures, ctx=_lib.Context(device))
+    fe.upload(frames); fe.detect(0, n)
+    fe.run_pairs(pairs, K, want_points=True)
+    out = fe.localize_chain(n - 1, K)                                   # warm-up (allocations)
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        out = fe.localize_chain(n - 1, K)
+    dt = (time.perf_counter() - t0) / repeats
+    ok = int((out["status"] == 0).sum())
+    res = {"what": f"vo_tracks_pnp_batch over {n - 1} consecutive {w}x{h} ORB pairs resident in HBM (src/visual_slam.py:183-266 without the bundle "
+                   "adjustment): feature tracks -> map / image coordinates -> solvePnPRansac -> camera -> new map points, five launches per frame, no host round trip",
+           "frames_per_s": round((n - 1) / dt, 1), "ms_per_frame": round(1e3 * dt / (n - 1), 4), "frames_localised": ok, "of": n - 1,
+           "mean_correspondences": round(float(out["n_corr"][1:ok].mean()), 1) if ok > 1 else 0.0,
+           "mean_pnp_inliers": round(float(out["n_inl"][1:ok].mean()), 1) if ok > 1 else 0.0, "map_points_at_the_end": int(out["n_map"][-1])}
+    fe.ctx.close()
+    return res
+
+
 PNP_K = np.array([[802.832, 0, 565.427], [0, 802.832, 240.124], [0, 0, 1.0]])      # the reference's camera (test.g2o:1)
 
 
