@@ -265,7 +265,9 @@ int vo_reprojection_filter(vo_ctx* ctx, const double* poses, int ncam, const dou
  * reprojectionError 8.0, confidence 0.99, SOLVEPNP_ITERATIVE) — src/visual_slam.py:231-235.
  * obj n x 3, img n x 2 (float64, row-major); rvec / tvec as cv2 returns them; mask[n] = 1 for inliers (cv2 returns
  * their indices).  n == 4 takes cv2's P3P branch (all four points inliers).  VO_ERR_TOO_FEW: n < 4 (cv2 asserts);
- * VO_ERR_NO_MODEL = retval False. */
+ * VO_ERR_NO_MODEL = retval False.  The final pose restates cv2's solvePnP(SOLVEPNP_ITERATIVE) (CvLevMarq) and is tested
+ * against oracle/voo_pnp.c only: cv2 takes its SVDs from LAPACK and its sums in build-dependent order, so agreement with a cv2
+ * wheel is to tolerance (tests/test_cv2_crosscheck.py states it where cv2 exists), never claimed bit for bit. */
 int vo_solve_pnp_ransac(vo_ctx* ctx, const double* obj, const double* img, int n, const double K[9], int iterations,
                         double reproj_err, double confidence, uint64_t seed, double rvec[3], double tvec[3],
                         uint8_t* mask, int32_t* n_inl);
@@ -290,7 +292,10 @@ int vo_resize_area(vo_ctx* ctx, const uint8_t* src, int sh, int sw, int channels
  * OpenCV 4.7's sift.dispatch.cpp / sift.simd.hpp stage for stage: doubled base image, Gaussian and DoG pyramids, scale-space
  * extrema with sub-pixel refinement, contrast and edge tests, orientation histograms, 4 x 4 x 8 descriptors (float, values
  * 0..255), keypoints in removeDuplicatedSorted's order, octave packed as cv2 packs it.  nfeatures > 0 applies
- * KeyPointsFilter::retainBest (libstdc++'s nth_element + partition, ties kept) as cv2 does.  VO_WARN_CAPACITY: more than `cap` keypoints (n_out = the number found). */
+ * KeyPointsFilter::retainBest (libstdc++'s nth_element + partition, ties kept) as cv2 does.  VO_WARN_CAPACITY: more than `cap` keypoints (n_out = the number found).
+ * Keypoints and descriptors are bit-identical to the ORACLE (oracle/voo_sift.c: the scalar code paths of sift.simd.hpp, one rounding
+ * per operation); a cv2 wheel accumulates the descriptor norm in SIMD lanes, so its uint8 bins can differ by +-1 where value * scale
+ * lands near .5 — parity with cv2 itself is unpinned (tests/test_cv2_crosscheck.py carries the tolerance for machines that have cv2). */
 typedef struct {
     int32_t nfeatures;            /* 0 = keep every keypoint */
     int32_t n_octave_layers;      /* 3 */
