@@ -10,10 +10,25 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def reference_chain(O, feats, pairs, K, max_norm=50.0):
-    """The reference's loop over a sequence, on the oracle's stage outputs.  feats[f] = dict(xy, desc)."""
+def _KP(K, T):
+    """K @ T with the operation order of the kernels (k_triangulate_pairs, k_chain_pose): left-to-right sums of products, one rounding
+    per operation — numpy's matmul may fuse or reorder them, and the chain amplifies last-bit differences of its inputs."""
+    return np.array([[K[r, 0] * T[0, c] + K[r, 1] * T[1, c] + K[r, 2] * T[2, c] for c in range(4)] for r in range(3)])
+
+
+def _inv_pose(R, t):
+    """[R^T | -R^T t] as k_triangulate_pairs / k_chain_init form it."""
+    t = np.asarray(t).ravel()
+    return np.array([[R[0, r], R[1, r], R[2, r], -(R[0, r] * t[0] + R[1, r] * t[1] + R[2, r] * t[2])] for r in range(3)])
+
+
+def reference_chain(O, feats, pairs, K, max_norm=50.0, follow=None):
+    """The reference's loop over a sequence, on the oracle's stage outputs.  feats[f] = dict(xy, desc).
+    follow = the device's poses [n, 3, 4]: every solvePnPRansac result is reported as computed, but the chain then continues from
+    the DEVICE's camera, so that every step is compared on identical inputs (a RANSAC over points near its 8-pixel threshold turns
+    a 1e-9 difference of the previous pose into a different winner: the free-running chains agree only while the geometry is good)."""
     feature_mapper, mappoints, cameras = {}, {}, {}
-    out = dict(poses=[], n_corr=[], n_inl=[], status=[], n_map=[], E_inl=[])
+    out = dict(poses=[], n_corr=[], n_inl=[], status=[], n_map=[], E_inl=[], corr=[None])
     alive = True
     for p, (a, b) in enumerate(pairs):
         qi, ti, _ = O.match_hamming(feats[a]["desc"], feats[b]["desc"], 2)
@@ -27,15 +42,16 @@ def reference_chain(O, feats, pairs, K, max_norm=50.0):
         for fid1, fid2, _ in m3d:                                      # update_feature_mapper (:183-188) / initialize_map (:48-52)
             feature_mapper[fid2] = fid1
         if p == 0:                                                     # initialize_map (:43-92), cameras consistent with the points
-            X = O.triangulate(K @ np.hstack([R.T, -R.T @ t]), K @ np.eye(3, 4), p1[inl].T, p2[inl].T)
+            X = O.triangulate(_KP(K, _inv_pose(R, t)), _KP(K, np.eye(3, 4)), p1[inl].T, p2[inl].T)
             X = X / X[3]
-            cameras[a] = np.hstack([R.T, -R.T @ t]); cameras[b] = np.eye(3, 4)
+            cameras[a] = _inv_pose(R, t); cameras[b] = np.eye(3, 4)
             for idx, (fid1, _, _) in enumerate(m3d):
                 mappoints[fid1] = X[:3, idx].copy()
             out["poses"] += [cameras[a], cameras[b]]
             out["n_corr"].append(0); out["n_inl"].append(0); out["status"].append(0); out["n_map"].append(len(mappoints))
             continue
         if not alive:
+            out["corr"].append(None)
             out["poses"].append(np.zeros((3, 4))); out["n_corr"].append(0); out["n_inl"].append(0); out["status"].append(None); out["n_map"].append(len(mappoints))
             continue
         obj, img = [], []                                              # estimate_current_camera_position (:201-227)
@@ -45,7 +61,7 @@ def reference_chain(O, feats, pairs, K, max_norm=50.0):
                 feature_id = feature_mapper[feature_id]
             if feature_id in mappoints:
                 obj.append(mappoints[feature_id]); img.append(kp2)
-        out["n_corr"].append(len(obj))
+        out["n_corr"].append(len(obj)); out["corr"].append((np.array(obj).reshape(-1, 3), np.array(img).reshape(-1, 2)))
         rc, rvec, tvec, pmask, ninl = O.solve_pnp_ransac(np.array(obj).reshape(-1, 3), np.array(img).reshape(-1, 2), K) if len(obj) >= 4 else (-1, None, None, None, 0)
         out["n_inl"].append(int(ninl))
         if rc != 0:                                                    # cv2 raises / retval False: no camera is added (:253-261)
@@ -55,7 +71,9 @@ def reference_chain(O, feats, pairs, K, max_norm=50.0):
         out["status"].append(0)
         cameras[b] = np.hstack([O.rodrigues(rvec), tvec.reshape(3, 1)])   # R, _ = cv2.Rodrigues(rvec); TrackedCamera(R, tvec) (:243-249)
         out["poses"].append(cameras[b])
-        X = O.triangulate(K @ cameras[a], K @ cameras[b], p1[inl].T, p2[inl].T)     # add_information_to_map (:164-172)
+        if follow is not None:
+            cameras[b] = np.array(follow[p + 1], np.float64)
+        X = O.triangulate(_KP(K, cameras[a]), _KP(K, cameras[b]), p1[inl].T, p2[inl].T)     # add_information_to_map (:164-172)
         X = X / X[3]
         snapshot = dict(mappoints)                                     # self.mappointdict is built before the loop (:154-156)
         for idx, (fid1, fid2, _) in enumerate(m3d):
