@@ -190,7 +190,12 @@ __device__ __forceinline__ float4 sb_base_finish(const SiftBaseSrc& B, uint2 raw
 //  and the refinement subtract where they read — bit-identical to buildDoGPyramid's stored planes, 3 of 19 plane transfers per
 //  octave less, 40 % less scratch per frame.)
 #define SW_TW 128                      // columns of a strip
-#define SW_RS 8                        // source rows per step
+#ifndef SW_SCHED_FENCE
+#define SW_SCHED_FENCE 3
+#endif
+#ifndef SW_RS
+#define SW_RS 16                       // source rows per step (8: a thread makes 4 row-pass outputs from 9 16-byte LDS reads and 2 x 2 column-pass outputs
+#endif                                 //   from N + 1 8-byte reads; 16: 8 from 10 and 2 x 4 from N + 3 — the sweeps are bound by the LDS pipe)
 #define SW_THREADS 256
 struct SiftTaps { int n; float k[SIFT_MAX_TAPS]; };
 
@@ -246,15 +251,20 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     const int per_row = INW / 4;                           // 16-byte pieces of a row segment (<= 48)
     const int nsteps = (Y1 - Y0 + 2 * r + SW_RS - 1) / SW_RS;
 
-    // loads: wavefront v brings rows v and v + 4 of a step's eight source rows, lane = 16-byte piece of the row; the row index
+    // loads: wavefront v brings rows v, v + 4, ... of a step's SW_RS source rows, lane = 16-byte piece of the row; the row index
     // (and its reflection at the image border) is a scalar
-    float4 ld[2];
+    constexpr int LQ = SW_RS / 4;                          // rows a wavefront loads per step
+    constexpr int RO = SW_RS * SW_TW / SW_THREADS;         // outputs of a thread in the row pass (consecutive columns of one row)
+    constexpr int CR = SW_RS / 4;                          // rows of a thread's two columns in the column pass
+    static_assert(SW_RS % 4 == 0 && RO % 4 == 0 && SW_TW % RO == 0, "step geometry");
+    float4 ld[LQ];
     const bool bfast = BASE && interior && B.channels == 1;   // single-channel frames: bytes now, pixels when the registers go to LDS
-    uint2 braw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
-    uint32_t bbw[2] = {0u, 0u};
+    uint2 braw[LQ]; uint32_t bbw[LQ];
+#pragma unroll
+    for (int q = 0; q < LQ; q++) { braw[q] = make_uint2(0u, 0u); bbw[q] = 0u; }
     auto issue = [&](int k) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < LQ; q++) {
             const int yy = reflect101(Y0 - r + k * SW_RS + wave + 4 * q, h);
             const int x = xa + 4 * lane;
             if (BASE) {
@@ -277,93 +287,109 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
     };
     issue(0);
     // thread roles
-    const int rrow = tid >> 5, rx4 = (tid & 31) * 4;       // row pass: 4 consecutive columns of one of the 8 rows
-    const int cc = 2 * lane;                               // column pass: two adjacent columns of two consecutive rows (scalar: 2 wave ..)
+    constexpr int TPR = SW_TW / RO;                         // threads per row in the row pass
+    const int rrow = tid / TPR, rx = (tid % TPR) * RO;      // row pass: RO consecutive columns of one of the SW_RS rows
+    const int cc = 2 * lane;                               // column pass: two adjacent columns of CR consecutive rows (scalar: CR wave ..)
     const int woff = R4 - r;                               // window start inside the aligned span
     const int x = x0 + cc;
     for (int k = 0; k < nsteps; k++) {
         // the segment of step k: registers -> LDS (all threads are past the row pass of step k - 1: second barrier below)
         if (lane < per_row) {
-            if (bfast) { ld[0] = sb_base_finish(B, braw[0], bbw[0], xa + 4 * lane, w); ld[1] = sb_base_finish(B, braw[1], bbw[1], xa + 4 * lane, w); }
-            *(float4*)(s_in + wave * INP + 4 * lane) = ld[0];
-            *(float4*)(s_in + (wave + 4) * INP + 4 * lane) = ld[1];
+#pragma unroll
+            for (int q = 0; q < LQ; q++) {
+                if (bfast) ld[q] = sb_base_finish(B, braw[q], bbw[q], xa + 4 * lane, w);
+                *(float4*)(s_in + (wave + 4 * q) * INP + 4 * lane) = ld[q];
+            }
         }
         if (k + 1 < nsteps) issue(k + 1);                  // in flight during this step's arithmetic
         __syncthreads();
-        // ---- row pass: s_in row rrow -> ring row (k * 8 + rrow)
+        // ---- row pass: s_in row rrow -> ring row (k * SW_RS + rrow)
         {
             const int seq = k * SW_RS + rrow;
-            const float* in = s_in + rrow * INP + rx4;
-            float acc[4];
+            const float* in = s_in + rrow * INP + rx;
+            float acc[RO];
             if (N > 0) {
-                float win[2 * DM::R4 + 4];
+                float win[2 * DM::R4 + RO];
 #pragma unroll
-                for (int i = 0; i < (2 * DM::R4 + 4) / 4; i++) { const float4 v = *(const float4*)(in + 4 * i); win[4 * i] = v.x; win[4 * i + 1] = v.y; win[4 * i + 2] = v.z; win[4 * i + 3] = v.w; }
+                for (int i = 0; i < (2 * DM::R4 + RO) / 4; i++) { const float4 v = *(const float4*)(in + 4 * i); win[4 * i] = v.x; win[4 * i + 1] = v.y; win[4 * i + 2] = v.z; win[4 * i + 3] = v.w; }
                 constexpr int WO = DM::R4 - DM::R;
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] = tk[0] * win[WO + q];
+                for (int q = 0; q < RO; q++) acc[q] = tk[0] * win[WO + q];
 #pragma unroll
                 for (int i = 1; i < N; i++) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[q] += tk[i] * win[WO + i + q];
+                    for (int q = 0; q < RO; q++) acc[q] += tk[i] * win[WO + i + q];
                 }
-                *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+                for (int q = 0; q < RO; q += 4) *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] = t.k[0] * in[woff + q];
+                for (int q = 0; q < RO; q++) acc[q] = t.k[0] * in[woff + q];
                 for (int i = 1; i < n; i++) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[q] += t.k[i] * in[woff + i + q];
+                    for (int q = 0; q < RO; q++) acc[q] += t.k[i] * in[woff + i + q];
                 }
-                *(float4*)(s_ring + (seq % RING) * SW_TW + rx4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+                for (int q = 0; q < RO; q += 4) *(float4*)(s_ring + (seq % RING) * SW_TW + rx + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
             }
         }
         __syncthreads();
-        // ---- column pass: output rows m = 8 k - 2 r + 2 wave + q (relative to Y0) have their whole window in the ring now.  A
-        //      thread owns TWO ADJACENT COLUMNS of two rows: the ring is read eight bytes at a time and the arithmetic runs on
+        // ---- column pass: output rows m = SW_RS k - 2 r + CR wave + q (relative to Y0) have their whole window in the ring now.  A
+        //      thread owns TWO ADJACENT COLUMNS of CR rows: the ring is read eight bytes at a time and the arithmetic runs on
         //      float pairs (v_pk_add / v_pk_mul_f32: the same IEEE operations per component, half the instructions).  m0 and every
         //      ring row index are scalars (a wavefront's property)
         {
             typedef float v2f __attribute__((ext_vector_type(2)));
-            const int m0 = k * SW_RS - 2 * r + 2 * wave;
-            if (m0 + 1 >= 0 && Y0 + m0 < Y1 && x < w) {
-                v2f acc[2];
+            const int m0 = k * SW_RS - 2 * r + CR * wave;
+            if (m0 + CR - 1 >= 0 && Y0 + m0 < Y1 && x < w) {
+                v2f acc[CR];
                 const int rb0 = (m0 + 4 * RING) % RING;
                 if (N > 0) {
-                    v2f win[N + 1];
+                    // the window slides outwards from the centre rows: tap pair i needs rows R + q + i and R + q - i, i.e. ONE new row
+                    // on either side per i — only 2 CR rows are live at a time (the whole window in registers cost 60 VGPRs at 27 taps
+                    // and a wavefront per SIMD of occupancy)
+                    auto ring_row = [&](int i) { int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; return *(const v2f*)(s_ring + ri * SW_TW + cc); };
+                    v2f hi[CR], lo[CR];
 #pragma unroll
-                    for (int i = 0; i < N + 1; i++) { int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; win[i] = *(const v2f*)(s_ring + ri * SW_TW + cc); }
-#pragma unroll
-                    for (int q = 0; q < 2; q++) acc[q] = tk[DM::R] * win[DM::R + q];
+                    for (int q = 0; q < CR; q++) { hi[q] = ring_row(DM::R + q); lo[q] = hi[q]; acc[q] = tk[DM::R] * hi[q]; }
 #pragma unroll
                     for (int i = 1; i <= DM::R; i++) {
 #pragma unroll
-                        for (int q = 0; q < 2; q++) acc[q] += tk[DM::R + i] * (win[DM::R + q + i] + win[DM::R + q - i]);
+                        for (int q = 0; q + 1 < CR; q++) hi[q] = hi[q + 1];
+                        hi[CR - 1] = ring_row(DM::R + CR - 1 + i);
+#pragma unroll
+                        for (int q = CR - 1; q > 0; q--) lo[q] = lo[q - 1];
+                        lo[0] = ring_row(DM::R - i);
+#pragma unroll
+                        for (int q = 0; q < CR; q++) acc[q] += tk[DM::R + i] * (hi[q] + lo[q]);
+#if SW_SCHED_FENCE
+                        if (i % SW_SCHED_FENCE == 0) __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from hoisting every load to the top again
+#endif
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 2; q++) acc[q] = t.k[r] * *(const v2f*)(s_ring + ((rb0 + r + q) % RING) * SW_TW + cc);
+                    for (int q = 0; q < CR; q++) acc[q] = t.k[r] * *(const v2f*)(s_ring + ((rb0 + r + q) % RING) * SW_TW + cc);
                     for (int i = 1; i <= r; i++) {
 #pragma unroll
-                        for (int q = 0; q < 2; q++)
+                        for (int q = 0; q < CR; q++)
                             acc[q] += t.k[r + i] * (*(const v2f*)(s_ring + ((rb0 + r + q + i) % RING) * SW_TW + cc) + *(const v2f*)(s_ring + ((rb0 + r + q - i) % RING) * SW_TW + cc));
                     }
                 }
                 const bool two = x + 1 < w;
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
+                for (int q = 0; q < CR; q++) {
                     const int m = m0 + q, y = Y0 + m;
                     if (m >= 0 && y < Y1) {
                         const size_t o = (size_t)y * stride + x;
                         if (two) *(v2f*)(dstG + o) = acc[q];
                         else dstG[o] = acc[q].x;
-                        // (row y of q = 0 and column x are even: steps, segments and a thread's column pair start at even indices)
-                        if (dstH && q == 0 && (y >> 1) < hh && (x >> 1) < hw) dstH[(size_t)(y >> 1) * hstride + (x >> 1)] = acc[0].x;
+                        // (row y of an even q and column x are even: steps, segments and a thread's rows / column pair start at even indices)
+                        if (dstH && (q & 1) == 0 && (y >> 1) < hh && (x >> 1) < hw) dstH[(size_t)(y >> 1) * hstride + (x >> 1)] = acc[q].x;
                     }
                 }
             }
         }
-        // (no barrier here: the next step writes s_in, which nobody reads after the second barrier above, and touches the rings
+        // (no barrier here: the next step writes s_in, which nobody reads after the second barrier above, and touches the ring
         //  only after its own first barrier, which every thread reaches after this column pass)
     }
 }
