@@ -70,3 +70,35 @@ def test_stale_rendezvous_directory_is_not_trusted(tmp_path):
     assert leader.communicate(timeout=90)[0].strip() == "b'fresh'" and follower.communicate(timeout=90)[0].strip() == "b'fresh'"
     assert leader.returncode == 0 and follower.returncode == 0
     assert FileRendezvous is not None and not d.exists()
+
+
+def test_bench_quotes_counters_only_from_a_pass_on_these_sources(tmp_path, monkeypatch):
+    """roofline.traffic / valu come from profiles/<tag>_pmc_traffic.json only when the file carries the hash of the sources the library
+    is built from (tools/source_hash.py): counters of an older kernel are reported as null, not replayed (round-3 review, weak #4)."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from tools import source_hash as SH
+    prof = tmp_path / "profiles"; prof.mkdir()
+    rec = {"k_fast<false>": {"hbm_bytes_per_launch": 865000000, "valu_wave_insts_per_launch": 398000000},
+           "_meta": {"frames_per_launch": 257, "source_hash": SH.source_hash()}}
+    (prof / f"{bench.PROFILE_TAG}_pmc_traffic.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench._PMC_CACHE.clear()
+    assert bench.pmc_sum("orb", "fast_score_nms", "hbm_bytes_per_launch", 257) == 865000000.0
+    assert bench.pmc_sum("orb", "fast_score_nms", "hbm_bytes_per_launch", 129) is None            # another chunk size: not this pass
+    rec["_meta"]["source_hash"] = "0" * 40
+    (prof / f"{bench.PROFILE_TAG}_pmc_traffic.json").write_text(json.dumps(rec))
+    bench._PMC_CACHE.clear()
+    assert bench.pmc_sum("orb", "fast_score_nms", "hbm_bytes_per_launch", 257) is None
+    assert bench.pmc_sum("orb", "fast_score_nms", "valu_wave_insts_per_launch", 257) is None
+    bench._PMC_CACHE.clear()
+
+
+def test_traffic_tool_doubles_fetch_size_for_streaming_kernels_only():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import collect_traffic as CT
+    for k in ("k_fast<false>", "k_resize_direct", "k_blur_direct", "k_sb_sweep<27, false>", "k_sb_extrema<5>", "k_jpeg_idct", "k_nn_fp4<false>"):
+        assert CT.streaming(k), k
+    for k in ("k_harris", "k_angle", "k_brief", "k_sb_descriptor", "k_sb_orient", "k_ransac", "k_pose", "k_sel_rows<true>"):
+        assert not CT.streaming(k), k
