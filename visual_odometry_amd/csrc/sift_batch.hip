@@ -190,6 +190,9 @@ __device__ __forceinline__ float4 sb_base_finish(const SiftBaseSrc& B, uint2 raw
 //  and the refinement subtract where they read — bit-identical to buildDoGPyramid's stored planes, 3 of 19 plane transfers per
 //  octave less, 40 % less scratch per frame.)
 #define SW_TW 128                      // columns of a strip
+#ifndef SW_DMAP_MIN
+#define SW_DMAP_MIN 99                 // tap counts from which the ring is double-mapped (costs LDS: the short, HBM-bound filters keep their occupancy)
+#endif
 #ifndef SW_SCHED_FENCE
 #define SW_SCHED_FENCE 3
 #endif
@@ -212,11 +215,23 @@ struct SweepDims {
     static constexpr int INW = SW_TW + 2 * R4;                  // floats of a source row segment (starts 16-byte aligned)
     static constexpr int INP = INW + 4;                          // LDS pitch of s_in
     static constexpr int RING = (NN + SW_RS - 1 + 7) & ~7;       // row-filtered rows kept
-    static constexpr int LDS_FLOATS = SW_RS * INP + RING * SW_TW;
+    // long filters keep the first EXT ring rows a second time behind the ring: a column window then never wraps and its LDS reads
+    // are one base register + immediate offsets (the wrap test of every row was a sixth of the loop's instructions)
+    static constexpr bool DMAP = N >= SW_DMAP_MIN;
+    static constexpr int EXT = DMAP ? (NN + SW_RS / 4 - 1 + 7) & ~7 : 0;
+    static constexpr int LDS_FLOATS = SW_RS * INP + (RING + EXT) * SW_TW;
 };
 
+#ifndef SW_WAVES_PER_EU
+#define SW_WAVES_PER_EU 0
+#endif
+#if SW_WAVES_PER_EU
+#define SW_OCC __attribute__((amdgpu_waves_per_eu(SW_WAVES_PER_EU, SW_WAVES_PER_EU)))
+#else
+#define SW_OCC
+#endif
 template <int N, bool BASE>
-__global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_t src_fs, float* dstG, size_t g_fs,
+__global__ __launch_bounds__(SW_THREADS) SW_OCC void k_sb_sweep(const float* src, size_t src_fs, float* dstG, size_t g_fs,
                                                          int w, int h, int stride, int seg, SiftTaps t, float* dstH, size_t h_fs, int hstride, int hw, int hh,
                                                          SiftBaseSrc B)
 {
@@ -320,8 +335,13 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
 #pragma unroll
                     for (int q = 0; q < RO; q++) acc[q] += tk[i] * win[WO + i + q];
                 }
+                const int ridx = seq % DM::RING;
 #pragma unroll
-                for (int q = 0; q < RO; q += 4) *(float4*)(s_ring + (seq % DM::RING) * SW_TW + rx + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+                for (int q = 0; q < RO; q += 4) *(float4*)(s_ring + ridx * SW_TW + rx + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+                if (DM::DMAP && ridx < DM::EXT) {
+#pragma unroll
+                    for (int q = 0; q < RO; q += 4) *(float4*)(s_ring + (ridx + DM::RING) * SW_TW + rx + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < RO; q++) acc[q] = t.k[0] * in[woff + q];
@@ -348,7 +368,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sb_sweep(const float* src, size_
                     // the window slides outwards from the centre rows: tap pair i needs rows R + q + i and R + q - i, i.e. ONE new row
                     // on either side per i — only 2 CR rows are live at a time (the whole window in registers cost 60 VGPRs at 27 taps
                     // and a wavefront per SIMD of occupancy)
-                    auto ring_row = [&](int i) { int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; return *(const v2f*)(s_ring + ri * SW_TW + cc); };
+                    const float* wbase = s_ring + rb0 * SW_TW + cc;          // (double-mapped ring: rows rb0 .. rb0 + N + CR - 2 are contiguous)
+                    auto ring_row = [&](int i) {
+                        if (DM::DMAP) return *(const v2f*)(wbase + i * SW_TW);
+                        int ri = rb0 + i; ri = ri >= DM::RING ? ri - DM::RING : ri; return *(const v2f*)(s_ring + ri * SW_TW + cc); };
                     v2f hi[CR], lo[CR];
 #pragma unroll
                     for (int q = 0; q < CR; q++) { hi[q] = ring_row(DM::R + q); lo[q] = hi[q]; acc[q] = tk[DM::R] * hi[q]; }
