@@ -205,6 +205,13 @@ def launch_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
+
+    def forward(signum, _frame):                         # the launcher is told to stop (a driver's time limit): so are the ranks
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        raise KeyboardInterrupt
+    old_handlers = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGHUP)}
     try:
         live = set(range(n))
         while live:
@@ -229,6 +236,8 @@ def launch_ranks(n, argv):
                     p.wait(max(0.1, deadline - time.time()))
                 except subprocess.TimeoutExpired:
                     p.kill()
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     return rc
 
 

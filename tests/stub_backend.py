@@ -44,6 +44,10 @@ class FrontEnd:
     def __init__(self, height, width, max_frames, max_pairs, device=0, **kw):
         if os.environ.get("VO_STUB_FAIL_RANK") == os.environ.get("RANK", "0"):
             raise SystemExit(7)                                    # the launcher test's failing rank
+        if os.environ.get("VO_STUB_HANG_RANK") == os.environ.get("RANK", "0"):
+            import time                                            # the launcher test's rank that never finishes
+            open(os.path.join(os.environ["VO_RENDEZVOUS_DIR"], "hung_rank_pid"), "w").write(str(os.getpid()))
+            time.sleep(600)
         self.h, self.w, self.max_frames, self.max_pairs, self.device = height, width, max_frames, max_pairs, device
         self.detector, self.kp_cap = kw.get("detector", "orb"), 64
         self.ctx = _Ctx()

@@ -102,3 +102,31 @@ def test_traffic_tool_doubles_fetch_size_for_streaming_kernels_only():
         assert CT.streaming(k), k
     for k in ("k_harris", "k_angle", "k_brief", "k_sb_descriptor", "k_sb_orient", "k_ransac", "k_pose", "k_sel_rows<true>"):
         assert not CT.streaming(k), k
+
+
+def test_stopping_the_launcher_stops_the_ranks(tmp_path):
+    """SIGTERM to `bench.py --gpus 2` (a driver's time limit) reaches the rank processes: nothing is left behind."""
+    import signal
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "VO_RENDEZVOUS_KEY")}
+    env.update(VO_BENCH_STUB="tests.stub_backend", PYTHONPATH=ROOT, VO_RENDEZVOUS_DIR=str(tmp_path), VO_STUB_HANG_RANK="1")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + FLAGS, env=env, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    marker = tmp_path / "hung_rank_pid"
+    t0 = time.time()
+    while not marker.exists() and time.time() - t0 < 120:
+        time.sleep(0.1)
+    assert marker.exists(), "the hanging rank never started"
+    pid = int(marker.read_text())
+    p.send_signal(signal.SIGTERM)
+    p.communicate(timeout=60)
+    assert p.returncode == 130
+    t0 = time.time()
+    while time.time() - t0 < 20:
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(pid, signal.SIGKILL)
+        raise AssertionError("the rank survived its launcher")
