@@ -570,12 +570,17 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     __shared__ uint16_t s_q[FT_QCAP + 1];            // + one spare slot for the branch-free push
     static_assert(FT_GROUPS_X * FT_SCH * 4 + 4 <= FT_SCH * FT_SCW, "the group queue of phase B (dead before the score tile is cleared) and its spare slot fit the score tile");
     const int f = blockIdx.y, lane = threadIdx.x;
-    const int bid = xcd_tile(blockIdx.x, g.ftiles_total);
+    // DENSE: the tiles of the whole level; else only the tiles that can hold a keypoint (LevelGeom.fox / foy)
+    const int bid = xcd_tile(blockIdx.x, DENSE ? g.dtiles_total : g.ftiles_total);
     int l = 0;
-    while (l + 1 < g.nlevels && bid >= g.lv[l + 1].ftile_base) l++;
+    while (l + 1 < g.nlevels && bid >= (DENSE ? g.lv[l + 1].dtile_base : g.lv[l + 1].ftile_base)) l++;
     const LevelGeom lv = g.lv[l];
-    const int tile = bid - lv.ftile_base;
-    const int x0 = (tile % lv.ftiles_x) * FAST_TW, y0 = (tile / lv.ftiles_x) * FAST_TH;
+    const int tile = bid - (DENSE ? lv.dtile_base : lv.ftile_base), tiles_x = DENSE ? lv.dtiles_x : lv.ftiles_x;
+    const int x0 = (DENSE ? 0 : lv.fox) + (tile % tiles_x) * FAST_TW, y0 = (DENSE ? 0 : lv.foy) + (tile / tiles_x) * FAST_TH;
+    // pixels whose score anyone reads: the dense map wants every pixel that has a ring; the pipeline only the kept region and the
+    // one-pixel ring around it (the neighbours of its 3 x 3 suppression)
+    const int gxlo = DENSE ? 3 : max(3, g.edge - 1), gxhi = DENSE ? lv.w - 4 : min(lv.w - 4, lv.w - g.edge);
+    const int gylo = DENSE ? 3 : max(3, g.edge - 1), gyhi = DENSE ? lv.h - 4 : min(lv.h - 4, lv.h - g.edge);
     const uint8_t* img = pyr + (size_t)f * g.frame_bytes + lv.off;
     const int t = g.fast_thr;
 
@@ -625,8 +630,8 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
     static_assert(FT_SCH <= 32 && FT_SCW <= 128, "queue entries hold the score-tile row in 5 bits and the column in 7");
     constexpr int FB_ROWS = FT_SCH / 2;                // steps per band
     const uint32_t T2 = (uint32_t)t * 0x00010001u, K1 = 0x7fff7fffu - T2;
-    const int xlo = max(x0 - 1, 3), xhi = min(x0 + FAST_TW, lv.w - 4);
-    const bool edge_tile = x0 < 4 || x0 + FAST_TW + 4 > lv.w || y0 < 4 || y0 + FAST_TH + 4 > lv.h;
+    const int xlo = max(x0 - 1, gxlo), xhi = min(x0 + FAST_TW, gxhi);
+    const bool edge_tile = x0 - 1 < gxlo || x0 + FAST_TW > gxhi || y0 - 1 < gylo || y0 + FAST_TH > gyhi;
     const int band = lane >> 5, gc = lane & 31;
     // answer bits of pixel 0..3 of a group: 15, 7, 31, 23
     uint32_t colmask;                                  // pixels of this lane's group where a corner is possible / needed
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         uint32_t gq = e0 + lane < gn ? s_g32[e0 + lane] : 0u;
         if (edge_tile) {                                                       // wave-uniform: rows that cannot hold a corner
             const int gy = y0 - 1 + (int)((gq >> 8) & 31u);
-            gq = gy >= 3 && gy < lv.h - 3 ? gq : 0u;
+            gq = gy >= gylo && gy <= gyhi ? gq : 0u;
         }
         const uint32_t entry = (gq & 0x1f00u) | ((gq & 31u) << 2);
         constexpr uint32_t bpos[4] = {15, 7, 31, 23};
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(64) void k_fast(const uint8_t* pyr, uint8_t* score,
         for (int i = lane; i < FT_SCH * (FAST_TW + 2); i += 64) {
             const int gr = i / (FAST_TW + 2), cx = 3 + i % (FAST_TW + 2);
             const int gx = x0 - 4 + cx, gy = y0 - 1 + gr;
-            if (gx < xlo || gx > xhi || gy < 3 || gy >= lv.h - 3) continue;
+            if (gx < xlo || gx > xhi || gy < gylo || gy > gyhi) continue;
             s_sc[gr * FT_SCW + cx] = (uint8_t)fast_score_or_zero(s_px + (gr + 3) * FT_PXW + 12 + cx, t);
         }
         __syncthreads();
@@ -840,8 +845,8 @@ static_assert((FAST_TH * FAST_TW) % 64 == 0, "the dense fallback appends with fu
 void launch_fast(hipStream_t s, const uint8_t* pyr, uint8_t* score, uint32_t* hist, const PyrGeom& g, int F,
                  uint32_t* tile_list, int* tile_count)
 {
-    if (tile_list) hipLaunchKernelGGL(k_fast<false>, dim3(g.ftiles_total, F), dim3(64), 0, s, pyr, score, hist, g, tile_list, tile_count);
-    else hipLaunchKernelGGL(k_fast<true>, dim3(g.ftiles_total, F), dim3(64), 0, s, pyr, score, hist, g, tile_list, tile_count);
+    if (tile_list) { if (g.ftiles_total > 0) hipLaunchKernelGGL(k_fast<false>, dim3(g.ftiles_total, F), dim3(64), 0, s, pyr, score, hist, g, tile_list, tile_count); }
+    else hipLaunchKernelGGL(k_fast<true>, dim3(g.dtiles_total, F), dim3(64), 0, s, pyr, score, hist, g, tile_list, tile_count);
 }
 
 // ------------------------------------------------------------------ retainBest by FAST score
@@ -942,7 +947,7 @@ __global__ __launch_bounds__(64) void k_sel_rows(const uint32_t* tile_list, cons
         const uint32_t* lst = tile_list + (tile0 + t) * FT_LISTCAP;
         for (int j = lane; j < cnt; j += 64) {
             const uint32_t e = lst[j];
-            if ((int)(e >> 16) >= T) { const uint32_t gx = (uint32_t)(t * FAST_TW) + (e & 255u); atomicOr(&s_bm[((e >> 8) & 255u) * W32 + (gx >> 5)], 1u << (gx & 31u)); }
+            if ((int)(e >> 16) >= T) { const uint32_t gx = (uint32_t)(lv.fox + t * FAST_TW) + (e & 255u); atomicOr(&s_bm[((e >> 8) & 255u) * W32 + (gx >> 5)], 1u << (gx & 31u)); }
         }
     }
     __syncthreads();
@@ -968,10 +973,10 @@ __global__ __launch_bounds__(64) void k_sel_rows(const uint32_t* tile_list, cons
         for (int j = lane; j < cnt; j += 64) {
             const uint32_t e = lst[j];
             if ((int)(e >> 16) >= T) {
-                const uint32_t ly = (e >> 8) & 255u, gx = (uint32_t)(t * FAST_TW) + (e & 255u);
+                const uint32_t ly = (e >> 8) & 255u, gx = (uint32_t)(lv.fox + t * FAST_TW) + (e & 255u);
                 const int wd = (int)(ly * W32 + (gx >> 5));
                 const int pos = base + (int)s_pf[wd] + __popc(s_bm[wd] & ((1u << (gx & 31u)) - 1u));
-                if (pos < lv.cand_cap) { out_pos[pos] = (((uint32_t)(chunk * FAST_TH) + ly) << 16) | gx; out_resp[pos] = (float)(e >> 16); }
+                if (pos < lv.cand_cap) { out_pos[pos] = (((uint32_t)(lv.foy + chunk * FAST_TH) + ly) << 16) | gx; out_resp[pos] = (float)(e >> 16); }
                 else overflow = true;
             }
         }

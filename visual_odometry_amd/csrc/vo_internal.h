@@ -16,7 +16,9 @@ struct LevelGeom {
     int w, h, stride, off;       // level image; off = byte offset inside one frame's pyramid
     int quota;                   // ORB per-level feature budget
     float scale;                 // layerScale[l]
-    int ftile_base, ftiles_x;    // FAST tiles (prefix over levels)
+    int ftile_base, ftiles_x;    // FAST tiles of the pipeline (prefix over levels): they cover only what can hold a keypoint — the
+    int fox, foy;                //   level minus its edgeThreshold border — and start at (fox, foy)
+    int dtile_base, dtiles_x;    // FAST tiles of the dense score map (stage API): the whole level from (0, 0)
     int btile_base, btiles_x;    // blur tiles
     int cand_off, cand_cap;      // candidate slots of this level inside a frame's candidate arrays
     int sel_chunk_base;          // first selection chunk (= row of FAST tiles) of this level
@@ -25,7 +27,7 @@ struct LevelGeom {
 struct PyrGeom {
     int nlevels, frame_bytes;    // frame_bytes: pyramid bytes per frame
     int edge, fast_thr, score_type, nfeatures;
-    int ftiles_total, btiles_total;
+    int ftiles_total, btiles_total, dtiles_total;
     int cand_total, kp_cap;
     int sel_chunks_total;
     LevelGeom lv[VO_MAX_LEVELS];
