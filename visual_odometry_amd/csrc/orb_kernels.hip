@@ -446,7 +446,7 @@ void launch_resize_area(hipStream_t st, const uint8_t* src, int cn, int sstride,
 //  D. 3x3 non-max suppression on the corners (decide, then clear the losers in the LDS score tile), survivors
 //     inside the border feed the per-level score histogram retainBest needs (global atomics, a few per tile);
 //  E. dense 16-byte stores of the score tile.
-// Tile 112 x 24: 30 groups per row = two rows per 64-lane step, 9 KB of LDS per wave (4 waves / SIMD).
+// Tile 112 x 20 (FAST_TW x FAST_TH): 30 groups per row = two rows per 64-lane step, 9 KB of LDS per wave (4 waves / SIMD).
 #define FT_PXW (FAST_TW + 32)            // LDS pixel tile: columns x0-16 .. x0+TW+15
 #define FT_PXH (FAST_TH + 8)             // rows y0-4 .. y0+TH+3
 #define FT_SCW (FAST_TW + 16)            // LDS score tile: columns x0-4 .. x0+TW+11 (dword aligned with the output)
