@@ -23,11 +23,11 @@ fe.detect(0, 257)
 lib.vo_debug_fast_stats(out, 0)
 t, g, q, c, w, it, ov = [int(out[i]) for i in range(7)]
 px = fe.stage_bytes("fast_score_nms", 257)                 # pyramid pixels of 257 frames
-ring = t * 26 * 114                                          # pixels the pre-test looks at: every tile + its one-pixel ring
+ring = t * 22 * 114                                          # pixels the pre-test looks at: every tile + its one-pixel ring
 print(f"k_fast<false>, 257 frames of the 1280x720 flight, 8 levels, threshold 20 (counted by the kernel, -DFT_STATS build)")
 print(f"  tiles                     {t:12d}   ({t // 257} per frame; {px / 257:.0f} pyramid pixels per frame)")
 print(f"  pre-tested pixels         {ring:12d}   (tile + ring: {ring / px:.3f} x the pyramid pixels)")
-print(f"  groups with a survivor    {g:12d}   {100.0 * g / (t * 26 * 30):6.2f} % of the groups of 4 pixels")
+print(f"  groups with a survivor    {g:12d}   {100.0 * g / (t * 22 * 30):6.2f} % of the groups of 4 pixels")
 print(f"  pre-test survivors        {q:12d}   {100.0 * q / px:6.2f} % of the pyramid pixels, {q / t:.1f} per tile")
 print(f"  FAST corners              {c:12d}   {100.0 * c / px:6.2f} %  ({100.0 * c / max(q, 1):.1f} % of the survivors)")
 print(f"  listed NMS winners        {w:12d}   {100.0 * w / px:6.2f} %  (inside the 31-pixel border)")
