@@ -278,3 +278,31 @@ def test_randomised_images_and_parameters(oracle, ctx, seed):
         assert not ref["overflow"], tag
         for k in ("xy", "octave", "response", "angle", "size", "desc"):
             assert np.array_equal(got[k], ref[k]), f"{tag}: {k}"
+
+
+@pytest.mark.parametrize("w,h,nlevels", [(200, 150, 8), (129, 97, 8), (96, 70, 4), (70, 64, 3), (400, 66, 8)])
+def test_levels_too_small_to_hold_a_keypoint(oracle, w, h, nlevels):
+    """Pyramid levels narrower than two border widths (edgeThreshold 31) have no FAST tiles at all in the pipeline: they must contribute
+    nothing — also on a context whose buffers held other data before — and the remaining levels are unaffected."""
+    from conftest import random_image
+    from visual_odometry_amd import _lib
+    from visual_odometry_amd.frontend import FrontEnd
+    c = _lib.Context(0)
+    try:
+        big = FrontEnd(480, 640, max_frames=2, max_pairs=1, nfeatures=1000, ctx=c)         # leaves counts and lists in freed memory
+        big.upload(np.stack([random_image(1, 480, 640), random_image(2, 480, 640)])); big.detect(0, 2)
+        img = random_image(w * 31 + h, h, w)
+        p = oracle.orb_params(nfeatures=300, nlevels=nlevels)
+        want = oracle.orb_detect_and_compute(img, p)
+        for order in ("cv2", "canonical"):
+            if order == "canonical":
+                oracle.set_keypoint_order("canonical"); want = oracle.orb_detect_and_compute(img, p)
+            fe = FrontEnd(h, w, max_frames=2, max_pairs=1, nfeatures=300, nlevels=nlevels, ctx=c, keypoint_order=order)
+            fe.upload(np.stack([img, img])); fe.detect(0, 2)
+            for slot in range(2):
+                got = fe.features(slot)
+                for k in ("xy", "octave", "response", "angle", "desc"):
+                    assert np.array_equal(got[k], want[k]), (order, slot, k)
+    finally:
+        oracle.set_keypoint_order("cv2")
+        c.close()

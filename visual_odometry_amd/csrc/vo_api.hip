@@ -681,6 +681,11 @@ static int run_detect(vo_ctx* ctx, int first_slot, int F, int upto)
         StageTimer t(ctx, ST_MISC);
         HIPCHK(hipMemsetAsync(ff.hist, 0, (size_t)F * VO_MAX_LEVELS * 256 * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ff.flags, 0, (size_t)F * sizeof(int), s));
+        // a level too small to hold a keypoint (narrower than two border widths) has no FAST tiles and no selection chunk: nobody
+        // would write its candidate count
+        HIPCHK(hipMemsetAsync(ff.cand_count, 0, (size_t)F * VO_MAX_LEVELS * sizeof(int), s));
+        if (ctx->kp_order == 1 && ctx->cv2_ready)
+            HIPCHK(hipMemsetAsync(ctx->cv2.all_count + (size_t)first_slot * VO_MAX_LEVELS, 0, (size_t)F * VO_MAX_LEVELS * sizeof(int), s));
     }
     { StageTimer t(ctx, ST_FAST); launch_fast(s, pyr, score, ff.hist, g, F, upto < 2 ? nullptr : ff.tile_list, ff.tile_count); }
     if (upto < 2) return VO_OK;
